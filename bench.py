@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the DHD-S view-transform hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+One "step" = one pass of the hot path over one batch of synthetic input resident in HBM:
+    MGHS : height argmax -> band, context re-layout, geometry + grouping (prepare),
+           4-grid pooling forward (bev + low/mid/high), pooling backward (depth/context grads)
+    SFA  : attention stage forward + backward on cat[x_2d, x_3d] (B,512,200,200)
+at the DHD-S shapes of projects/configs/DHD/DHD-S.py (6 cameras 256x704 -> 16x44 features,
+D=44, C=64, grids 200x200x{1,4,4,8}, samples_per_gpu=4).  Samples are independent, so ranks
+shard them with no data-path collective ("weak" scaling); rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline     : achieved HBM GB/s of the dominant kernel (mghs_pool_fwd), algorithmic bytes
+                  / mean launch duration from HIP events on the launch stream
+  cpu_baseline : the CPU oracle (numpy MGHS + torch-CPU SFA stage) timed on this box's host cores
+                 on a small sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dhd_amd import _lib, mghs_op, synthetic as syn  # noqa: E402
+from dhd_amd.mix import channel_spatial_stage  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=50)
+    p.add_argument('--warmup', type=int, default=10)
+    p.add_argument('--batch', type=int, default=4, help='samples per GPU (DHD-S.py:243 samples_per_gpu=4)')
+    p.add_argument('--no-sfa', action='store_true', help='time the MGHS part only')
+    p.add_argument('--cpu-samples', type=int, default=2, help='samples for the CPU baseline leg (0 = skip)')
+    return p.parse_args()
+
+
+class HotPath:
+    """Device-resident inputs + the exact C-ABI call sequence of MGHS.view_transform fwd/bwd."""
+
+    def __init__(self, dev, batch, seed, with_sfa):
+        self.dev, self.B = dev, batch
+        cfg = self.cfg = syn.dhd_s_config()
+        N, D, fh, fw, C = 6, 44, 16, 44, 64
+        self.calib_np = syn.make_calibration(seed, batch, N, cfg['input_size'])
+        depth, feat, hidx = syn.lift_inputs(seed + 1, batch, N, D, fh, fw, C, 65)
+        self.inputs_np = (depth, feat, hidx)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        u = torch.linspace(0, 703, fw, dtype=torch.float)
+        v = torch.linspace(0, 255, fh, dtype=torch.float)
+        d = torch.arange(1.0, 45.0, 1.0, dtype=torch.float)
+        s2e, _, intrin, post_rot, post_tran, bda = [t(a) for a in self.calib_np]
+        self.calib, self._keep = mghs_op.make_calib(s2e, intrin, post_rot, post_tran, bda,
+                                                    (u.to(dev), v.to(dev), d.to(dev)))
+        full = {'x': [-40, 40, 0.4], 'y': [-40, 40, 0.4], 'z': [-1, 5.4, 6.4]}
+        grids = [mghs_op.grid_from_cfg(g) for g in (full, cfg['mask_1_grid'], cfg['mask_2_grid'], cfg['mask_3_grid'])]
+        self.plan = mghs_op.Plan(batch, N, D, fh, fw, C, grids)
+        self.depth, self.feat = t(depth), t(feat)
+        self.height = t(syn.height_probs_from_index(hidx, 65))
+        self.ws = self.plan.new_workspace(dev)
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        self.out_grads = [torch.randn(s, generator=g).to(dev) for s in self.plan.out_shapes()]
+        self.with_sfa = with_sfa
+        if with_sfa:
+            torch.manual_seed(seed)
+            self.stage = channel_spatial_stage(512).to(dev).train()
+            self.x = torch.randn(batch, 512, 200, 200, generator=g).to(dev).requires_grad_()
+            self.gy = torch.randn(batch, 256, 200, 200, generator=g).to(dev)
+        self.ev = []  # (start, end) HIP events around the dominant kernel, one pair per timed step
+        # algorithmic bytes of one pooling-forward launch (fused form):
+        #   dense outputs written once + depth read once + context read once
+        self.pool_fwd_bytes = batch * (4 * C * 17 * 200 * 200 + 4 * N * D * fh * fw + 4 * N * fh * fw * C)
+
+    def step(self, record):
+        cfg = self.cfg
+        band = mghs_op.height_band(self.height, cfg['height_range'], cfg['mask_range'])
+        feat_nhwc = mghs_op._nchw_to_nhwc(self.feat)
+        mghs_op.prepare(self.plan, self.calib, band, self.ws)
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        outs = mghs_op.pool_forward(self.plan, self.depth, feat_nhwc, self.ws)
+        if record:
+            e1.record()
+            self.ev.append((e0, e1))
+        dg, fg = mghs_op.pool_backward(self.plan, self.depth, feat_nhwc, self.out_grads, self.ws)
+        fg_nchw = mghs_op._nhwc_to_nchw(fg)
+        if self.with_sfa:
+            self.x.grad = None
+            y = self.stage(self.x)
+            y.backward(self.gy)
+        return outs, dg, fg_nchw
+
+
+def cpu_baseline(hp, n_samples):
+    """Oracle timing on the host: numpy MGHS view_transform fwd+bwd (the reference's op sequence,
+    4x geometry + 4x sort + pool + permute) and, for the SFA stage, the reference formula in
+    torch-CPU fp32 with all host threads."""
+    from oracle import mghs_oracle as O  # checker / baseline only
+    cfg = hp.cfg
+    n = min(n_samples, hp.B)
+    calib = [a[:n] for a in hp.calib_np]
+    depth, feat, hidx = (a[:n * 6] for a in hp.inputs_np)
+    t0 = time.perf_counter()
+    outs = O.view_transform(cfg, calib, depth, feat, hidx)
+    gr = [np.ones_like(o) for o in outs]
+    O.view_transform_backward(cfg, calib, depth, feat, hidx, gr)
+    t_mghs = time.perf_counter() - t0
+    t_sfa = 0.0
+    if hp.with_sfa:
+        torch.set_num_threads(os.cpu_count())
+        st = channel_spatial_stage(512)
+        x = torch.randn(n, 512, 200, 200, requires_grad=True)
+        t0 = time.perf_counter()
+        xb, xv = torch.split(x, 256, dim=1)
+        a1 = st.fc(x.mean(-1).mean(-1))[:, :, None, None]
+        xb1, xv1 = a1 * xb, (1 - a1) * xv
+        a2 = torch.sigmoid(st.spacial_leanring(xb1 + xv1))
+        (a2 * xb1 + (1 - a2) * xv1).sum().backward()
+        t_sfa = time.perf_counter() - t0
+    return dict(value=n / (t_mghs + t_sfa), unit='samples/s', cores=os.cpu_count(), kind='port',
+                sample=f'{n} sample(s) of the same workload: oracle/mghs_oracle.py view_transform fwd+bwd '
+                       f'({t_mghs:.2f} s, numpy, mostly 1 thread)' +
+                       (f' + SFA stage fwd+bwd in torch-CPU fp32 ({t_sfa:.2f} s, {os.cpu_count()} threads)' if hp.with_sfa else ''))
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    _lib.load()
+    hp = HotPath(dev, a.batch, 1000 + rank, not a.no_sfa)
+
+    for _ in range(a.warmup):
+        hp.step(False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        hp.step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        kern_ms = float(np.mean([s.elapsed_time(e) for s, e in hp.ev]))
+        achieved = hp.pool_fwd_bytes / (kern_ms * 1e-3) / 1e9
+        line = dict(
+            metric='samples/sec (6-cam fwd+bwd) DHD-S view-transform hot path', value=a.batch * world * a.steps / elapsed,
+            unit='samples/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps,
+            higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+            config=dict(workload='DHD-S (configs[1]) hot path: MGHS 4-grid lift-splat fwd+bwd incl. geometry/grouping'
+                                 + ('' if a.no_sfa else ' + SFA attention stage fwd+bwd') +
+                                 '; 6 cams 256x704 -> 16x44, D=44, C=64, grids 200x200x{1,4,4,8}; dense backbone/encoder convs not in the step',
+                        samples_per_gpu=a.batch, global_batch=a.batch * world, parallelism=f'sample-sharded x{world}, no data-path collective'),
+            roofline=dict(bound='hbm', kernel='mghs_pool_fwd', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s',
+                          frac=achieved / HBM_PEAK_GBPS, traffic=None, launch_ms=kern_ms,
+                          algorithmic_bytes=hp.pool_fwd_bytes))
+        if world == 1 and a.cpu_samples > 0:
+            line['cpu_baseline'] = cpu_baseline(hp, a.cpu_samples)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

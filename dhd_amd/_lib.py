@@ -1,0 +1,116 @@
+"""ctypes binding of libdhd_amd.so (C ABI declared in include/dhd_amd.h).
+
+There is deliberately no fallback: if the HIP library is missing or a call fails, the
+error is raised to the caller.  `import torch` must precede the load so that the library
+binds to the HIP runtime PyTorch already mapped (same SONAME, libamdhip64.so.7).
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime first)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdhd_amd.so')
+
+DHD_MAX_GRIDS = 4
+ABI_VERSION = 1
+
+_ERRORS = {-1: 'DHD_EINVAL (bad argument)', -2: 'DHD_ENOSPACE (workspace too small)',
+           -3: 'DHD_EUNSUPPORTED (size outside supported range)'}
+
+
+class DhdError(RuntimeError):
+    pass
+
+
+class Grid(C.Structure):
+    _fields_ = [('lower', C.c_float * 3), ('interval', C.c_float * 3), ('size', C.c_float * 3),
+                ('n', C.c_int32 * 3)]
+
+
+class MghsDesc(C.Structure):
+    _fields_ = [('batch', C.c_int32), ('n_cams', C.c_int32), ('n_depth', C.c_int32),
+                ('fh', C.c_int32), ('fw', C.c_int32), ('channels', C.c_int32), ('n_grids', C.c_int32),
+                ('grid', Grid * DHD_MAX_GRIDS)]
+
+
+class Calib(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ('sensor2ego', 'intrin', 'post_rot', 'post_tran', 'bda', 'inv_post_rot', 'combine',
+                 'frustum_u', 'frustum_v', 'frustum_d')]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_PROTOTYPES = {
+    'dhd_abi_version': ([], _I),
+    'dhd_bev_pool_v2_forward': ([_P] * 8 + [_I, _I, _P], _I),
+    'dhd_bev_pool_v2_backward': ([_P] * 10 + [_I, _I, _P], _I),
+    'dhd_mghs_workspace_bytes': ([C.POINTER(MghsDesc), C.POINTER(C.c_size_t)], _I),
+    'dhd_height_band': ([_P, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P], _I),
+    'dhd_feat_nchw_to_nhwc': ([_P, _P, _I, _I, _I, _P], _I),
+    'dhd_feat_nhwc_to_nchw': ([_P, _P, _I, _I, _I, _P], _I),
+    'dhd_mghs_prepare': ([C.POINTER(MghsDesc), C.POINTER(Calib), _P, _P, C.c_size_t, _P], _I),
+    'dhd_mghs_forward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P], _I),
+    'dhd_mghs_backward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P, _P, _P], _I),
+    'dhd_mghs_voxel_index': ([C.POINTER(MghsDesc), C.POINTER(Calib), _I, _P, _P, _P], _I),
+    'dhd_mghs_stats': ([C.POINTER(MghsDesc), _P, C.POINTER(C.c_int32 * DHD_MAX_GRIDS),
+                        C.POINTER(C.c_int32 * DHD_MAX_GRIDS), _P], _I),
+    'dhd_sfa_channel_mean': ([_P, _P, _I, _I, _I, _P], _I),
+    'dhd_sfa_blend1': ([_P, _P, _P, _I, _I, _I, _P], _I),
+    'dhd_sfa_blend2': ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
+    'dhd_sfa_blend2_backward': ([_P] * 7 + [_I, _I, _I, _P], _I),
+    'dhd_sfa_blend1_backward': ([_P] * 5 + [_I, _I, _I, _P], _I),
+    'dhd_sfa_mean_backward': ([_P, _P, _I, _I, _I, _P], _I),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises DhdError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DhdError(
+            f'{LIB_PATH} not found: build it with `make -C dhd_amd/csrc` (or __graft_entry__.build()). '
+            'dhd_amd has no CPU or PyTorch fallback for its HIP kernels.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in _PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if lib.dhd_abi_version() != ABI_VERSION:
+        raise DhdError(f'libdhd_amd.so ABI {lib.dhd_abi_version()} != expected {ABI_VERSION}: rebuild')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise DhdError(f'{what}: {_ERRORS.get(rc, rc)}')
+    raise DhdError(f'{what}: hipError_t {rc}')
+
+
+def stream_ptr(device=None):
+    """The current PyTorch HIP stream as a void* for the C ABI."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def require_gpu_tensor(t, dtype, name):
+    if not t.is_cuda:
+        raise DhdError(f'{name} must live on the GPU: dhd_amd runs only as HIP kernels (got {t.device})')
+    if t.dtype != dtype:
+        raise DhdError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise DhdError(f'{name} must be contiguous')
+    return t

@@ -1,0 +1,228 @@
+"""Functional layer over the fused MGHS entry points of libdhd_amd.so (include/dhd_amd.h section 2).
+
+`mghs_pool` is the autograd-visible replacement for the reference's
+4x (get_ego_coor -> voxel_pooling_prepare_v2 -> bev_pool_v2 -> permute -> cat) chain,
+models/necks/lss_heightmap.py:380-459.  Gradients flow to `depth` and `tran_feat` only; the
+height branch enters through an argmax/bool mask and carries none (:434-442).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def grid_struct(lower, interval, size):
+    """dhd_grid from the three float32 triples MGHS.create_grid_infos produces (:99-102)."""
+    g = _lib.Grid()
+    for a in range(3):
+        g.lower[a] = float(lower[a])
+        g.interval[a] = float(interval[a])
+        g.size[a] = float(size[a])
+        g.n[a] = int(size[a])
+    return g
+
+
+def grid_from_cfg(cfg):
+    """Same arithmetic as create_grid_infos: python doubles, rounded to float32 by torch.Tensor."""
+    axes = [cfg[k] for k in ('x', 'y', 'z')]
+    lower = torch.Tensor([a[0] for a in axes])
+    interval = torch.Tensor([a[2] for a in axes])
+    size = torch.Tensor([(a[1] - a[0]) / a[2] for a in axes])
+    return grid_struct(lower.tolist(), interval.tolist(), size.tolist())
+
+
+class Plan:
+    """Static description of one view transform: sizes + grids (no device state)."""
+
+    def __init__(self, batch, n_cams, n_depth, fh, fw, channels, grids):
+        if not 1 <= len(grids) <= _lib.DHD_MAX_GRIDS:
+            raise ValueError('1..4 grids')
+        d = _lib.MghsDesc()
+        d.batch, d.n_cams, d.n_depth, d.fh, d.fw, d.channels = batch, n_cams, n_depth, fh, fw, channels
+        d.n_grids = len(grids)
+        for i in range(_lib.DHD_MAX_GRIDS):
+            d.grid[i] = grids[min(i, len(grids) - 1)]
+        self.desc = d
+        self.grids = list(grids)
+        nbytes = C.c_size_t(0)
+        _lib.check(_lib.load().dhd_mghs_workspace_bytes(C.byref(d), C.byref(nbytes)), 'dhd_mghs_workspace_bytes')
+        self.workspace_bytes = int(nbytes.value)
+
+    def out_shapes(self):
+        d = self.desc
+        return [(d.batch, g.n[2] * d.channels, g.n[1], g.n[0]) for g in self.grids]
+
+    def new_workspace(self, device):
+        return torch.empty(self.workspace_bytes, dtype=torch.uint8, device=device)
+
+
+def _f32(t, name):
+    return _lib.require_gpu_tensor(t.detach(), torch.float32, name)
+
+
+def make_calib(sensor2ego, intrin, post_rot, post_tran, bda, frustum_axes, inv_post_rot=None, combine=None):
+    """Pack device tensors into a dhd_calib.  Returns (struct, keepalive list)."""
+    u, v, d = frustum_axes
+    dev = sensor2ego.device
+    keep = []
+
+    def prep(t, name):
+        if t is None:
+            return None
+        t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        keep.append(t)
+        return _f32(t, name)
+
+    c = _lib.Calib()
+    for name, t in (('sensor2ego', sensor2ego), ('intrin', intrin), ('post_rot', post_rot),
+                    ('post_tran', post_tran), ('bda', bda), ('inv_post_rot', inv_post_rot),
+                    ('combine', combine), ('frustum_u', u), ('frustum_v', v), ('frustum_d', d)):
+        tt = prep(t, name)
+        setattr(c, name, tt.data_ptr() if tt is not None else None)
+    return c, keep
+
+
+def height_band(height, height_range, mask_range):
+    """(B*N, H, fH, fW) height distribution -> uint8 band id per pixel (0/1/2, 255 = none).
+    height_feature_to_height_map + create_mask_3, lss_heightmap.py:528-564."""
+    lib = _lib.load()
+    h = _f32(height.float().contiguous(), 'height')
+    bn, nh, fh, fw = h.shape
+    if nh != len(height_range):
+        raise ValueError('height has %d bins, height_range %d' % (nh, len(height_range)))
+    # float32 values exactly as torch.tensor(height_range) and the python-scalar comparisons see them
+    hr = (C.c_float * nh)(*torch.tensor(height_range, dtype=torch.float32).tolist())
+    mr = (C.c_float * 4)(*torch.tensor(list(mask_range), dtype=torch.float32).tolist())
+    band = torch.empty((bn, fh, fw), dtype=torch.uint8, device=h.device)
+    with torch.cuda.device(h.device):
+        rc = lib.dhd_height_band(_lib.ptr(h), bn, nh, fh, fw, hr, mr, _lib.ptr(band), _lib.stream_ptr(h.device))
+    _lib.check(rc, 'dhd_height_band')
+    return band
+
+
+def _nchw_to_nhwc(x):
+    lib = _lib.load()
+    bn, c, fh, fw = x.shape
+    out = torch.empty((bn, fh, fw, c), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.dhd_feat_nchw_to_nhwc(_lib.ptr(x), _lib.ptr(out), bn, c, fh * fw, _lib.stream_ptr(x.device))
+    _lib.check(rc, 'dhd_feat_nchw_to_nhwc')
+    return out
+
+
+def _nhwc_to_nchw(x):
+    lib = _lib.load()
+    bn, fh, fw, c = x.shape
+    out = torch.empty((bn, c, fh, fw), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.dhd_feat_nhwc_to_nchw(_lib.ptr(x), _lib.ptr(out), bn, c, fh * fw, _lib.stream_ptr(x.device))
+    _lib.check(rc, 'dhd_feat_nhwc_to_nchw')
+    return out
+
+
+def prepare(plan, calib, band, workspace):
+    lib = _lib.load()
+    dev = workspace.device
+    if band is not None:
+        _lib.require_gpu_tensor(band, torch.uint8, 'band')
+    with torch.cuda.device(dev):
+        rc = lib.dhd_mghs_prepare(C.byref(plan.desc), C.byref(calib), _lib.ptr(band), _lib.ptr(workspace),
+                                  workspace.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, 'dhd_mghs_prepare')
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * _lib.DHD_MAX_GRIDS)()
+    for i in range(_lib.DHD_MAX_GRIDS):
+        arr[i] = tensors[i].data_ptr() if i < len(tensors) else None
+    return arr
+
+
+def pool_forward(plan, depth, feat_nhwc, workspace):
+    lib = _lib.load()
+    dev = depth.device
+    outs = [torch.empty(s, dtype=torch.float32, device=dev) for s in plan.out_shapes()]
+    arr = _ptr_array(outs)
+    with torch.cuda.device(dev):
+        rc = lib.dhd_mghs_forward(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
+                                  _lib.ptr(workspace), _lib.stream_ptr(dev))
+    _lib.check(rc, 'dhd_mghs_forward')
+    return outs
+
+
+def pool_backward(plan, depth, feat_nhwc, out_grads, workspace):
+    lib = _lib.load()
+    dev = depth.device
+    depth_grad = torch.empty_like(depth)
+    feat_grad = torch.empty_like(feat_nhwc)
+    arr = _ptr_array(out_grads)
+    with torch.cuda.device(dev):
+        rc = lib.dhd_mghs_backward(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
+                                   _lib.ptr(depth_grad), _lib.ptr(feat_grad), _lib.ptr(workspace),
+                                   _lib.stream_ptr(dev))
+    _lib.check(rc, 'dhd_mghs_backward')
+    return depth_grad, feat_grad
+
+
+class _MGHSPool(torch.autograd.Function):
+    """depth (B*N,D,fH,fW), tran_feat (B*N,C,fH,fW) -> one (B, nz*C, ny, nx) tensor per grid."""
+
+    @staticmethod
+    def forward(ctx, depth, tran_feat, plan, workspace):
+        depth = _lib.require_gpu_tensor(depth.float().contiguous(), torch.float32, 'depth')
+        tran_feat = _lib.require_gpu_tensor(tran_feat.float().contiguous(), torch.float32, 'tran_feat')
+        feat_nhwc = _nchw_to_nhwc(tran_feat)
+        outs = pool_forward(plan, depth, feat_nhwc, workspace)
+        ctx.plan = plan
+        ctx.save_for_backward(depth, feat_nhwc, workspace)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        depth, feat_nhwc, workspace = ctx.saved_tensors
+        plan = ctx.plan
+        gs = []
+        for g, shape in zip(grads, plan.out_shapes()):
+            if g is None:
+                g = torch.zeros(shape, dtype=torch.float32, device=depth.device)
+            gs.append(g.float().contiguous())
+        depth_grad, feat_grad_nhwc = pool_backward(plan, depth, feat_nhwc, gs, workspace)
+        return depth_grad, _nhwc_to_nchw(feat_grad_nhwc), None, None
+
+
+def mghs_pool(plan, calib, band, depth, tran_feat, workspace=None):
+    """Prepare (geometry + grouping) and pool.  `workspace` may be passed to reuse memory in
+    inference; under autograd a fresh one is held by the graph until backward has run."""
+    if workspace is None:
+        workspace = plan.new_workspace(depth.device)
+    prepare(plan, calib, band, workspace)
+    return _MGHSPool.apply(depth, tran_feat, plan, workspace)
+
+
+def voxel_index(plan, calib, grid_index, want_ego=False):
+    """Per-point voxel rank of one grid (-1 = dropped) and optionally the ego coordinates
+    (B,N,D,fH,fW,3): the device twin of lss_heightmap.py:179-231 + :329-354, for parity checks and
+    for the voxel_pooling_prepare_v2 mirror."""
+    lib = _lib.load()
+    d = plan.desc
+    dev = torch.device('cuda', torch.cuda.current_device())
+    npts = d.batch * d.n_cams * d.n_depth * d.fh * d.fw
+    rank = torch.empty(npts, dtype=torch.int32, device=dev)
+    ego = torch.empty((d.batch, d.n_cams, d.n_depth, d.fh, d.fw, 3), dtype=torch.float32, device=dev) if want_ego else None
+    rc = lib.dhd_mghs_voxel_index(C.byref(d), C.byref(calib), grid_index, _lib.ptr(rank), _lib.ptr(ego),
+                                  _lib.stream_ptr(dev))
+    _lib.check(rc, 'dhd_mghs_voxel_index')
+    return rank, ego
+
+
+def stats(plan, workspace):
+    lib = _lib.load()
+    kept = (C.c_int32 * _lib.DHD_MAX_GRIDS)()
+    ivs = (C.c_int32 * _lib.DHD_MAX_GRIDS)()
+    with torch.cuda.device(workspace.device):
+        rc = lib.dhd_mghs_stats(C.byref(plan.desc), _lib.ptr(workspace), C.byref(kept), C.byref(ivs),
+                                _lib.stream_ptr(workspace.device))
+    _lib.check(rc, 'dhd_mghs_stats')
+    n = plan.desc.n_grids
+    return list(kept)[:n], list(ivs)[:n]

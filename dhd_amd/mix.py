@@ -1,0 +1,128 @@
+"""SFA (dual-feature aggregation) with the reference's registry name, constructor and state-dict
+keys (projects/mmdet3d_plugin/models/necks/mix.py: channel_spatial_stage :8-59, SFA :61-90).
+
+The attention stage is memory-bound: in eager PyTorch it is one reduction plus ~6 element-wise
+passes over (B,256..512,200,200) tensors.  Here the reduction and the two convex blends are HIP
+kernels (csrc/sfa.hip) driven by ONE autograd node, so forward touches x three times and backward
+writes dL/dx into a single buffer instead of summing three full-size partial gradients.  The tiny
+fc and the two 1x1 conv + BatchNorm layers in between stay ordinary PyTorch modules (dense, MFMA
+library path); their parameter gradients are produced by replaying their own sub-graphs inside the
+node's backward.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .registry import NECKS
+
+
+def _call(fn_name, *args):
+    lib = _lib.load()
+    _lib.check(getattr(lib, fn_name)(*args), fn_name)
+
+
+class _AttentionStage(torch.autograd.Function):
+    """x (B,2C,H,W) -> x_fuse (B,C,H,W); `stage` owns fc / spacial_leanring."""
+
+    @staticmethod
+    def forward(ctx, x, stage, *params):
+        x = _lib.require_gpu_tensor(x.float().contiguous(), torch.float32, 'SFA input')
+        if x.data_ptr() % 16:
+            x = x.clone()
+        b, c2, h, w = x.shape
+        c, hw = c2 // 2, h * w
+        dev = x.device
+        st = _lib.stream_ptr(dev)
+        # Function.forward runs with grad mode off; the inner modules are recorded explicitly
+        build_graph = any(ctx.needs_input_grad)
+        with torch.cuda.device(dev):
+            s = torch.empty((b, c2), dtype=torch.float32, device=dev)
+            _call('dhd_sfa_channel_mean', _lib.ptr(x), _lib.ptr(s), b, c2, hw, st)
+            with torch.set_grad_enabled(build_graph):
+                s_in = s.requires_grad_(build_graph)
+                a1 = stage.fc(s_in)  # (B, C), post-sigmoid (mix.py:43)
+            a1d = a1.detach().contiguous()
+            u = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
+            _call('dhd_sfa_blend1', _lib.ptr(x), _lib.ptr(a1d), _lib.ptr(u), b, c, hw, st)
+            with torch.set_grad_enabled(build_graph):
+                u_in = u.requires_grad_(build_graph)
+                s2 = stage.spacial_leanring(u_in)  # pre-sigmoid attention_2 (mix.py:51)
+            s2d = s2.detach().contiguous()
+            out = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
+            _call('dhd_sfa_blend2', _lib.ptr(x), _lib.ptr(a1d), _lib.ptr(s2d), _lib.ptr(out), b, c, hw, st)
+        if build_graph:
+            ctx.inner = (s_in, a1, u_in, s2)
+            ctx.fc_params = [p for p in stage.fc.parameters() if p.requires_grad]
+            ctx.sp_params = [p for p in stage.spacial_leanring.parameters() if p.requires_grad]
+            ctx.save_for_backward(x, a1d, s2d)
+            ctx.dims = (b, c, hw)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, a1d, s2d = ctx.saved_tensors
+        s_in, a1, u_in, s2 = ctx.inner
+        b, c, hw = ctx.dims
+        dev = x.device
+        st = _lib.stream_ptr(dev)
+        go = go.float().contiguous()
+        with torch.cuda.device(dev):
+            gx = torch.empty_like(x)
+            gs2 = torch.empty_like(s2d)
+            ga1 = torch.empty((b, c), dtype=torch.float32, device=dev)
+            _call('dhd_sfa_blend2_backward', _lib.ptr(x), _lib.ptr(a1d), _lib.ptr(s2d), _lib.ptr(go), _lib.ptr(gx),
+                  _lib.ptr(gs2), _lib.ptr(ga1), b, c, hw, st)
+            # 1x1 conv / BN branch: parameter grads accumulate into .grad, dL/du comes back in u_in.grad
+            torch.autograd.backward([s2], [gs2], inputs=[u_in] + ctx.sp_params)
+            gu = u_in.grad.contiguous()
+            u_in.grad = None
+            _call('dhd_sfa_blend1_backward', _lib.ptr(x), _lib.ptr(a1d), _lib.ptr(gu), _lib.ptr(gx), _lib.ptr(ga1),
+                  b, c, hw, st)
+            torch.autograd.backward([a1], [ga1], inputs=[s_in] + ctx.fc_params)
+            gs = s_in.grad.contiguous()
+            s_in.grad = None
+            _call('dhd_sfa_mean_backward', _lib.ptr(gs), _lib.ptr(gx), b, 2 * c, hw, st)
+        ctx.inner = None
+        return (gx, None) + (None,) * len(ctx.needs_input_grad[2:])
+
+
+class channel_spatial_stage(nn.Module):
+    def __init__(self, features):
+        """features: channels of cat[x_bev, x_voxel] (mix.py:9-35)."""
+        super().__init__()
+        reduction = 16
+        self.channels = features // 2
+        self.fc = nn.Sequential(nn.Linear(features, features // reduction), nn.ReLU(inplace=False),
+                                nn.Linear(features // reduction, self.channels), nn.Sigmoid())
+        self.spacial_leanring = nn.Sequential(
+            nn.Conv2d(self.channels, self.channels, kernel_size=1, stride=1, padding=0),
+            nn.BatchNorm2d(self.channels), nn.ReLU(inplace=True),
+            nn.Conv2d(self.channels, self.channels, kernel_size=1, stride=1, padding=0),
+            nn.BatchNorm2d(self.channels))
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        params = list(self.fc.parameters()) + list(self.spacial_leanring.parameters())
+        return _AttentionStage.apply(x, self, *params)
+
+
+@NECKS.register_module()
+class SFA(nn.Module):
+    def __init__(self, in_channels, out_channels, stride=1):
+        super().__init__()
+        self.mysk_7 = channel_spatial_stage(features=in_channels)
+        self.mix_channels = in_channels
+        self.out_channels = out_channels
+        self.mix_residual = nn.Sequential(
+            nn.Conv2d(in_channels // 2, out_channels, kernel_size=3, stride=stride, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True),
+            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels))
+        self.mix_shortcut = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, stride=stride, kernel_size=1, bias=False),
+            nn.BatchNorm2d(out_channels))
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, inputs):
+        fused = self.mysk_7(inputs)
+        return self.relu(self.mix_residual(fused) + self.mix_shortcut(inputs))

@@ -1,0 +1,200 @@
+/*
+ * dhd_amd.h -- C ABI of libdhd_amd.so: the MI355X (gfx950) implementation of DHD's
+ * height-decoupled LSS view transform (MGHS) and SFA attention stage.
+ *
+ * Conventions
+ *   - Every pointer marked [dev] is device (HBM) memory owned by the caller; the library
+ *     never allocates, frees or copies.  Scratch lives in one caller-provided workspace.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream, which is
+ *     what the reference's launches use: ops/bev_pool_v2/src/bev_pool_cuda.cu:129,138).
+ *     All work is enqueued asynchronously on it; nothing synchronises.
+ *   - Return value: 0 on success, a positive hipError_t if a launch failed, or one of the
+ *     negative DHD_E* codes for argument errors.  (The reference validates nothing and
+ *     returns void: ops/bev_pool_v2/src/bev_pool.cpp:30-57.)
+ *   - All floating point data is float32, all indices int32, exactly as in the reference
+ *     (ops/bev_pool_v2/bev_pool.py:19-25).
+ *
+ * File:line citations are into /root/reference/projects/mmdet3d_plugin/.
+ */
+#ifndef DHD_AMD_H
+#define DHD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DHD_OK 0
+#define DHD_EINVAL (-1)     /* null pointer / non-positive size / inconsistent sizes */
+#define DHD_ENOSPACE (-2)   /* workspace too small */
+#define DHD_EUNSUPPORTED (-3)
+
+#define DHD_ABI_VERSION 1
+int dhd_abi_version(void);
+
+/* ------------------------------------------------------------------------------------ *
+ * 1. Operator-level drop-in: the two entry points of the reference's pybind extension.
+ * ------------------------------------------------------------------------------------ */
+
+/* Replaces bev_pool_v2_forward (ops/bev_pool_v2/src/bev_pool.cpp:30-57 -> kernel
+ * bev_pool_cuda.cu:21-50).  Same argument meaning and order of the index arrays
+ * (interval_lengths BEFORE interval_starts).  `out` is (B,Dz,Dy,Dx,C), must be pre-zeroed by
+ * the caller (bev_pool.py:27) and is written in place: for every interval i,
+ *   out[ranks_bev[start_i]*c + ch] = sum_k feat[ranks_feat[start_i+k]*c + ch] * depth[ranks_depth[start_i+k]]. */
+int dhd_bev_pool_v2_forward(const float* depth,            /* [dev] (B,N,D,fH,fW)     */
+                            const float* feat,             /* [dev] (B,N,fH,fW,C)     */
+                            float* out,                    /* [dev] (B,Dz,Dy,Dx,C)    */
+                            const int32_t* ranks_depth,    /* [dev] (n_points)        */
+                            const int32_t* ranks_feat,     /* [dev] (n_points)        */
+                            const int32_t* ranks_bev,      /* [dev] (n_points)        */
+                            const int32_t* interval_lengths, /* [dev] (n_intervals)   */
+                            const int32_t* interval_starts,  /* [dev] (n_intervals)   */
+                            int c, int n_intervals, void* stream);
+
+/* Replaces bev_pool_v2_backward (bev_pool.cpp:74-104 -> kernel bev_pool_cuda.cu:69-123).
+ * Intervals are those of the points re-grouped by ranks_feat (bev_pool.py:47-57); depth_grad
+ * and feat_grad are pre-zeroed by the caller (bev_pool.py:67-68).  out_grad is (B,Dz,Dy,Dx,C). */
+int dhd_bev_pool_v2_backward(const float* out_grad, float* depth_grad, float* feat_grad,
+                             const float* depth, const float* feat,
+                             const int32_t* ranks_depth, const int32_t* ranks_feat,
+                             const int32_t* ranks_bev,
+                             const int32_t* interval_lengths_bp, const int32_t* interval_starts_bp,
+                             int c, int n_intervals_bp, void* stream);
+
+/* ------------------------------------------------------------------------------------ *
+ * 2. Fused MGHS view transform (replaces the 4x get_ego_coor + 4x voxel_pooling_prepare_v2
+ *    + 4x bev_pool_v2 + permute + cat chain of models/necks/lss_heightmap.py:380-459).
+ * ------------------------------------------------------------------------------------ */
+
+#define DHD_MAX_GRIDS 4
+
+/* One voxel grid (MGHS.create_grid_infos, lss_heightmap.py:86-102): float32 lower bound,
+ * interval and size per axis (x,y,z), computed by the caller exactly as the reference does
+ * (python double arithmetic, then float32), plus the integer extents n = int(size). */
+typedef struct dhd_grid {
+  float lower[3];
+  float interval[3];
+  float size[3];
+  int32_t n[3]; /* nx, ny, nz */
+} dhd_grid;
+
+/* Problem description shared by prepare / forward / backward. */
+typedef struct dhd_mghs_desc {
+  int32_t batch;    /* B                                   */
+  int32_t n_cams;   /* N                                   */
+  int32_t n_depth;  /* D  (frustum depth bins)             */
+  int32_t fh, fw;   /* feature map                          */
+  int32_t channels; /* C  (context channels)               */
+  int32_t n_grids;  /* 1..4; grid 0 pools every pixel, grid k>=1 pools pixels of band k-1 */
+  dhd_grid grid[DHD_MAX_GRIDS];
+} dhd_mghs_desc;
+
+/* Camera calibration, all [dev] float32, laid out as the reference's input list
+ * (lss_heightmap.py:384-390).  inv_post_rot / combine are OPTIONAL (may be NULL): when given they
+ * are used instead of the library's own 3x3 inverse (so a caller can inject the matrices
+ * torch.inverse produced, lss_heightmap.py:209,220); when NULL they are derived on the device
+ * with LU + partial pivoting in float32 (the LAPACK algorithm the reference reaches through
+ * torch.inverse). */
+typedef struct dhd_calib {
+  const float* sensor2ego;   /* (B,N,4,4) */
+  const float* intrin;       /* (B,N,3,3) */
+  const float* post_rot;     /* (B,N,3,3) */
+  const float* post_tran;    /* (B,N,3)   */
+  const float* bda;          /* (B,3,3)   */
+  const float* inv_post_rot; /* (B,N,3,3) or NULL */
+  const float* combine;      /* (B,N,3,3) or NULL: sensor2ego[:3,:3] @ inv(intrin) */
+  const float* frustum_u;    /* (fW)  MGHS.create_frustum axes, lss_heightmap.py:105-134 */
+  const float* frustum_v;    /* (fH) */
+  const float* frustum_d;    /* (D)  */
+} dhd_calib;
+
+/* Bytes of workspace needed by dhd_mghs_prepare/forward/backward for `desc`. */
+int dhd_mghs_workspace_bytes(const dhd_mghs_desc* desc, size_t* bytes);
+
+/* Height argmax -> band id per pixel (height_feature_to_height_map + create_mask_3,
+ * lss_heightmap.py:528-564).  height is (B*N, H, fH, fW) (probabilities or logits: only the
+ * argmax matters, first index on ties as torch.argmax); height_range is H host floats;
+ * mask_range = {h_min, thr1, thr2, h_max} host floats.  band[p] = 0/1/2, or 255 if the pixel's
+ * height is in no band. */
+int dhd_height_band(const float* height /*[dev]*/, int bn, int n_height, int fh, int fw,
+                    const float* height_range /*host*/, const float* mask_range /*host*/,
+                    uint8_t* band /*[dev] (B*N,fH,fW)*/, void* stream);
+
+/* (B*N, C, fH, fW) -> (B*N, fH, fW, C) and back (the reference's feat.permute(0,1,3,4,2) at
+ * lss_heightmap.py:290, made contiguous at bev_pool.py:21). */
+int dhd_feat_nchw_to_nhwc(const float* src, float* dst, int bn, int c, int hw, void* stream);
+int dhd_feat_nhwc_to_nchw(const float* src, float* dst, int bn, int c, int hw, void* stream);
+
+/* Geometry + index preparation (get_ego_coor lss_heightmap.py:179-231 and
+ * voxel_pooling_prepare_v2 :303-371 for all grids at once): computes every frustum point's
+ * voxel in each grid with the reference's float32 operation order and truncation rule, and
+ * groups the kept points by voxel (device counting sort; order inside a voxel is unspecified,
+ * as with the reference's unstable argsort, :355).  `band` is the per-pixel band id from
+ * dhd_height_band (ignored when n_grids == 1; may then be NULL).  The result stays in
+ * `workspace` and is consumed by dhd_mghs_forward / dhd_mghs_backward until the next prepare. */
+int dhd_mghs_prepare(const dhd_mghs_desc* desc, const dhd_calib* calib, const uint8_t* band,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Pooling forward for all grids.  depth (B*N,D,fH,fW); feat_nhwc (B*N,fH,fW,C).
+ * out[g] is the FINAL reference layout (B, nz_g*C, ny_g, nx_g) with channel = z*C + c
+ * (bev_pool.py:105 permute + lss_heightmap.py:298-299 collapse_z; identical memory to the
+ * un-collapsed (B,C... ) no: to (B,nz,C,ny,nx)).  Every element is written (zeros included);
+ * no pre-zeroing needed. */
+int dhd_mghs_forward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                     float* const out[DHD_MAX_GRIDS], const void* workspace, void* stream);
+
+/* Pooling backward.  out_grad[g] has the layout of out[g].  depth_grad (B*N,D,fH,fW) and
+ * feat_grad_nhwc (B*N,fH,fW,C) are fully overwritten (zero-filled internally).  Pixels outside
+ * a band contribute nothing to that band's grid, matching d(tran_feat * mask), :436-442. */
+int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                      const float* const out_grad[DHD_MAX_GRIDS], float* depth_grad,
+                      float* feat_grad_nhwc, const void* workspace, void* stream);
+
+/* Introspection for parity tests and for the voxel_pooling_prepare_v2 mirror: per-point voxel
+ * rank of ONE grid for every frustum point, -1 if dropped (band-independent), i.e. the map
+ * point -> ranks_bev of lss_heightmap.py:329-354.  rank_map is [dev] (B*N*D*fH*fW) int32.
+ * ego (optional, may be NULL) receives the (B,N,D,fH,fW,3) coordinates of get_ego_coor. */
+int dhd_mghs_voxel_index(const dhd_mghs_desc* desc, const dhd_calib* calib, int grid_index,
+                         int32_t* rank_map, float* ego, void* stream);
+
+/* Number of pooled (point, grid) pairs of the last prepare, per grid: n_kept[g] points,
+ * n_intervals[g] non-empty voxels.  Reads back from the workspace: synchronises `stream`. */
+int dhd_mghs_stats(const dhd_mghs_desc* desc, const void* workspace, int32_t n_kept[DHD_MAX_GRIDS],
+                   int32_t n_intervals[DHD_MAX_GRIDS], void* stream);
+
+/* ------------------------------------------------------------------------------------ *
+ * 3. SFA channel/spatial attention stage (models/necks/mix.py:37-59), memory-bound parts.
+ *    x is (B, 2C, H, W): channels [0,C) = x_bev, [C,2C) = x_voxel.
+ * ------------------------------------------------------------------------------------ */
+
+/* fea_S = x.mean(-1).mean(-1)  (mix.py:41) -> s (B, 2C). */
+int dhd_sfa_channel_mean(const float* x, float* s, int b, int c2, int hw, void* stream);
+
+/* fea_U_1 = a1*x_bev + (1-a1)*x_voxel  (mix.py:46-50); a1 is (B,C) post-sigmoid. */
+int dhd_sfa_blend1(const float* x, const float* a1, float* u, int b, int c, int hw, void* stream);
+
+/* x_fuse = sigmoid(s2)*(a1*x_bev) + (1-sigmoid(s2))*((1-a1)*x_voxel)  (mix.py:53-58);
+ * s2 = spacial_leanring(fea_U_1) pre-sigmoid, (B,C,H,W). */
+int dhd_sfa_blend2(const float* x, const float* a1, const float* s2, float* out, int b, int c,
+                   int hw, void* stream);
+
+/* Backward of blend2 and blend1 together.  Inputs: go = dL/dx_fuse, gu = dL/dfea_U_1 (from the
+ * 1x1-conv branch).  Outputs: gx (B,2C,H,W) = dL/dx through both blends (the mean path is added
+ * by dhd_sfa_mean_backward), gs2 (B,C,H,W) = dL/ds2, ga1 (B,C) = dL/da1.
+ * Two entry points because gs2 is needed before gu exists:
+ *   dhd_sfa_blend2_backward: go -> gs2, and the blend2 part of gx / ga1 (ga1 zero-initialised here)
+ *   dhd_sfa_blend1_backward: gu -> accumulates into gx / ga1. */
+int dhd_sfa_blend2_backward(const float* x, const float* a1, const float* s2, const float* go,
+                            float* gx, float* gs2, float* ga1, int b, int c, int hw, void* stream);
+int dhd_sfa_blend1_backward(const float* x, const float* a1, const float* gu, float* gx,
+                            float* ga1, int b, int c, int hw, void* stream);
+
+/* gx[b,ch,:] += gs[b,ch] / hw   (backward of the channel mean). */
+int dhd_sfa_mean_backward(const float* gs, float* gx, int b, int c2, int hw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DHD_AMD_H */

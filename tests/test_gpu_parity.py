@@ -1,0 +1,382 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference goldens.
+Everything here needs a real MI355X:  python -m pytest tests -m gpu"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, golden_calib, small_dhds_cfg
+from dhd_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def grid_cfgs(cfg):
+    from dhd_amd.lss_heightmap import _FULL_GRID
+    return [dict(_FULL_GRID), cfg['mask_1_grid'], cfg['mask_2_grid'], cfg['mask_3_grid']]
+
+
+def make_plan(cfg, batch, n_cams, channels=None, n_grids=4):
+    from dhd_amd import mghs_op
+    from oracle import mghs_oracle as O
+    axes = O.frustum_axes(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    fh, fw = cfg['input_size'][0] // cfg['downsample'], cfg['input_size'][1] // cfg['downsample']
+    grids = [mghs_op.grid_from_cfg(g) for g in grid_cfgs(cfg)[:n_grids]]
+    plan = mghs_op.Plan(batch, n_cams, len(axes[2]), fh, fw, channels or cfg['out_channels'], grids)
+    return plan, axes
+
+
+def device_calib(calib, axes, dev, inv_post_rot=None, combine=None):
+    from dhd_amd import mghs_op
+    s2e, _, intrin, post_rot, post_tran, bda = [T(a, dev) for a in calib]
+    return mghs_op.make_calib(s2e, intrin, post_rot, post_tran, bda, tuple(T(a, dev) for a in axes),
+                              None if inv_post_rot is None else T(inv_post_rot, dev),
+                              None if combine is None else T(combine, dev))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# --------------------------------------------------------------------------- operator seam
+
+def test_reference_known_answer_test(gpu):
+    """ops/bev_pool_v2/bev_pool.py:163-194, verbatim values, through the reference's signature."""
+    from dhd_amd import bev_pool_v2
+    depth = torch.tensor([0.3, 0.4, 0.2, 0.1, 0.7, 0.6, 0.8, 0.9], device=gpu).view(1, 1, 2, 2, 2).requires_grad_()
+    feat = torch.ones(1, 1, 2, 2, 2, device=gpu).requires_grad_()
+    rd = torch.tensor([0, 4, 1, 6], device=gpu).int()
+    rf = torch.tensor([0, 0, 1, 2], device=gpu).int()
+    rb = torch.tensor([0, 0, 1, 1], device=gpu).int()
+    st = torch.tensor([0, 2], device=gpu).int()
+    ln = torch.tensor([2, 2], device=gpu).int()
+    out = bev_pool_v2(depth, feat, rd, rf, rb, (1, 1, 2, 2, 2), st, ln)
+    assert out.shape == (1, 2, 1, 2, 2)
+    loss = out.sum()
+    loss.backward()
+    assert abs(loss.item() - 4.4) < 1e-6
+    assert torch.allclose(depth.grad.flatten().cpu(), torch.tensor([2., 2., 0., 0., 2., 0., 2., 0.]))
+    assert torch.allclose(feat.grad.flatten().cpu(), torch.tensor([1., 1., .4, .4, .8, .8, 0., 0.]))
+
+
+@pytest.mark.parametrize('channels', [1, 8, 24, 64, 80, 128])
+def test_bev_pool_v2_operator_vs_oracle(gpu, channels):
+    """Operator seam with the golden's canonical index lists (full grid of g2b), any channel count."""
+    from dhd_amd import bev_pool_v2
+    from oracle import mghs_oracle as O
+    g = golden('g2b_small_dhds')
+    rb, rd, rf, st, ln = (g[n + '0'] for n in ('ranks_bev', 'ranks_depth', 'ranks_feat', 'interval_starts', 'interval_lengths'))
+    B, N, D, fh, fw = 2, 2, 44, 4, 11
+    depth = g['depth'].reshape(B, N, D, fh, fw)
+    feat = syn.hash_signed(900 + channels, (B, N, fh, fw, channels))
+    shape = (B, 1, 200, 200, channels)
+    ref = O.bev_pool_v2(depth, feat, rd, rf, rb, shape, st, ln)
+    dt, ft = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+    out = bev_pool_v2(dt, ft, T(rd, gpu), T(rf, gpu), T(rb, gpu), shape, T(st, gpu), T(ln, gpu))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=2e-6, rtol=1e-6)
+    w = syn.hash_signed(901, ref.shape)
+    (out * T(w, gpu)).sum().backward()
+    og = np.ascontiguousarray(w.transpose(0, 2, 3, 4, 1))  # (B,Dz,Dy,Dx,C)
+    dg, fg = O.bev_pool_v2_backward(og, depth, feat, rd, rf, rb)
+    np.testing.assert_allclose(dt.grad.cpu().numpy(), dg, atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), fg, atol=1e-5, rtol=1e-5)
+
+
+def test_bev_pool_v2_empty_and_cpu_tensor_errors(gpu):
+    from dhd_amd import bev_pool_v2, _lib
+    z = torch.zeros(0, dtype=torch.int32, device=gpu)
+    depth = torch.rand(1, 1, 2, 2, 2, device=gpu)
+    feat = torch.rand(1, 1, 2, 2, 4, device=gpu)
+    out = bev_pool_v2(depth, feat, z, z, z, (1, 1, 3, 3, 4), z, z)
+    assert out.shape == (1, 4, 1, 3, 3) and float(out.abs().sum()) == 0.0
+    with pytest.raises(_lib.DhdError):
+        bev_pool_v2(depth.cpu(), feat.cpu(), z.cpu(), z.cpu(), z.cpu(), (1, 1, 3, 3, 4), z.cpu(), z.cpu())
+
+
+# --------------------------------------------------------------------------- geometry / indices
+
+@pytest.mark.parametrize('name', ['g2_smoke', 'g2b_small_dhds', 'g2c_no_band', 'g2d_out_of_grid'])
+def test_voxel_index_bit_exact_vs_reference(gpu, name):
+    """Given the reference's own small matrices, ego coordinates and every grid's point->voxel map
+    are bit-identical to what the reference's Python computed (lss_heightmap.py:206-230,331-354)."""
+    from dhd_amd import mghs_op
+    g = golden(name)
+    cfg = syn.smoke_config() if name == 'g2_smoke' else small_dhds_cfg()
+    B, N = g['sensor2ego'].shape[:2]
+    plan, axes = make_plan(cfg, B, N)
+    calib, keep = device_calib(golden_calib(g), axes, gpu, g['ref_inv_post_rot'], g['ref_combine'])
+    for k in range(4):
+        rank, ego = mghs_op.voxel_index(plan, calib, k, want_ego=True)
+        assert np.array_equal(ego.cpu().numpy(), g['coor']), k
+        assert np.array_equal(rank.cpu().numpy(), g[f'rank_map{k}']), k
+
+
+@pytest.mark.parametrize('name', ['g2_smoke', 'g2b_small_dhds'])
+def test_voxel_index_raw_calibration_vs_oracle(gpu, name):
+    """From raw calibration the device's own 3x3 inverse is the oracle's algorithm: bit-exact too."""
+    from dhd_amd import mghs_op
+    from oracle import mghs_oracle as O
+    g = golden(name)
+    cfg = syn.smoke_config() if name == 'g2_smoke' else small_dhds_cfg()
+    calib_np = golden_calib(g)
+    B, N = calib_np[0].shape[:2]
+    plan, axes = make_plan(cfg, B, N)
+    calib, keep = device_calib(calib_np, axes, gpu)
+    coor = O.ego_coor(axes, calib_np[0], calib_np[2], calib_np[3], calib_np[4], calib_np[5])
+    grids = [O.FULL_GRID] + [{a: cfg[k][a] for a in 'xyz'} for k in ('mask_1_grid', 'mask_2_grid', 'mask_3_grid')]
+    for k in range(4):
+        rank, ego = mghs_op.voxel_index(plan, calib, k, want_ego=True)
+        assert np.array_equal(ego.cpu().numpy(), coor), k
+        assert np.array_equal(rank.cpu().numpy(), O.voxel_rank(coor, grids[k])), k
+
+
+def test_height_band_vs_oracle_with_ties(gpu):
+    from dhd_amd import mghs_op
+    from oracle import mghs_oracle as O
+    cfg = syn.dhd_s_config()
+    idx = syn.height_index(5, (12, 16, 44), 65)
+    idx[0, 0, :5] = [0, 15, 16, 63, 64]
+    h = syn.height_probs_from_index(idx, 65)
+    h[1, 10, 3, 3] = 0.5  # tie with the hashed maximum: first index must win
+    h[1, 50, 3, 3] = 0.5
+    h[1, idx[1, 3, 3], 3, 3] = 0.25
+    band = mghs_op.height_band(T(h, gpu), cfg['height_range'], cfg['mask_range']).cpu().numpy()
+    ref_idx = h.argmax(1)
+    assert ref_idx[1, 3, 3] == 10
+    assert np.array_equal(band, O.band_index(ref_idx, cfg['height_range'], cfg['mask_range']))
+    assert list(band[0, 0, :5]) == [0, 0, 1, 2, 255]
+
+
+def test_feature_relayout_round_trip(gpu):
+    from dhd_amd import mghs_op
+    x = T(syn.hash_signed(3, (5, 70, 7, 13)), gpu)
+    y = mghs_op._nchw_to_nhwc(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(mghs_op._nhwc_to_nchw(y), x)
+
+
+# --------------------------------------------------------------------------- fused view transform
+
+def run_fused(gpu, cfg, calib_np, depth, feat, hidx, inv=None, comb=None, weights_seed=None):
+    from dhd_amd import mghs_op
+    B, N = calib_np[0].shape[:2]
+    plan, axes = make_plan(cfg, B, N, channels=feat.shape[1])
+    calib, keep = device_calib(calib_np, axes, gpu, inv, comb)
+    height = T(syn.height_probs_from_index(hidx, len(cfg['height_range'])), gpu)
+    band = mghs_op.height_band(height, cfg['height_range'], cfg['mask_range'])
+    dt, ft = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+    ws = plan.new_workspace(gpu)
+    outs = mghs_op.mghs_pool(plan, calib, band, dt, ft, ws)
+    grads = None
+    if weights_seed is not None:
+        loss = sum((o * T(syn.hash_signed(weights_seed + k, tuple(o.shape)), gpu)).sum() for k, o in enumerate(outs))
+        loss.backward()
+        grads = (dt.grad.cpu().numpy(), ft.grad.cpu().numpy())
+    return [o.detach().cpu().numpy() for o in outs], grads, (plan, ws)
+
+
+@pytest.mark.parametrize('name', ['g2_smoke', 'g2b_small_dhds', 'g2c_no_band', 'g2d_out_of_grid'])
+def test_view_transform_small_vs_reference(gpu, name):
+    """The 4 outputs of MGHS.view_transform and the gradients of a weighted sum, against the
+    reference's own results (ragged cases: a band with no pixel, a rig outside every grid)."""
+    g = golden(name)
+    cfg = syn.smoke_config() if name == 'g2_smoke' else small_dhds_cfg()
+    outs, grads, _ = run_fused(gpu, cfg, golden_calib(g), g['depth'], g['tran_feat'], g['height_idx'],
+                               g['ref_inv_post_rot'], g['ref_combine'], int(g['seed_w']))
+    for k, o in enumerate(outs):
+        assert o.shape == g[f'out{k}'].shape
+        np.testing.assert_allclose(o, g[f'out{k}'], atol=1e-5, rtol=1e-5)
+        assert np.array_equal(o != 0, g[f'out{k}'] != 0) or np.abs(o - g[f'out{k}']).max() < 1e-6
+    np.testing.assert_allclose(grads[0], g['depth_grad'], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(grads[1], g['feat_grad'], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('channels', [3, 24, 64, 96, 128])
+def test_view_transform_channel_counts_vs_oracle(gpu, channels):
+    from oracle import mghs_oracle as O
+    cfg = small_dhds_cfg()
+    calib_np = syn.make_calibration(70 + channels, 1, 3, cfg['input_size'])
+    depth, feat, hidx = syn.lift_inputs(80 + channels, 1, 3, 44, 4, 11, channels, 65)
+    outs, grads, _ = run_fused(gpu, cfg, calib_np, depth, feat, hidx, weights_seed=500)
+    ref = O.view_transform(cfg, calib_np, depth, feat, hidx)
+    for o, r in zip(outs, ref):
+        np.testing.assert_allclose(o, r, atol=1e-5, rtol=1e-5)
+    ws = [syn.hash_signed(500 + k, r.shape) for k, r in enumerate(ref)]
+    dg, fg = O.view_transform_backward(cfg, calib_np, depth, feat, hidx, ws)
+    np.testing.assert_allclose(grads[0], dg, atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(grads[1], fg, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('batch', [1, 2])
+def test_full_dhds_size_vs_reference(gpu, batch):
+    """DHD-S, 6 cameras, 200x200x{1,4,4,8}: index hashes, sampled voxels, sums and gradients of the
+    reference run (fixtures hold hashes/samples; inputs are regenerated from integer hashes)."""
+    from dhd_amd import mghs_op
+    g = golden(f'g3_dhds_b{batch}')
+    cfg = syn.dhd_s_config()
+    calib_np = golden_calib(g)
+    _, s_in, s_w = (int(v) for v in g['seeds'])
+    depth, feat, hidx = syn.lift_inputs(s_in, batch, 6, 44, 16, 44, 64, 65)
+    plan, axes = make_plan(cfg, batch, 6)
+    calib, keep = device_calib(calib_np, axes, gpu, g['ref_inv_post_rot'], g['ref_combine'])
+    for k in range(4):
+        rank, ego = mghs_op.voxel_index(plan, calib, k, want_ego=(k == 0))
+        if k == 0:
+            assert sha(ego.cpu().numpy()) == str(g['coor_sha'])
+        assert sha(rank.cpu().numpy()) == str(g[f'rank_map_sha{k}']), k
+    outs, grads, (plan, ws) = run_fused(gpu, cfg, calib_np, depth, feat, hidx, g['ref_inv_post_rot'], g['ref_combine'], s_w)
+    kept, ivs = mghs_op.stats(plan, ws)
+    assert kept[0] == int(g['n_kept0']) and ivs[0] == int(g['n_intervals0'])
+    for k, o in enumerate(outs):
+        np.testing.assert_allclose(o.reshape(-1)[g[f'out_pos{k}']], g[f'out_val{k}'], atol=3e-5, rtol=1e-5)
+        s = g[f'out_sum{k}']
+        assert abs(o.astype(np.float64).sum() - s[0]) < 1e-6 * s[1] + 1e-3
+        assert abs(np.abs(o).astype(np.float64).sum() - s[1]) < 1e-6 * s[1] + 1e-3
+        assert int(np.count_nonzero(o)) == int(s[2])
+    np.testing.assert_allclose(grads[0].reshape(-1)[g['depth_grad_pos']], g['depth_grad_val'], atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(grads[1].reshape(-1)[g['feat_grad_pos']], g['feat_grad_val'], atol=2e-4, rtol=1e-5)
+    for a, key in ((grads[0], 'depth_grad_sum'), (grads[1], 'feat_grad_sum')):
+        assert abs(a.astype(np.float64).sum() - g[key][0]) < 1e-5 * g[key][1] + 1e-2
+
+
+def test_full_size_properties_batch4(gpu):
+    """BASELINE workload size (B=4): size-independent checks.  (1) checksum: the sum over every
+    voxel and channel equals sum over kept points of depth * sum_c feat, computed from the per-point
+    maps; (2) linearity in depth; (3) two runs agree to rounding (within-voxel order is free);
+    (4) raw-calibration path keeps the same number of points as the oracle-free count."""
+    from dhd_amd import mghs_op
+    cfg = syn.dhd_s_config()
+    B = 4
+    calib_np = syn.make_calibration(77, B, 6, cfg['input_size'])
+    depth, feat, hidx = syn.lift_inputs(78, B, 6, 44, 16, 44, 64, 65)
+    outs, grads, (plan, ws) = run_fused(gpu, cfg, calib_np, depth, feat, hidx, weights_seed=600)
+    outs2, _, _ = run_fused(gpu, cfg, calib_np, (2 * depth).astype(np.float32), feat, hidx)
+    _, axes = make_plan(cfg, B, 6)
+    calib, keep = device_calib(calib_np, axes, gpu)
+    from oracle import mghs_oracle as O
+    band = O.band_index(hidx, cfg['height_range'], cfg['mask_range'])
+    fsum = feat.astype(np.float64).sum(1)  # (BN, fH, fW)
+    d64 = depth.astype(np.float64)
+    kept, ivs = mghs_op.stats(plan, ws)
+    for k in range(4):
+        rank, _ = mghs_op.voxel_index(plan, calib, k)
+        m = (rank.cpu().numpy() >= 0).reshape(B * 6, 44, 16, 44)
+        if k > 0:
+            m = m & (band == k - 1)[:, None]
+        assert int(m.sum()) == kept[k]
+        expect = (d64 * m * fsum[:, None]).sum()
+        got = outs[k].astype(np.float64).sum()
+        assert abs(got - expect) < 1e-4 * np.abs(d64 * m * np.abs(feat).astype(np.float64).sum(1)[:, None]).sum() + 1e-3
+        # not bit-linear: the within-voxel summation order differs from run to run
+        np.testing.assert_allclose(outs2[k], 2 * outs[k], atol=1e-4, rtol=1e-4)
+        assert int(np.count_nonzero(outs[k].reshape(B, -1, 64, *outs[k].shape[2:]).any(2))) <= ivs[k]
+    outs3, grads3, _ = run_fused(gpu, cfg, calib_np, depth, feat, hidx, weights_seed=600)
+    for a, b in zip(outs, outs3):
+        np.testing.assert_allclose(a, b, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(grads[0], grads3[0], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(grads[1], grads3[1], atol=1e-3, rtol=1e-4)
+
+
+# --------------------------------------------------------------------------- module level
+
+def test_mghs_module_matches_reference_outputs(gpu):
+    """MGHS.view_transform through the registry-built module (raw calibration -> device inverse)."""
+    from dhd_amd import build_neck
+    g = golden('g2b_small_dhds')
+    cfg = dict(small_dhds_cfg(), type='MGHS', heightnet_cfg=dict(use_dcn=False, use_aspp=False))
+    m = build_neck(cfg).to(gpu)
+    calib = [T(a, gpu) for a in golden_calib(g)]
+    B, N = calib[0].shape[:2]
+    x = torch.zeros(B, N, 1, 4, 11, device=gpu)
+    height = T(syn.height_probs_from_index(g['height_idx'], 65), gpu)
+    dt, ft = T(g['depth'], gpu).requires_grad_(), T(g['tran_feat'], gpu).requires_grad_()
+    bev, depth, h, lo, mid, hi = m.view_transform([x] + calib, dt, ft, height)
+    assert depth is dt and h is height
+    for k, o in enumerate((bev, lo, mid, hi)):
+        ref = g[f'out{k}']
+        diff = np.abs(o.detach().cpu().numpy() - ref)
+        # own inverse: a boundary point may land in the neighbouring voxel; everything else is equal
+        assert (diff > 1e-5).sum() <= 4 * 8 * 3, k
+    assert m.grid_config is m.mask_3_grid  # state the reference leaves behind
+    ego = m.get_ego_coor(*calib)
+    assert np.abs(ego.cpu().numpy() - g['coor']).max() < 1e-4
+    # operator-seam route through the API-parity methods gives the same tensors
+    m.create_grid_infos(**{a: cfg['mask_2_grid'][a] for a in 'xyz'})
+    via_seam = m.voxel_pooling_v2(ego, dt.view(B, N, 44, 4, 11), (ft * (T(g['band'], gpu) == 1)[:, None]).view(B, N, 8, 4, 11))
+    np.testing.assert_allclose(via_seam.detach().cpu().numpy(), mid.detach().cpu().numpy(), atol=1e-5)
+
+
+def test_mghs_forward_backward_end_to_end(gpu):
+    from dhd_amd import MGHS
+    cfg = small_dhds_cfg()
+    cfg['in_channels'] = 32
+    torch.manual_seed(0)
+    m = MGHS(**cfg).to(gpu)
+    B, N = 2, 2
+    calib = [T(a, gpu) for a in syn.make_calibration(5, B, N, cfg['input_size'])]
+    x = torch.randn(B, N, 32, 4, 11, device=gpu)
+    mlp = m.get_mlp_input(*calib)
+    bev, depth, height, lo, mid, hi = m([x] + calib + [mlp])
+    assert bev.shape == (B, 8, 200, 200) and lo.shape == (B, 32, 200, 200) and hi.shape == (B, 64, 200, 200)
+    assert depth.shape == (B * N, 44, 4, 11) and height.shape == (B * N, 65, 4, 11)
+    gt_d = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, 1 + 40 * syn.hash_uniform(2, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    gt_h = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, -1 + 6 * syn.hash_uniform(3, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    loss = m.get_height_loss(gt_d, gt_h, height) + bev.square().mean() + lo.mean() + mid.mean() + hi.mean()
+    loss.backward()
+    assert m.depth_net.weight.grad is not None and torch.isfinite(m.depth_net.weight.grad).all()
+    assert m.height_net.depth_conv[-1].weight.grad is not None
+
+
+# --------------------------------------------------------------------------- SFA
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_sfa_vs_reference(gpu, mode):
+    from dhd_amd import SFA
+    g = golden('g5_sfa')
+    sfa = SFA(in_channels=32, out_channels=16)
+    sfa.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd.')})
+    sfa = sfa.to(gpu).train(mode == 'train')
+    x = T(g['x'], gpu).requires_grad_()
+    sd0 = {k: v.clone() for k, v in sfa.state_dict().items()}
+    stage = sfa.mysk_7(x)
+    np.testing.assert_allclose(stage.detach().cpu().numpy(), g[f'{mode}.stage'], atol=2e-5, rtol=1e-4)
+    sfa.load_state_dict(sd0)
+    out = sfa(x)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f'{mode}.out'], atol=5e-5, rtol=1e-4)
+    (out * T(g['w'], gpu)).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[f'{mode}.xgrad'], atol=2e-4, rtol=1e-3)
+    for k, p in sfa.named_parameters():
+        ref = g[f'{mode}.pgrad.{k}']
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=2e-4 * max(1.0, np.abs(ref).max()), rtol=1e-3)
+
+
+def test_sfa_stage_full_size_vs_torch(gpu):
+    """(1,512,200,200): the fused stage against the same math in plain PyTorch fp32."""
+    from dhd_amd.mix import channel_spatial_stage
+    torch.manual_seed(1)
+    st = channel_spatial_stage(512).to(gpu)
+    x = torch.randn(1, 512, 200, 200, device=gpu, requires_grad=True)
+    out = st(x)
+    g = torch.randn_like(out)
+    out.backward(g)
+    gx, gp = x.grad.clone(), [p.grad.clone() for p in st.parameters()]
+    x.grad = None
+    st.zero_grad()
+    for mod in st.modules():  # same batch statistics, do not double-update the running stats
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = 0.0
+    xb, xv = torch.split(x, 256, dim=1)
+    a1 = st.fc(x.mean(-1).mean(-1))[:, :, None, None]
+    xb1, xv1 = a1 * xb, (1 - a1) * xv
+    a2 = torch.sigmoid(st.spacial_leanring(xb1 + xv1))
+    ref = a2 * xb1 + (1 - a2) * xv1
+    ref.backward(g)
+    assert (out - ref).abs().max().item() < 1e-4
+    assert (gx - x.grad).abs().max().item() < 1e-4 * max(1.0, x.grad.abs().max().item())
+    for a, p in zip(gp, st.parameters()):
+        assert (a - p.grad).abs().max().item() < 2e-3 * max(1.0, p.grad.abs().max().item())

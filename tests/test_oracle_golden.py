@@ -1,0 +1,147 @@
+"""The CPU oracle against the fixtures recorded from the reference's own Python
+(tests/golden/make_golden.py) and against the reference's only known-answer test."""
+import numpy as np
+import pytest
+
+from conftest import golden, golden_calib, small_dhds_cfg
+from dhd_amd import synthetic as syn
+from oracle import mghs_oracle as O
+
+
+def grids_of(cfg):
+    return [O.FULL_GRID] + [{a: cfg[k][a] for a in 'xyz'} for k in ('mask_1_grid', 'mask_2_grid', 'mask_3_grid')]
+
+
+def test_reference_known_answer_test():
+    # ops/bev_pool_v2/bev_pool.py:163-194
+    depth = np.array([0.3, 0.4, 0.2, 0.1, 0.7, 0.6, 0.8, 0.9], np.float32).reshape(1, 1, 2, 2, 2)
+    feat = np.ones((1, 1, 2, 2, 2), np.float32)
+    rd, rf, rb = (np.array(v, np.int32) for v in ([0, 4, 1, 6], [0, 0, 1, 2], [0, 0, 1, 1]))
+    st, ln = np.array([0, 2], np.int32), np.array([2, 2], np.int32)
+    out = O.bev_pool_v2(depth, feat, rd, rf, rb, (1, 1, 2, 2, 2), st, ln)
+    assert out.shape == (1, 2, 1, 2, 2)
+    assert abs(float(out.sum()) - 4.4) < 1e-6
+    dg, fg = O.bev_pool_v2_backward(np.ones((1, 1, 2, 2, 2), np.float32), depth, feat, rd, rf, rb)
+    np.testing.assert_allclose(dg.reshape(-1), [2, 2, 0, 0, 2, 0, 2, 0], atol=1e-6)
+    np.testing.assert_allclose(fg.reshape(-1), [1, 1, .4, .4, .8, .8, 0, 0], atol=1e-6)
+
+
+def test_frustum_axes_match_torch_linspace_arange():
+    g0 = golden('g0_frustum')
+    for name in ('dhds', 'smoke', 'dhdl', 'stereo'):
+        cfg = g0[name + '_cfg']
+        u, v, d = O.frustum_axes(list(cfg[:3]), (int(cfg[3]), int(cfg[4])), int(cfg[5]))
+        for a, k in ((u, 'u'), (v, 'v'), (d, 'd')):
+            assert np.array_equal(a, g0[f'{name}_{k}']), (name, k)
+
+
+@pytest.mark.parametrize('name', ['g2_smoke', 'g2b_small_dhds', 'g2c_no_band', 'g2d_out_of_grid'])
+def test_small_cases_bit_exact_indices_and_values(name):
+    g = golden(name)
+    cfg = syn.smoke_config() if name == 'g2_smoke' else small_dhds_cfg()
+    calib = golden_calib(g)
+    axes = O.frustum_axes(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    fr = g['frustum']
+    assert np.array_equal(axes[0], fr[0, 0, :, 0]) and np.array_equal(axes[1], fr[0, :, 0, 1])
+    assert np.array_equal(axes[2], fr[:, 0, 0, 2])
+    # per-point arithmetic, given the reference's own small matrices: bit-exact
+    coor = O.ego_coor(axes, calib[0], calib[2], calib[3], calib[4], calib[5], g['ref_inv_post_rot'], g['ref_combine'])
+    assert np.array_equal(coor, g['coor'])
+    assert np.array_equal(O.band_index(g['height_idx'], cfg['height_range'], cfg['mask_range']), g['band'])
+    for k, grid in enumerate(grids_of(cfg)):
+        assert np.array_equal(O.voxel_rank(coor, grid), g[f'rank_map{k}'])
+        rb, rd, rf, st, ln = O.prepare_v2(coor, grid)
+        if rb is None:
+            assert len(g[f'ranks_bev{k}']) == 0
+            continue
+        for a, n in ((rb, 'ranks_bev'), (rd, 'ranks_depth'), (rf, 'ranks_feat'), (st, 'interval_starts'),
+                     (ln, 'interval_lengths')):
+            assert np.array_equal(a, g[n + str(k)]), (n, k)
+    outs = O.view_transform(cfg, calib, g['depth'], g['tran_feat'], g['height_idx'], g['ref_inv_post_rot'],
+                            g['ref_combine'])
+    for k, o in enumerate(outs):
+        assert o.shape == g[f'out{k}'].shape
+        np.testing.assert_allclose(o, g[f'out{k}'], atol=1e-6, rtol=0)
+    ws = [syn.hash_signed(int(g['seed_w']) + k, o.shape) for k, o in enumerate(outs)]
+    dg, fg = O.view_transform_backward(cfg, calib, g['depth'], g['tran_feat'], g['height_idx'], ws,
+                                       g['ref_inv_post_rot'], g['ref_combine'])
+    np.testing.assert_allclose(dg, g['depth_grad'], atol=5e-6, rtol=0)
+    np.testing.assert_allclose(fg, g['feat_grad'], atol=5e-6, rtol=0)
+
+
+def test_own_inverse_is_close_and_flips_few_points():
+    """inv3x3 is the LAPACK algorithm, not MKL's kernel: matrices agree to ~1 ulp and the voxel
+    map changes only for points sitting on a cell boundary."""
+    g = golden('g2b_small_dhds')
+    cfg = small_dhds_cfg()
+    calib = golden_calib(g)
+    ipr, comb = O.camera_matrices(calib[0], calib[2], calib[3])
+    np.testing.assert_allclose(ipr, g['ref_inv_post_rot'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(comb, g['ref_combine'], rtol=1e-5, atol=1e-7)
+    axes = O.frustum_axes(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    coor = O.ego_coor(axes, calib[0], calib[2], calib[3], calib[4], calib[5])
+    assert np.abs(coor - g['coor']).max() < 1e-4
+    for k, grid in enumerate(grids_of(cfg)):
+        bad = (O.voxel_rank(coor, grid) != g[f'rank_map{k}']).sum()
+        assert bad <= 3, (k, bad)
+
+
+@pytest.mark.parametrize('batch', [1, 2])
+def test_full_dhds_size_hashes_and_samples(batch):
+    import hashlib
+    g = golden(f'g3_dhds_b{batch}')
+    cfg = syn.dhd_s_config()
+    calib = golden_calib(g)
+    s_cal, s_in, s_w = (int(v) for v in g['seeds'])
+    depth, feat, hidx = syn.lift_inputs(s_in, batch, 6, 44, 16, 44, 64, 65)
+    axes = O.frustum_axes(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    coor = O.ego_coor(axes, calib[0], calib[2], calib[3], calib[4], calib[5], g['ref_inv_post_rot'], g['ref_combine'])
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(coor) == str(g['coor_sha'])
+    for k, grid in enumerate(grids_of(cfg)):
+        rm = O.voxel_rank(coor, grid)
+        assert sha(rm) == str(g[f'rank_map_sha{k}'])
+        assert int((rm >= 0).sum()) == int(g[f'n_kept{k}'])
+        assert len(np.unique(rm[rm >= 0])) == int(g[f'n_intervals{k}'])
+    outs = O.view_transform(cfg, calib, depth, feat, hidx, g['ref_inv_post_rot'], g['ref_combine'])
+    for k, o in enumerate(outs):
+        np.testing.assert_allclose(o.reshape(-1)[g[f'out_pos{k}']], g[f'out_val{k}'], atol=2e-5, rtol=1e-5)
+        s = g[f'out_sum{k}']
+        assert abs(o.astype(np.float64).sum() - s[0]) < 1e-3 * max(1.0, s[1]) * 1e-3
+        assert int(np.count_nonzero(o)) == int(s[2])
+    ws = [syn.hash_signed(s_w + k, o.shape) for k, o in enumerate(outs)]
+    dg, fg = O.view_transform_backward(cfg, calib, depth, feat, hidx, ws, g['ref_inv_post_rot'], g['ref_combine'])
+    np.testing.assert_allclose(dg.reshape(-1)[g['depth_grad_pos']], g['depth_grad_val'], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(fg.reshape(-1)[g['feat_grad_pos']], g['feat_grad_val'], atol=1e-4, rtol=1e-5)
+
+
+def test_mlp_input_and_height_loss_labels():
+    g = golden('g4_loss')
+    calib = golden_calib(g)
+    assert np.array_equal(O.get_mlp_input(*calib), g['mlp_input'])
+    cfg = syn.dhd_s_config()
+    np.testing.assert_array_equal(
+        O.downsampled_gt_height(g['gt_height'], 16, cfg['height_range'], cfg['height_interval']),
+        g['gt_height_onehot'])
+    for phase in ('init', 'after_forward'):
+        dcfg = list(g[f'depth_cfg_{phase}'])
+        np.testing.assert_array_equal(O.downsampled_gt_depth(g['gt_depth'], 16, dcfg, 44),
+                                      g[f'gt_depth_onehot_{phase}'])
+        loss = O.height_loss(g['gt_depth'], g['gt_height'], g['height_prob'], 16, dcfg, 44, cfg['height_range'],
+                             cfg['height_interval'], cfg['loss_height_weight'])
+        assert abs(loss - float(g[f'loss_height_{phase}'])) < 1e-5 * max(1.0, abs(loss))
+    # the quirk: after one forward the depth interval read by the loss is 0.5, not 1.0
+    assert list(g['depth_cfg_init']) == [1.0, 45.0, 1.0] and list(g['depth_cfg_after_forward']) == [1.0, 45.0, 0.5]
+    assert not np.array_equal(g['gt_depth_onehot_init'], g['gt_depth_onehot_after_forward'])
+
+
+def test_sfa_stage_eval_mode():
+    g = golden('g5_sfa')
+    sd = {k[3:]: g[k] for k in g.files if k.startswith('sd.')}
+    p = 'mysk_7.'
+    bn = lambda i: (sd[f'{p}spacial_leanring.{i}.weight'], sd[f'{p}spacial_leanring.{i}.bias'],
+                    sd[f'{p}spacial_leanring.{i}.running_mean'], sd[f'{p}spacial_leanring.{i}.running_var'])
+    out = O.sfa_stage(g['x'], sd[p + 'fc.0.weight'], sd[p + 'fc.0.bias'], sd[p + 'fc.2.weight'], sd[p + 'fc.2.bias'],
+                      sd[p + 'spacial_leanring.0.weight'], sd[p + 'spacial_leanring.0.bias'], bn(1),
+                      sd[p + 'spacial_leanring.3.weight'], sd[p + 'spacial_leanring.3.bias'], bn(4))
+    np.testing.assert_allclose(out, g['eval.stage'], atol=2e-6, rtol=1e-5)
