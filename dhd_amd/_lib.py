@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdhd_amd.so')
+LIB_PATH = os.environ.get('DHD_AMD_LIB', os.path.join(_HERE, 'csrc', 'libdhd_amd.so'))
 
 DHD_MAX_GRIDS = 4
 ABI_VERSION = 1

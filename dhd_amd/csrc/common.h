@@ -36,12 +36,33 @@ __device__ __forceinline__ int next_pow2(int v) {
   return p;
 }
 
-// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed, speed only).
-// Remap so that each XCD walks one contiguous range of logical tiles: neighbouring output rows
-// then share an L2 and their partial cache lines meet there before write-back.
-__device__ __forceinline__ int xcd_contiguous_tile(int block, int n_tiles) {
-  const int nx = 8;
-  int per = (n_tiles + nx - 1) / nx;
-  int t = (block % nx) * per + block / nx;
-  return t;  // may be >= n_tiles for the ragged tail: caller checks
+// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8: observed behaviour, used
+// for speed only).  Tiles are handed out in groups of `group` consecutive tiles per XCD, groups
+// round-robin over the XCDs: a group of 4 rows of a 200-float-wide tensor is exactly 25 cache
+// lines, so every partially written line is completed inside one XCD's L2, while heavy and light
+// rows still spread evenly over all 256 CUs.  Bijective on [0, 8*group*ceil(n/(8*group))).
+__device__ __forceinline__ int xcd_grouped_tile(int block, int group) {
+  const int xcd = block & 7, i = block >> 3;
+  return ((i / group) * 8 + xcd) * group + (i % group);
+}
+static inline int xcd_grouped_blocks(int n_tiles, int group) {
+  const int q = 8 * group;
+  return (n_tiles + q - 1) / q * q;
+}
+
+// Wave64 sum with DPP cross-lane adds (no LDS traffic); the total lands in lane 63 and is
+// broadcast through an SGPR.  quad_perm x2, row_shr:4, row_shr:8, row_bcast:15, row_bcast:31.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_bcast(float v) {
+  v = dpp_add<0xB1, 0xf>(v);
+  v = dpp_add<0x4E, 0xf>(v);
+  v = dpp_add<0x114, 0xf>(v);
+  v = dpp_add<0x118, 0xf>(v);
+  v = dpp_add<0x142, 0xa>(v);
+  v = dpp_add<0x143, 0xc>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }

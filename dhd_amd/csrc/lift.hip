@@ -15,21 +15,32 @@ struct BandLut {
   uint8_t band[kMaxHeightBins];  // band id per height bin, precomputed on the host in float32
 };
 
-// One thread per pixel; the H loads of a thread are strided by fH*fW, so a wave reads 64
-// consecutive floats of one bin plane per step (coalesced).
+// kBandLanes lanes per pixel, each scanning every kBandLanes-th height bin, then a lane-group
+// argmax that keeps torch.argmax's "first maximum wins".  Lane l of a group reads pixel p's bin
+// k*kBandLanes + l: a wave touches kBandLanes bin planes x 8 consecutive pixels per step.
+constexpr int kBandLanes = 8;
+
 __global__ __launch_bounds__(kBlock) void height_band_kernel(const float* __restrict__ height, int n_pix_total, int n_height,
                                                              int hw, BandLut lut, uint8_t* __restrict__ band) {
-  const int p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= n_pix_total) return;
-  const int bn = p / hw, i = p % hw;
+  const int gid = blockIdx.x * kBlock + threadIdx.x;
+  const int p = gid / kBandLanes, sub = gid % kBandLanes;
+  const bool ok = p < n_pix_total;
+  const int pp = ok ? p : 0;
+  const int bn = pp / hw, i = pp % hw;
   const float* src = height + (size_t)bn * n_height * hw + i;
-  float best = src[0];
-  int arg = 0;
-  for (int k = 1; k < n_height; ++k) {
+  float best = -INFINITY;
+  int arg = 0x7fffffff;
+  for (int k = sub; k < n_height; k += kBandLanes) {
     float v = src[(size_t)k * hw];
-    if (v > best) { best = v; arg = k; }  // first maximum wins, as torch.argmax
+    if (v > best || arg == 0x7fffffff) { best = v; arg = k; }
   }
-  band[p] = lut.band[arg];
+#pragma unroll
+  for (int m = 1; m < kBandLanes; m <<= 1) {
+    float ob = __shfl_xor(best, m, DHD_WAVE);
+    int oa = __shfl_xor(arg, m, DHD_WAVE);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+  }
+  if (ok && sub == 0) band[p] = lut.band[arg < n_height ? arg : 0];
 }
 
 // (bn, C, hw) -> (bn, hw, C) through a padded 64x64 LDS tile; both sides coalesced.
@@ -81,7 +92,7 @@ int dhd_height_band(const float* height, int bn, int n_height, int fh, int fw, c
     lut.band[k] = b;
   }
   const int n = bn * fh * fw;
-  hipLaunchKernelGGL(height_band_kernel, dim3(dhd_cdiv(n, kBlock)), dim3(kBlock), 0, dhd_stream(stream), height, n,
+  hipLaunchKernelGGL(height_band_kernel, dim3(dhd_cdiv((long)n * kBandLanes, kBlock)), dim3(kBlock), 0, dhd_stream(stream), height, n,
                      n_height, fh * fw, lut, band);
   DHD_LAUNCH_CHECK();
   return DHD_OK;

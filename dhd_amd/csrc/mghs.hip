@@ -22,6 +22,7 @@ constexpr int kScanItems = 8;
 constexpr int kChunk = kBlock * kScanItems;  // counters per scan block
 constexpr int kMaxTileX = 256;               // voxels along x per pooling tile
 constexpr int kTileC = 64;                   // channels per pooling tile (one wave lane each)
+constexpr int kCamFloats = 36;               // sizeof(CamMats)/4 = 33, padded
 
 // Host-derived layout, passed to kernels by value.
 struct Layout {
@@ -32,6 +33,8 @@ struct Layout {
   int V;         // total voxels over all grids
   int R;         // total output rows (b, z, y) over all grids
   int n_chunks;  // scan blocks
+  int sched_heavy;  // row groups of grid 0 that are front-loaded 1:sched_ratio among the others (0 = off)
+  int sched_ratio;
   int vox_base[DHD_MAX_GRIDS + 1];
   int row_base[DHD_MAX_GRIDS + 1];
   dhd_grid grid[DHD_MAX_GRIDS];
@@ -43,6 +46,8 @@ struct Layout {
   int* rnk;        // [2P]    arrival rank of the point inside its voxel
   int* s_pid;      // [2P]    point ids grouped by voxel (index into depth)
   int* s_pix;      // [2P]    pixel ids grouped by voxel (row of feat_nhwc)
+  float* cam;      // [B*N*kCamFloats] per-camera matrices (CamMats), written by mghs_camera
+  float* dg_part;  // [2P] backward scratch: depth-gradient parts from grid 0 ([p]) and the band grid ([P+p])
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -87,6 +92,23 @@ int make_layout(const dhd_mghs_desc* d, void* ws, Layout* L, size_t* bytes) {
   L->rnk = carve(2 * (size_t)L->P);
   L->s_pid = carve(2 * (size_t)L->P);
   L->s_pix = carve(2 * (size_t)L->P);
+  L->cam = reinterpret_cast<float*>(carve((size_t)L->B * L->N * kCamFloats));
+  L->dg_part = reinterpret_cast<float*>(carve(2 * (size_t)L->P));
+  // Launch order of the pooling tiles: grid 0 pools every pixel over the whole height, so its rows
+  // carry ~10x the points of a band-grid row.  Their gather is latency-bound; if they are
+  // dispatched back to back they occupy every workgroup slot and the HBM streaming of the light
+  // rows cannot start.  Front-load them, but interleaved 1:k with light row groups.
+  L->sched_heavy = 0; L->sched_ratio = 0;
+  if (L->G > 1 && L->row_base[1] % 4 == 0) {
+    int heavy = L->row_base[1] / 4, light = (L->R - L->row_base[1]) / 4;
+    int k = heavy > 0 ? light / heavy : 0;
+    // the period k+1 must be odd: row groups go round-robin over the 8 XCDs, an even period would
+    // put every heavy group on the same few XCDs
+    if (k > 4) k = 4;
+    if (k == 3) k = 2;
+    if (k == 1) k = 0;
+    if (k >= 2) { L->sched_heavy = heavy; L->sched_ratio = k; }
+  }
   if (bytes) *bytes = off;
   return DHD_OK;
 }
@@ -210,11 +232,24 @@ __device__ __forceinline__ int voxel_of(const dhd_grid& g, const float* e, int b
   return ((b * g.n[2] + idx[2]) * g.n[1] + idx[1]) * g.n[0] + idx[0];
 }
 
+// One thread per camera: the two 3x3 inverses are ~25 serial IEEE divisions, far too slow to
+// repeat in the prologue of every geometry workgroup.
+__global__ __launch_bounds__(64) void mghs_camera(Layout L, dhd_calib cal) {
+  const int bn = blockIdx.x * 64 + threadIdx.x;
+  if (bn >= L.B * L.N) return;
+  CamMats m;
+  load_camera(cal, bn, bn / L.N, &m);
+  float* dst = L.cam + (size_t)bn * kCamFloats;
+  const float* src = reinterpret_cast<const float*>(&m);
+  for (int i = 0; i < (int)(sizeof(CamMats) / 4); ++i) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(kBlock) void mghs_geom_count(Layout L, dhd_calib cal, const uint8_t* __restrict__ band) {
   __shared__ CamMats cam;
   const int bn = blockIdx.y;
   const int b = bn / L.N;
-  if (threadIdx.x == 0) load_camera(cal, bn, b, &cam);
+  if (threadIdx.x < sizeof(CamMats) / 4)
+    reinterpret_cast<float*>(&cam)[threadIdx.x] = L.cam[(size_t)bn * kCamFloats + threadIdx.x];
   __syncthreads();
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= L.dhw) return;
@@ -372,6 +407,84 @@ __device__ __forceinline__ bool decode_row(const Layout& L, int r, RowTile* t) {
   return true;
 }
 
+#ifdef DHD_ABLATION
+// Experiment-only build (make ablate): phases of the pooling kernels can be switched off to
+// price them.  Never defined in libdhd_amd.so.
+__device__ int g_ablate = 0;
+__device__ long long* g_trace = nullptr;  // 8 x int64 per block: tile, t0..t3 (100 MHz wall clock), xcc, n_points, 0
+#define ABL(bit) ((g_ablate & (bit)) != 0)
+#define TRACE(slot, val)                                                             \
+  do {                                                                               \
+    if (g_trace && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)           \
+      g_trace[(size_t)blockIdx.x * 8 + (slot)] = (long long)(val);                   \
+  } while (0)
+#define NOW() wall_clock64()
+#else
+#define ABL(bit) false
+#define TRACE(slot, val) do {} while (0)
+#define NOW() 0
+#endif
+
+typedef float vfloat4 __attribute__((ext_vector_type(4)));  // native vector: accepted by the nontemporal builtins
+
+constexpr int kRowGroup = 4;   // consecutive output rows handed to one XCD (25 whole cache lines at nx=200)
+constexpr int kGatherUnroll = 16;  // feature rows in flight per wave
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int lane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float lane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// blockIdx -> output row: XCD-grouped, then heavy (grid 0) row groups front-loaded 1:k.
+__device__ __forceinline__ int scheduled_row(const Layout& L, int block) {
+  const int pos = xcd_grouped_tile(block, kRowGroup);
+  int grp = pos / kRowGroup;
+  const int within = pos % kRowGroup;
+  if (L.sched_heavy > 0) {
+    const int k1 = L.sched_ratio + 1;
+    if (grp < L.sched_heavy * k1) {
+      const int q = grp / k1, r = grp % k1;
+      grp = (r == 0) ? q : L.sched_heavy + q * L.sched_ratio + (r - 1);
+    }
+  }
+  return grp * kRowGroup + within;
+}
+
+// voxel (column of the tile) that sorted point `idx` belongs to: the x with offs[x] <= idx < offs[x+1]
+__device__ __forceinline__ int column_of(const int* offs, int xn, int idx) {
+  int lo = 0, hi = xn;  // invariant: offs[lo] <= idx < offs[hi]
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (offs[mid] <= idx) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// smallest column x in [0, xn] with offs[x] >= idx (offs is non-decreasing)
+__device__ __forceinline__ int first_column_at_or_after(const int* offs, int xn, int idx) {
+  int lo = 0, hi = xn;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (offs[mid] < idx) lo = mid + 1; else hi = mid;
+  }
+  return rfl(lo);
+}
+
+// The sorted points of a row are split evenly over the waves of the workgroup (multiples of
+// kGatherUnroll), independent of how they cluster into voxels.
+__device__ __forceinline__ void wave_point_range(const int* offs, int xn, int wv, int* a, int* b) {
+  const int s = rfl(offs[0]), n = rfl(offs[xn]) - s;
+  int per = (n + kPoolWaves - 1) / kPoolWaves;
+  per = (per + kGatherUnroll - 1) / kGatherUnroll * kGatherUnroll;
+  *a = min(s + n, s + wv * per);
+  *b = min(s + n, *a + per);
+}
+
+// FULL: the channel tile is exactly 64 wide -> lane == channel; point indices are wave-uniform and
+// travel through SGPRs (v_readlane); kGatherUnroll feature rows are in flight per wave; products
+// are accumulated straight into the LDS tile with ds_add_f32 (tile_stride is odd: conflict-free).
+template <bool FULL>
 __global__ __launch_bounds__(kPoolBlock) void mghs_pool_fwd(Layout L, const float* __restrict__ depth,
                                                             const float* __restrict__ feat, OutPtrs out, int tile_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -379,85 +492,145 @@ __global__ __launch_bounds__(kPoolBlock) void mghs_pool_fwd(Layout L, const floa
   int* offs = reinterpret_cast<int*>(smem + (size_t)kTileC * tile_stride * 4);  // [kMaxTileX + 1]
 
   RowTile rt;
-  if (!decode_row(L, xcd_contiguous_tile(blockIdx.x, L.R), &rt)) return;
+  if (!decode_row(L, scheduled_row(L, blockIdx.x), &rt)) return;
   const int c0 = blockIdx.y * kTileC;
-  const int cn = min(kTileC, L.C - c0);
+  const int cn = FULL ? kTileC : min(kTileC, L.C - c0);
   const int x0 = blockIdx.z * kMaxTileX;
   if (x0 >= rt.nx) return;
   const int xn = min(kMaxTileX, rt.nx - x0);
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  TRACE(0, rt.vrow); TRACE(1, NOW());
 
   for (int i = t; i <= xn; i += kPoolBlock) offs[i] = L.offset[rt.vrow + x0 + i];
-  {
-    float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4* t4 = reinterpret_cast<float4*>(tile);
-    const int n4 = cn * tile_stride / 4;
-    for (int i = t; i < n4; i += kPoolBlock) t4[i] = z4;
-  }
+  for (int i = t; i < cn * tile_stride; i += kPoolBlock) tile[i] = 0.f;
   __syncthreads();
+  TRACE(2, NOW()); TRACE(6, offs[xn] - offs[0]);
+  TRACE(5, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)));  // HW_REG_XCC_ID, bits 3:0
 
-  // lane -> (sub-slot, channel): CL lanes cover the channels, 64/CL points are in flight per wave
-  const int CL = next_pow2(cn);
-  const int nsub = DHD_WAVE / CL;
-  const int c = lane % CL, sub = lane / CL;
-  const bool c_ok = c < cn;
-  const float* featc = feat + c0 + c;
-
-  for (int x = wv; x < xn; x += kPoolWaves) {
-    const int s = offs[x], e = offs[x + 1];
-    if (e == s) continue;
-    float acc = 0.f;
-    for (int s0 = s; s0 < e; s0 += DHD_WAVE) {
-      const int nb = min(DHD_WAVE, e - s0);
-      int pix = 0;
-      float dv = 0.f;
-      if (lane < nb) {
-        pix = L.s_pix[s0 + lane];
-        dv = depth[L.s_pid[s0 + lane]];
+  if (offs[xn] != offs[0] && !ABL(8)) {  // rows without any point (most of them) skip the gather entirely
+    if (FULL) {
+      const float* featc = feat + c0 + lane;
+      float* trow = tile + lane * tile_stride;
+      int a, b;
+      wave_point_range(offs, xn, wv, &a, &b);
+      // own the voxels whose first point lies in [a, b): every voxel has exactly one writer
+      a = rfl(offs[first_column_at_or_after(offs, xn, a)]);
+      b = rfl(offs[first_column_at_or_after(offs, xn, b)]);
+      int cur = -1;      // column being accumulated (wave-uniform)
+      float acc = 0.f;
+      int pix_n = 0, pid_n = 0;
+      float dv_n = 0.f;
+      if (a < b) {
+        if (a + lane < b) { pix_n = L.s_pix[a + lane]; pid_n = L.s_pid[a + lane]; }
+        if (a + lane < b) dv_n = depth[pid_n];
       }
-      // uniform trip count: the cross-lane reads below must be executed by every lane
-      const int steps = (nb + nsub - 1) / nsub;
-      for (int k = 0; k < steps; ++k) {
-        const int i = k * nsub + sub;
-        const bool live = i < nb;
-        int q = __shfl(pix, live ? i : 0, DHD_WAVE);
-        float d = __shfl(dv, live ? i : 0, DHD_WAVE);
-        float f = (live && c_ok) ? featc[(size_t)q * L.C] : 0.f;
-        acc = fmaf(d, f, acc);
+      for (int a0 = a; a0 < b; a0 += DHD_WAVE) {
+        const int nb = min(DHD_WAVE, b - a0);
+        const int pix = pix_n;
+        const float dv = dv_n;
+        const int col = lane < nb ? column_of(offs, xn, a0 + lane) : 0;
+        const int nxt = a0 + DHD_WAVE + lane;
+        if (nxt < b) { pix_n = L.s_pix[nxt]; pid_n = L.s_pid[nxt]; }  // next batch's indices: in flight during this one
+        int i = 0;
+        for (; i + kGatherUnroll <= nb; i += kGatherUnroll) {
+          float f[kGatherUnroll];
+#pragma unroll
+          for (int j = 0; j < kGatherUnroll; ++j) f[j] = featc[(size_t)lane_i(pix, i + j) * L.C];
+#pragma unroll
+          for (int j = 0; j < kGatherUnroll; ++j) {
+            const int cj = lane_i(col, i + j);
+            if (cj != cur) {
+              if (cur >= 0) trow[cur] = acc;
+              acc = 0.f;
+              cur = cj;
+            }
+            acc = fmaf(lane_f(dv, i + j), f[j], acc);
+          }
+        }
+        for (; i < nb; ++i) {
+          const int cj = lane_i(col, i);
+          if (cj != cur) {
+            if (cur >= 0) trow[cur] = acc;
+            acc = 0.f;
+            cur = cj;
+          }
+          acc = fmaf(lane_f(dv, i), featc[(size_t)lane_i(pix, i) * L.C], acc);
+        }
+        if (nxt < b) dv_n = depth[pid_n];  // its latency hides under the next batch's first feature loads
+      }
+      if (cur >= 0) trow[cur] = acc;
+    } else {
+      // lane -> (sub-slot, channel): CL lanes cover the channels, 64/CL points are in flight per wave
+      const int CL = next_pow2(cn);
+      const int nsub = DHD_WAVE / CL;
+      const int c = lane % CL, sub = lane / CL;
+      const bool c_ok = c < cn;
+      const float* featc = feat + c0 + c;
+      for (int x = wv; x < xn; x += kPoolWaves) {
+        const int s = offs[x], e = offs[x + 1];
+        if (e == s) continue;
+        float acc = 0.f;
+        for (int s0 = s; s0 < e; s0 += DHD_WAVE) {
+          const int nb = min(DHD_WAVE, e - s0);
+          int pix = 0;
+          float dv = 0.f;
+          if (lane < nb) {
+            pix = L.s_pix[s0 + lane];
+            dv = depth[L.s_pid[s0 + lane]];
+          }
+          // uniform trip count: the cross-lane reads below must be executed by every lane
+          const int steps = (nb + nsub - 1) / nsub;
+          for (int k = 0; k < steps; ++k) {
+            const int i = k * nsub + sub;
+            const bool live = i < nb;
+            int q = __shfl(pix, live ? i : 0, DHD_WAVE);
+            float d = __shfl(dv, live ? i : 0, DHD_WAVE);
+            float f = (live && c_ok) ? featc[(size_t)q * L.C] : 0.f;
+            acc = fmaf(d, f, acc);
+          }
+        }
+        for (int m = CL; m < DHD_WAVE; m <<= 1) acc += __shfl_xor(acc, m, DHD_WAVE);
+        if (sub == 0 && c_ok) tile[c * tile_stride + x] = acc;
       }
     }
-    for (int m = CL; m < DHD_WAVE; m <<= 1) acc += __shfl_xor(acc, m, DHD_WAVE);
-    if (sub == 0 && c_ok) tile[c * tile_stride + x] = acc;
+    __syncthreads();
   }
-  __syncthreads();
 
-  // stream the tile out: one (channel) row of xn floats per wave iteration
+  TRACE(3, NOW());
+  if (ABL(16)) return;
+  // stream the tile out: one (channel) row of xn floats per wave iteration, 16 bytes per lane
   float* og = out.p[rt.g];
   const bool vec = ((rt.nx & 3) == 0) && ((xn & 3) == 0);
   for (int cc = wv; cc < cn; cc += kPoolWaves) {
     size_t row = ((((size_t)rt.b * rt.nz + rt.z) * L.C + c0 + cc) * rt.ny + rt.y) * rt.nx + x0;
+    const float* src = tile + cc * tile_stride;
     if (vec) {
-      const float4* src = reinterpret_cast<const float4*>(tile + cc * tile_stride);
-      float4* dst = reinterpret_cast<float4*>(og + row);
-      for (int i = lane; i < xn / 4; i += DHD_WAVE) dst[i] = src[i];
+      vfloat4* dst = reinterpret_cast<vfloat4*>(og + row);
+      // streamed once and not re-read here: non-temporal, so the 700 MB output stream does not evict
+      // the gather's working set (features, depth, sorted lists) from L2 (measured: 235 -> 195 us)
+      for (int i = lane; i < xn / 4; i += DHD_WAVE) {
+        vfloat4 v = {src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]};
+        __builtin_nontemporal_store(v, dst + i);
+      }
     } else {
-      for (int i = lane; i < xn; i += DHD_WAVE) og[row + i] = tile[cc * tile_stride + i];
+      for (int i = lane; i < xn; i += DHD_WAVE) __builtin_nontemporal_store(src[i], og + row + i);
     }
   }
+  TRACE(4, NOW());
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(kPoolBlock) void mghs_pool_bwd(Layout L, const float* __restrict__ depth,
                                                             const float* __restrict__ feat, InPtrs og,
-                                                            float* __restrict__ depth_grad, float* __restrict__ feat_grad,
-                                                            int tile_stride) {
+                                                            float* __restrict__ feat_grad, int tile_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tile = reinterpret_cast<float*>(smem);
   int* offs = reinterpret_cast<int*>(smem + (size_t)kTileC * tile_stride * 4);
 
   RowTile rt;
-  if (!decode_row(L, xcd_contiguous_tile(blockIdx.x, L.R), &rt)) return;
+  if (!decode_row(L, scheduled_row(L, blockIdx.x), &rt)) return;
   const int c0 = blockIdx.y * kTileC;
-  const int cn = min(kTileC, L.C - c0);
+  const int cn = FULL ? kTileC : min(kTileC, L.C - c0);
   const int x0 = blockIdx.z * kMaxTileX;
   if (x0 >= rt.nx) return;
   const int xn = min(kMaxTileX, rt.nx - x0);
@@ -471,15 +644,75 @@ __global__ __launch_bounds__(kPoolBlock) void mghs_pool_bwd(Layout L, const floa
   const bool vec = ((rt.nx & 3) == 0) && ((xn & 3) == 0);
   for (int cc = wv; cc < cn; cc += kPoolWaves) {
     size_t row = ((((size_t)rt.b * rt.nz + rt.z) * L.C + c0 + cc) * rt.ny + rt.y) * rt.nx + x0;
+    float* dst = tile + cc * tile_stride;
     if (vec) {
-      float4* dst = reinterpret_cast<float4*>(tile + cc * tile_stride);
       const float4* src = reinterpret_cast<const float4*>(gsrc + row);
-      for (int i = lane; i < xn / 4; i += DHD_WAVE) dst[i] = src[i];
+      for (int i = lane; i < xn / 4; i += DHD_WAVE) {
+        float4 v = src[i];
+        dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+      }
     } else {
-      for (int i = lane; i < xn; i += DHD_WAVE) tile[cc * tile_stride + i] = gsrc[row + i];
+      for (int i = lane; i < xn; i += DHD_WAVE) dst[i] = gsrc[row + i];
     }
   }
   __syncthreads();
+  if (ABL(8)) return;
+
+  // depth-gradient parts: a point appears at most once in grid 0 and once in its band grid, so
+  // each part has exactly one writer (plain stores); dhd_mghs_backward sums the two parts.
+  // With several channel tiles (C > 64) the parts need atomics again.
+  float* dgp = L.dg_part + (rt.g == 0 ? 0 : L.P);
+  const bool dg_atomic = L.C > kTileC;
+
+  if (FULL) {
+    const float* featc = feat + c0 + lane;
+    float* fgc = feat_grad + c0 + lane;
+    const float* trow = tile + lane * tile_stride;
+    int a, b;
+    wave_point_range(offs, xn, wv, &a, &b);
+    int pix_n = 0, pid_n = 0;
+    float dv_n = 0.f;
+    if (a + lane < b) { pix_n = L.s_pix[a + lane]; pid_n = L.s_pid[a + lane]; }
+    if (a + lane < b) dv_n = depth[pid_n];
+    for (int a0 = a; a0 < b; a0 += DHD_WAVE) {
+      const int nb = min(DHD_WAVE, b - a0);
+      const int pix = pix_n, pid = pid_n;
+      const float dv = dv_n;
+      const int col = lane < nb ? column_of(offs, xn, a0 + lane) : 0;
+      const int nxt = a0 + DHD_WAVE + lane;
+      if (nxt < b) { pix_n = L.s_pix[nxt]; pid_n = L.s_pid[nxt]; }
+      float mine = 0.f;  // <out_grad[voxel], feat[pixel]> of the point this lane loaded
+      int i = 0;
+      for (; i + kGatherUnroll <= nb; i += kGatherUnroll) {
+        float f[kGatherUnroll], g[kGatherUnroll];
+        size_t off[kGatherUnroll];
+#pragma unroll
+        for (int j = 0; j < kGatherUnroll; ++j) {
+          off[j] = (size_t)lane_i(pix, i + j) * L.C;
+          f[j] = featc[off[j]];
+          g[j] = trow[lane_i(col, i + j)];
+        }
+#pragma unroll
+        for (int j = 0; j < kGatherUnroll; ++j) {
+          if (!ABL(1)) unsafeAtomicAdd(fgc + off[j], g[j] * lane_f(dv, i + j));
+          float tot = ABL(2) ? g[j] * f[j] : wave_sum_bcast(g[j] * f[j]);
+          if (lane == i + j) mine = tot;
+        }
+      }
+      for (; i < nb; ++i) {
+        const size_t off = (size_t)lane_i(pix, i) * L.C;
+        const float f = featc[off], g = trow[lane_i(col, i)];
+        if (!ABL(1)) unsafeAtomicAdd(fgc + off, g * lane_f(dv, i));
+        float tot = ABL(2) ? g * f : wave_sum_bcast(g * f);
+        if (lane == i) mine = tot;
+      }
+      if (lane < nb && !ABL(4)) {
+        if (dg_atomic) unsafeAtomicAdd(dgp + pid, mine); else dgp[pid] = mine;
+      }
+      if (nxt < b) dv_n = depth[pid_n];
+    }
+    return;
+  }
 
   const int CL = next_pow2(cn);
   const int nsub = DHD_WAVE / CL;
@@ -520,16 +753,24 @@ __global__ __launch_bounds__(kPoolBlock) void mghs_pool_bwd(Layout L, const floa
         float got = __shfl(tot, (owner_sub >= 0 && owner_sub < nsub) ? owner_sub * CL : 0, DHD_WAVE);
         if (owner_sub >= 0 && owner_sub < nsub) mine = got;
       }
-      if (lane < nb) unsafeAtomicAdd(depth_grad + pid, mine);
+      if (lane < nb) {
+        if (dg_atomic) unsafeAtomicAdd(dgp + pid, mine); else dgp[pid] = mine;
+      }
     }
   }
+}
+
+// depth_grad = part(grid 0) + part(band grid)
+__global__ __launch_bounds__(kBlock) void mghs_sum_parts(const float* __restrict__ part, int P, float* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < P) out[i] = part[i] + part[P + i];
 }
 
 int pool_smem_and_stride(const Layout& L, int* stride, size_t* smem) {
   int nx_max = 0;
   for (int g = 0; g < L.G; ++g) nx_max = nx_max > L.grid[g].n[0] ? nx_max : L.grid[g].n[0];
   int xt = nx_max < kMaxTileX ? nx_max : kMaxTileX;
-  int st = ((xt + 3) / 4) * 4 + 4;  // 16-byte aligned rows, +4 floats to spread the transposed accesses
+  int st = xt | 1;  // odd row stride: the transposed (lane = channel) LDS accesses hit 32 distinct banks
   *stride = st;
   *smem = (size_t)kTileC * st * 4 + (size_t)(kMaxTileX + 1) * 4;
   return nx_max;
@@ -538,6 +779,15 @@ int pool_smem_and_stride(const Layout& L, int* stride, size_t* smem) {
 }  // namespace
 
 extern "C" {
+
+#ifdef DHD_ABLATION
+int dhd_debug_set_ablation(int mask) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &mask, sizeof(int));
+}
+int dhd_debug_set_trace(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(void*));
+}
+#endif
 
 int dhd_abi_version(void) { return DHD_ABI_VERSION; }
 
@@ -567,6 +817,8 @@ int dhd_mghs_prepare(const dhd_mghs_desc* desc, const dhd_calib* calib, const ui
   if (L.G > 1 && !band) return DHD_EINVAL;
   hipStream_t st = dhd_stream(stream);
   DHD_HIP(hipMemsetAsync(L.count, 0, (size_t)L.V * 4, st));
+  hipLaunchKernelGGL(mghs_camera, dim3(dhd_cdiv(L.B * L.N, 64)), dim3(64), 0, st, L, *calib);
+  DHD_LAUNCH_CHECK();
   dim3 gp(dhd_cdiv(L.dhw, kBlock), L.B * L.N);
   hipLaunchKernelGGL(mghs_geom_count, gp, dim3(kBlock), 0, st, L, *calib, band);
   DHD_LAUNCH_CHECK();
@@ -592,17 +844,20 @@ int dhd_mghs_forward(const dhd_mghs_desc* desc, const float* depth, const float*
   }
   int stride; size_t smem;
   int nx_max = pool_smem_and_stride(L, &stride, &smem);
-  dim3 grid(8 * dhd_cdiv(L.R, 8), dhd_cdiv(L.C, kTileC), dhd_cdiv(nx_max, kMaxTileX));
-  hipLaunchKernelGGL(mghs_pool_fwd, grid, dim3(kPoolBlock), smem, dhd_stream(stream), L, depth, feat_nhwc, o, stride);
+  dim3 grid(xcd_grouped_blocks(L.R, kRowGroup), dhd_cdiv(L.C, kTileC), dhd_cdiv(nx_max, kMaxTileX));
+  if (L.C % kTileC == 0)
+    hipLaunchKernelGGL(mghs_pool_fwd<true>, grid, dim3(kPoolBlock), smem, dhd_stream(stream), L, depth, feat_nhwc, o, stride);
+  else
+    hipLaunchKernelGGL(mghs_pool_fwd<false>, grid, dim3(kPoolBlock), smem, dhd_stream(stream), L, depth, feat_nhwc, o, stride);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
 
 int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                       const float* const out_grad[DHD_MAX_GRIDS], float* depth_grad, float* feat_grad_nhwc,
-                      const void* workspace, void* stream) {
+                      void* workspace, void* stream) {
   Layout L;
-  int rc = make_layout(desc, const_cast<void*>(workspace), &L, nullptr);
+  int rc = make_layout(desc, workspace, &L, nullptr);
   if (rc) return rc;
   if (!workspace || !depth || !feat_nhwc || !out_grad || !depth_grad || !feat_grad_nhwc) return DHD_EINVAL;
   InPtrs in;
@@ -611,13 +866,19 @@ int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float
     if (g < L.G && !out_grad[g]) return DHD_EINVAL;
   }
   hipStream_t st = dhd_stream(stream);
-  DHD_HIP(hipMemsetAsync(depth_grad, 0, (size_t)L.P * 4, st));
+  DHD_HIP(hipMemsetAsync(L.dg_part, 0, 2 * (size_t)L.P * 4, st));
   DHD_HIP(hipMemsetAsync(feat_grad_nhwc, 0, (size_t)L.B * L.N * L.hw * L.C * 4, st));
   int stride; size_t smem;
   int nx_max = pool_smem_and_stride(L, &stride, &smem);
-  dim3 grid(8 * dhd_cdiv(L.R, 8), dhd_cdiv(L.C, kTileC), dhd_cdiv(nx_max, kMaxTileX));
-  hipLaunchKernelGGL(mghs_pool_bwd, grid, dim3(kPoolBlock), smem, st, L, depth, feat_nhwc, in, depth_grad,
-                     feat_grad_nhwc, stride);
+  dim3 grid(xcd_grouped_blocks(L.R, kRowGroup), dhd_cdiv(L.C, kTileC), dhd_cdiv(nx_max, kMaxTileX));
+  if (L.C % kTileC == 0)
+    hipLaunchKernelGGL(mghs_pool_bwd<true>, grid, dim3(kPoolBlock), smem, st, L, depth, feat_nhwc, in, feat_grad_nhwc,
+                       stride);
+  else
+    hipLaunchKernelGGL(mghs_pool_bwd<false>, grid, dim3(kPoolBlock), smem, st, L, depth, feat_nhwc, in, feat_grad_nhwc,
+                       stride);
+  DHD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mghs_sum_parts, dim3(dhd_cdiv(L.P, kBlock)), dim3(kBlock), 0, st, L.dg_part, L.P, depth_grad);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }

@@ -138,19 +138,20 @@ int dhd_mghs_prepare(const dhd_mghs_desc* desc, const dhd_calib* calib, const ui
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Pooling forward for all grids.  depth (B*N,D,fH,fW); feat_nhwc (B*N,fH,fW,C).
- * out[g] is the FINAL reference layout (B, nz_g*C, ny_g, nx_g) with channel = z*C + c
- * (bev_pool.py:105 permute + lss_heightmap.py:298-299 collapse_z; identical memory to the
- * un-collapsed (B,C... ) no: to (B,nz,C,ny,nx)).  Every element is written (zeros included);
- * no pre-zeroing needed. */
+ * out[g] is the FINAL reference layout (B, nz_g*C, ny_g, nx_g) with channel = z*C + c, i.e. the
+ * result of bev_pool.py:105 (permute) followed by lss_heightmap.py:298-299 (collapse_z); the same
+ * memory viewed as (B, nz_g, C, ny_g, nx_g) serves collapse_z=False.  Every element is written
+ * (zeros included); no pre-zeroing needed. */
 int dhd_mghs_forward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                      float* const out[DHD_MAX_GRIDS], const void* workspace, void* stream);
 
 /* Pooling backward.  out_grad[g] has the layout of out[g].  depth_grad (B*N,D,fH,fW) and
  * feat_grad_nhwc (B*N,fH,fW,C) are fully overwritten (zero-filled internally).  Pixels outside
- * a band contribute nothing to that band's grid, matching d(tran_feat * mask), :436-442. */
+ * a band contribute nothing to that band's grid, matching d(tran_feat * mask), :436-442.
+ * The workspace's scratch region is written (the grouping produced by prepare is not). */
 int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                       const float* const out_grad[DHD_MAX_GRIDS], float* depth_grad,
-                      float* feat_grad_nhwc, const void* workspace, void* stream);
+                      float* feat_grad_nhwc, void* workspace, void* stream);
 
 /* Introspection for parity tests and for the voxel_pooling_prepare_v2 mirror: per-point voxel
  * rank of ONE grid for every frustum point, -1 if dropped (band-independent), i.e. the map
