@@ -29,7 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from dhd_amd import _lib, mghs_op, synthetic as syn  # noqa: E402
+from dhd_amd import _lib, dist as ddist, mghs_op, synthetic as syn  # noqa: E402
 from dhd_amd.mix import channel_spatial_stage  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
@@ -137,19 +137,14 @@ def cpu_baseline(hp, n_samples):
 
 def main():
     a = parse()
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    rank, local, world = ddist.env_world()
     if world != a.gpus and world > 1:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    ddist.init_from_env(backend='nccl', device=dev)  # RCCL; used only for the barrier / MAX around the timed region
     _lib.load()
     hp = HotPath(dev, a.batch, 1000 + rank, not a.no_sfa)
 
@@ -158,20 +153,15 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        ddist.barrier()
+        torch.cuda.synchronize()
 
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         hp.step(True)
     fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
 
     if rank == 0:
         kern_ms = float(np.mean([s.elapsed_time(e) for s, e in hp.ev]))
@@ -190,9 +180,7 @@ def main():
         if world == 1 and a.cpu_samples > 0:
             line['cpu_baseline'] = cpu_baseline(hp, a.cpu_samples)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ddist.shutdown()
 
 
 if __name__ == '__main__':

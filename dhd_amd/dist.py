@@ -1,0 +1,67 @@
+"""Process-group plumbing for the sample-sharded (data-parallel) hot path.
+
+The MGHS/SFA path has no cross-sample reduction (every index carries the batch id,
+models/necks/lss_heightmap.py:335-337,351-352; SFA's mean is per sample, mix.py:41), so ranks
+take disjoint samples and exchange nothing on the data path.  The only collectives are the
+ones a training step needs around it: a barrier + MAX of the elapsed time for measurement, and
+the gradient all-reduce of the dense modules' parameters (RCCL when the backend is "nccl").
+One process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+
+
+def init_from_env(backend=None, device=None):
+    """Initialise the default process group from the launcher's environment (no-op for 1 rank).
+    backend: 'nccl' (= RCCL on ROCm) for GPU ranks, 'gloo' for CPU tests."""
+    rank, local, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        kw = {}
+        if backend == 'nccl' and device is not None:
+            kw['device_id'] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local, world
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced [lo, hi) of `n_items` independent samples for `rank`."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device='cpu'):
+    """MAX of a python float over all ranks (the slowest rank defines the step time)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device='cpu'):
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()

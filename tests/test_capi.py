@@ -1,0 +1,94 @@
+"""C-ABI surface checks that need no GPU: the library loads, exports every symbol the header
+declares, validates arguments before touching the device, and the package fails loudly
+(instead of falling back) when the library or the GPU is missing."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'dhd_amd.h')
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\bint\s+(dhd_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_and_binding_table_agree():
+    from dhd_amd import _lib
+    assert declared_symbols() == sorted(_lib.EXPORTED_SYMBOLS)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from dhd_amd import _lib
+    lib = _lib.load()
+    assert os.path.samefile(_lib.LIB_PATH, os.path.join(ROOT, 'dhd_amd', 'csrc', 'libdhd_amd.so'))
+    for name in declared_symbols():
+        assert getattr(lib, name) is not None, name
+    assert lib.dhd_abi_version() == _lib.ABI_VERSION
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r' T (dhd_[a-z0-9_]+)', out))
+    assert exported == set(declared_symbols()), exported ^ set(declared_symbols())
+
+
+def test_library_is_a_gfx950_code_object():
+    from dhd_amd import _lib
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    assert b'gfx950' in blob and b'gfx90a' not in blob and b'sm_' not in blob
+
+
+def test_argument_validation_happens_on_the_host():
+    from dhd_amd import _lib
+    lib = _lib.load()
+    n = C.c_size_t(0)
+    d = _lib.MghsDesc()
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == -1  # all-zero desc
+    d.batch, d.n_cams, d.n_depth, d.fh, d.fw, d.channels, d.n_grids = 1, 6, 44, 16, 44, 64, 4
+    for g, nz in zip(range(4), (1, 4, 4, 8)):
+        d.grid[g].n[0], d.grid[g].n[1], d.grid[g].n[2] = 200, 200, nz
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == 0
+    per_sample = n.value
+    assert 8e6 < per_sample < 2e7  # ~2V + 8P ints: about 12 MB per DHD-S sample
+    d.batch = 4
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == 0 and 3.9 * per_sample < n.value < 4.1 * per_sample
+    d.n_grids = 5
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == -1
+    d.n_grids = 4
+    assert lib.dhd_mghs_prepare(C.byref(d), None, None, None, 0, None) == -1
+    assert lib.dhd_bev_pool_v2_forward(None, None, None, None, None, None, None, None, 64, 10, None) == -1
+    assert lib.dhd_bev_pool_v2_forward(None, None, None, None, None, None, None, None, 64, 0, None) == 0  # nothing to do
+    assert lib.dhd_sfa_channel_mean(None, None, 1, 512, 40000, None) == -1
+    assert lib.dhd_height_band(None, 6, 65, 16, 44, None, None, None, None) == -1
+    d.batch = 1 << 20
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == -3  # beyond the int32 index space
+
+
+def test_no_silent_fallback_without_gpu_or_library():
+    from dhd_amd import _lib, bev_pool_v2, SFA
+    from dhd_amd import mghs_op
+    z = torch.zeros(0, dtype=torch.int32)
+    with pytest.raises(_lib.DhdError):
+        bev_pool_v2(torch.rand(1, 1, 2, 2, 2), torch.rand(1, 1, 2, 2, 4), z, z, z, (1, 1, 3, 3, 4), z, z)
+    with pytest.raises(_lib.DhdError):
+        SFA(32, 16)(torch.rand(1, 32, 5, 5))
+    with pytest.raises(_lib.DhdError):
+        mghs_op.height_band(torch.rand(2, 65, 4, 11), [0.1 * i for i in range(65)], [0, 1, 2, 3])
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['DHD_AMD_LIB'] = '/nonexistent/libdhd_amd.so'\n"
+            "from dhd_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.DhdError as e:\n    print('LOUD', e)\n" % ROOT)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+    assert 'LOUD' in out.stdout and 'no CPU or PyTorch fallback' in out.stdout
+
+
+def test_product_code_never_imports_the_oracle():
+    for base, _, files in os.walk(os.path.join(ROOT, 'dhd_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(base, f)).read()
+                assert 'oracle' not in text.replace('oracle-free', ''), os.path.join(base, f)

@@ -1,0 +1,74 @@
+"""world_size-2 checks on CPU (gloo): sample sharding, the timing collectives bench.py uses, and
+gradient averaging of the dense producer (HeightNet) under DDP -- the N>1 path of the hot path is
+'shard the samples, all-reduce only parameter gradients'."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from dhd_amd import dist as D
+    from dhd_amd import HeightNet
+    r, _, w = D.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    lo, hi = D.shard_range(7, r, w)
+    D.barrier()
+    slow = D.max_over_ranks(1.0 + r)
+    total = D.sum_over_ranks(hi - lo)
+    # DDP over the dense producer: each rank sees different samples, gradients come out averaged
+    torch.manual_seed(0)
+    net = HeightNet(16, 16, 9, use_dcn=False, use_aspp=False)
+    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    g = torch.Generator().manual_seed(100 + r)
+    x, mlp = torch.randn(2, 16, 4, 6, generator=g), torch.randn(1, 2, 27, generator=g)
+    ddp(x, mlp).square().mean().backward()
+    grad = net.depth_conv[-1].weight.grad.clone()
+    q.put((rank, (lo, hi), slow, total, grad))
+    D.shutdown()
+
+
+def test_gloo_world_size_2_sharding_timing_and_ddp():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == (0, 4) and res[1][1] == (4, 7)          # disjoint cover of the 7 samples
+    assert res[0][2] == res[1][2] == 2.0                        # MAX over ranks
+    assert res[0][3] == res[1][3] == 7.0
+    assert torch.allclose(res[0][4], res[1][4]) and res[0][4].abs().sum() > 0  # averaged gradients agree
+
+
+def test_shard_range_properties():
+    sys.path.insert(0, ROOT)
+    from dhd_amd.dist import shard_range
+    for n in (0, 1, 5, 8, 33):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

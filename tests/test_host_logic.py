@@ -1,0 +1,131 @@
+"""Host-side mirror of the reference interface, on CPU: registry/config surface, module state,
+the small torch-level helpers, against the goldens recorded from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, golden_calib
+from dhd_amd import synthetic as syn
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_registry_builds_reference_type_names():
+    import dhd_amd
+    for name in ('MGHS', 'MGHS_Depth', 'MGHS_Stereo', 'SFA'):
+        assert name in dhd_amd.NECKS
+    m = dhd_amd.build_neck(dict(type='SFA', in_channels=512, out_channels=256))
+    assert sum(p.numel() for p in m.parameters()) == 1469728  # measured on the reference's mix.py
+    with pytest.raises(KeyError):
+        dhd_amd.build_neck(dict(type='LSSViewTransformer'))
+    assert dhd_amd.build_neck(None) is None
+
+
+def test_mghs_constructor_state_matches_reference():
+    import dhd_amd
+    cfg = syn.dhd_s_config()
+    m = dhd_amd.build_neck(dict(cfg, type='MGHS'))
+    g0 = golden('g0_frustum')
+    assert m.D == 44 and m.H == 65 and tuple(m.frustum.shape) == (44, 16, 44, 3)
+    assert np.array_equal(m.frustum[0, 0, :, 0].numpy(), g0['dhds_u'])
+    assert np.array_equal(m.frustum[0, :, 0, 1].numpy(), g0['dhds_v'])
+    assert np.array_equal(m.frustum[:, 0, 0, 2].numpy(), g0['dhds_d'])
+    assert m.grid_size.tolist() == [200.0, 200.0, 1.0] and m.grid_lower_bound.tolist() == [-40.0, -40.0, -1.0]
+    keys = set(m.state_dict())
+    for k in ('depth_net.weight', 'depth_net.bias', 'height_net.reduce_conv.0.weight', 'height_net.bn.running_mean',
+              'height_net.depth_mlp.fc1.weight', 'height_net.depth_se.conv_reduce.weight',
+              'height_net.depth_conv.0.conv1.weight', 'height_net.depth_conv.3.aspp1.atrous_conv.weight',
+              'height_net.depth_conv.4.conv_offset.weight', 'height_net.depth_conv.4.weight',
+              'height_net.depth_conv.5.weight'):
+        assert k in keys, k
+    assert tuple(m.depth_net.weight.shape) == (44 + 64, 256, 1, 1)
+    assert sum(p.numel() for p in m.parameters()) == 6801909
+    md = dhd_amd.build_neck(dict(cfg, type='MGHS_Depth', collapse_z=False, depthnet_cfg=dict(use_dcn=False),
+                                 grid_config=dict(cfg['grid_config'], depth=[1.0, 45.0, 0.5])))
+    assert md.D == 88 and 'depth_net.context_conv.weight' in md.state_dict() and md.loss_depth_weight == 3.0
+    ms = dhd_amd.build_neck(dict(cfg, type='MGHS_Stereo', heightnet_cfg=dict(use_dcn=False), depthnet_cfg=dict(use_dcn=False, stereo=True)))
+    assert tuple(ms.cv_frustum.shape) == (44, 64, 176, 3) and tuple(ms.frustum.shape) == (44, 16, 44, 3)
+    assert 'depth_net.cost_volumn_net.0.weight' in ms.state_dict()
+
+
+def test_mlp_input_and_losses_match_reference_fixtures():
+    import dhd_amd
+    g = golden('g4_loss')
+    cfg = syn.dhd_s_config()
+    cfg['input_size'] = (64, 176)
+    m = dhd_amd.MGHS(**cfg)
+    calib = [T(a) for a in golden_calib(g)]
+    assert np.array_equal(m.get_mlp_input(*calib).numpy(), g['mlp_input'])
+    gd, gh, hp = T(g['gt_depth']), T(g['gt_height']), T(g['height_prob'])
+    np.testing.assert_array_equal(m.get_downsampled_gt_height(gh).numpy(), g['gt_height_onehot'])
+    np.testing.assert_array_equal(m.get_downsampled_gt_depth(gd).numpy(), g['gt_depth_onehot_init'])
+    assert abs(float(m.get_height_loss(gd, gh, hp)) - float(g['loss_height_init'])) < 1e-6
+    # the state view_transform leaves behind (mask_3_grid: depth interval 0.5 while D stays 44)
+    m._set_grid(m.mask_3_grid)
+    np.testing.assert_array_equal(m.get_downsampled_gt_depth(gd).numpy(), g['gt_depth_onehot_after_forward'])
+    assert abs(float(m.get_height_loss(gd, gh, hp)) - float(g['loss_height_after_forward'])) < 1e-6
+    sparse = m.downsample_sparse_map(gh, 16)
+    assert tuple(sparse.shape) == (1, 2, 4, 11) and float(sparse.min()) >= -1.5
+
+
+def test_height_map_helpers_follow_reference_semantics():
+    import dhd_amd
+    from oracle import mghs_oracle as O
+    cfg = syn.dhd_s_config()
+    m = dhd_amd.MGHS(**cfg)
+    idx = syn.height_index(9, (3, 16, 44), 65)
+    hm = m.height_feature_to_height_map(T(syn.height_probs_from_index(idx, 65)), m.height_range)
+    masks = m.create_mask_3(hm, *m.mask_range)
+    band = np.full(idx.shape, 255, np.uint8)
+    for k, mk in enumerate(masks):
+        band[mk.numpy()] = k
+    assert np.array_equal(band, O.band_index(idx, cfg['height_range'], cfg['mask_range']))
+    with pytest.raises(ValueError):
+        m.height_feature_to_height_map(torch.zeros(2, 3, 4), m.height_range)
+
+
+def test_voxel_pooling_prepare_v2_mirror_on_cpu_matches_reference_lists():
+    """The API-parity index routine is plain torch and must reproduce the reference's lists
+    (canonical order) from the reference's own coordinates."""
+    import dhd_amd
+    from conftest import small_dhds_cfg
+    g = golden('g2b_small_dhds')
+    cfg = small_dhds_cfg()
+    m = dhd_amd.MGHS(**dict(cfg, heightnet_cfg=dict(use_dcn=False)))
+    coor = T(g['coor'])
+    grids = [dict(x=[-40, 40, 0.4], y=[-40, 40, 0.4], z=[-1, 5.4, 6.4]), cfg['mask_1_grid'], cfg['mask_2_grid'], cfg['mask_3_grid']]
+    for k, grid in enumerate(grids):
+        m.create_grid_infos(**{a: grid[a] for a in 'xyz'})
+        rb, rd, rf, st, ln = m.voxel_pooling_prepare_v2(coor)
+        for a, n in ((rb, 'ranks_bev'), (rd, 'ranks_depth'), (rf, 'ranks_feat'), (st, 'interval_starts'), (ln, 'interval_lengths')):
+            assert a.dtype == torch.int32 and np.array_equal(a.numpy(), g[n + str(k)]), (n, k)
+    far = coor + 1000.0
+    assert m.voxel_pooling_prepare_v2(far) == (None, None, None, None, None)
+
+
+def test_heightnet_and_depthnet_run_on_cpu_with_reference_shapes():
+    from dhd_amd import HeightNet, DepthNet
+    torch.manual_seed(0)
+    hn = HeightNet(32, 32, 65).eval()
+    x, mlp = torch.randn(4, 32, 4, 11), torch.randn(2, 2, 27)
+    assert tuple(hn(x, mlp).shape) == (4, 65, 4, 11)
+    dn = DepthNet(32, 32, 16, 44, use_dcn=False, aspp_mid_channels=24).eval()
+    assert tuple(dn(x, mlp).shape) == (4, 44 + 16, 4, 11)
+    # zero-initialised offsets: the deformable conv equals a plain grouped 3x3 conv
+    dcn = hn.depth_conv[4]
+    y = torch.randn(2, 32, 5, 7)
+    ref = torch.nn.functional.conv2d(y, dcn.weight, padding=1, groups=4)
+    assert torch.allclose(dcn(y), ref, atol=1e-5)
+
+
+def test_synthetic_inputs_are_bit_reproducible():
+    a = syn.lift_inputs(5, 1, 2, 44, 4, 11, 8, 65)
+    b = syn.lift_inputs(5, 1, 2, 44, 4, 11, 8, 65)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert float(a[0].min()) > 0 and a[2].max() < 65
+    import hashlib
+    assert hashlib.sha256(syn.hash_u32(7, 1000).tobytes()).hexdigest()[:16] == hashlib.sha256(syn.hash_u32(7, 1000).tobytes()).hexdigest()[:16]
+    c = syn.make_calibration(3, 2, 6)
+    assert c[0].shape == (2, 6, 4, 4) and np.allclose(np.linalg.det(c[0][:, :, :3, :3].astype(np.float64)), 1.0, atol=1e-5)
