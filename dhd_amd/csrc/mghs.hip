@@ -16,13 +16,24 @@
 namespace {
 
 constexpr int kBlock = 256;      // geometry / scan / scatter
-constexpr int kPoolBlock = 512;  // pooling: 8 waves per output row tile
+#ifndef DHD_POOL_BLOCK
+#define DHD_POOL_BLOCK 512
+#endif
+#ifndef DHD_TILE_X
+#define DHD_TILE_X 256
+#endif
+constexpr int kPoolBlock = DHD_POOL_BLOCK;  // pooling: waves per output tile
 constexpr int kPoolWaves = kPoolBlock / DHD_WAVE;
 constexpr int kScanItems = 8;
 constexpr int kChunk = kBlock * kScanItems;  // counters per scan block
-constexpr int kMaxTileX = 256;               // voxels along x per pooling tile
+constexpr int kMaxTileX = DHD_TILE_X;        // voxels along x per pooling tile
 constexpr int kTileC = 64;                   // channels per pooling tile (one wave lane each)
 constexpr int kCamFloats = 36;               // sizeof(CamMats)/4 = 33, padded
+constexpr int kRowGroup = 4;                 // consecutive dense rows handed to one XCD (25 whole cache lines at nx=200)
+constexpr int kGroupRows = 4;                // rows per sparse group
+constexpr int kGroupMaxVox = 1024;           // voxels per sparse group (kGroupRows * nx)
+constexpr int kGroupSlots = 128;             // non-empty voxels a sparse group can hold before it falls back to dense rows
+constexpr int kGroupMaxPts = 2048;           // points above which a group goes straight to the dense path
 
 // Host-derived layout, passed to kernels by value.
 struct Layout {
@@ -33,8 +44,14 @@ struct Layout {
   int V;         // total voxels over all grids
   int R;         // total output rows (b, z, y) over all grids
   int n_chunks;  // scan blocks
-  int sched_heavy;  // row groups of grid 0 that are front-loaded 1:sched_ratio among the others (0 = off)
-  int sched_ratio;
+  int nxc;          // x chunks per dense row
+  // pooling work list: `n_dense_rows` rows are processed one row per workgroup through a dense LDS
+  // tile (grid 0, or every row when grouping is off); the remaining rows are processed as
+  // `n_groups` groups of kGroupRows consecutive rows through the sparse path.
+  int n_dense_rows, n_groups;
+  int sched_cycles, sched_light;  // per XCD: `sched_cycles` x (kRowGroup dense rows + sched_light groups), then groups only
+  int per_xcd;                    // work items per XCD
+  int sched_heavy, sched_ratio;   // row-only schedule (backward): grid-0 row groups front-loaded 1:ratio
   int vox_base[DHD_MAX_GRIDS + 1];
   int row_base[DHD_MAX_GRIDS + 1];
   dhd_grid grid[DHD_MAX_GRIDS];
@@ -46,6 +63,7 @@ struct Layout {
   int* rnk;        // [2P]    arrival rank of the point inside its voxel
   int* s_pid;      // [2P]    point ids grouped by voxel (index into depth)
   int* s_pix;      // [2P]    pixel ids grouped by voxel (row of feat_nhwc)
+  int* s_vox;      // [2P]    voxel id of every grouped entry (non-decreasing)
   float* cam;      // [B*N*kCamFloats] per-camera matrices (CamMats), written by mghs_camera
   float* dg_part;  // [2P] backward scratch: depth-gradient parts from grid 0 ([p]) and the band grid ([P+p])
 };
@@ -92,18 +110,42 @@ int make_layout(const dhd_mghs_desc* d, void* ws, Layout* L, size_t* bytes) {
   L->rnk = carve(2 * (size_t)L->P);
   L->s_pid = carve(2 * (size_t)L->P);
   L->s_pix = carve(2 * (size_t)L->P);
+  L->s_vox = carve(2 * (size_t)L->P);
   L->cam = reinterpret_cast<float*>(carve((size_t)L->B * L->N * kCamFloats));
   L->dg_part = reinterpret_cast<float*>(carve(2 * (size_t)L->P));
-  // Launch order of the pooling tiles: grid 0 pools every pixel over the whole height, so its rows
-  // carry ~10x the points of a band-grid row.  Their gather is latency-bound; if they are
-  // dispatched back to back they occupy every workgroup slot and the HBM streaming of the light
-  // rows cannot start.  Front-load them, but interleaved 1:k with light row groups.
+  {
+    int nx_max = 0;
+    for (int g = 0; g < L->G; ++g) nx_max = nx_max > L->grid[g].n[0] ? nx_max : L->grid[g].n[0];
+    L->nxc = (nx_max + kMaxTileX - 1) / kMaxTileX;
+  }
+  // Work list and launch order.  Grid 0 pools every pixel over the whole height: its rows carry
+  // ~10x the points of a band-grid row and go through the dense row tile.  Band-grid rows hold a
+  // handful of points each: they are processed four rows at a time (3200 contiguous, line-aligned
+  // bytes per channel at nx=200) by the sparse path.  Dense rows are latency-bound; dispatched back
+  // to back they would occupy every workgroup slot while HBM idles, so each XCD alternates
+  // kRowGroup dense rows with `sched_light` groups until the dense rows are used up.
+  bool grouping = L->G > 1 && L->C == kTileC && L->nxc == 1 && L->row_base[1] % kRowGroup == 0;
+  for (int g = 1; g < L->G && grouping; ++g)
+    grouping = L->grid[g].n[1] % kGroupRows == 0 && L->grid[g].n[0] % 4 == 0 && L->grid[g].n[0] * kGroupRows <= kGroupMaxVox;
+  L->n_dense_rows = grouping ? L->row_base[1] : L->R;
+  L->n_groups = grouping ? (L->R - L->row_base[1]) / kGroupRows : 0;
+  {
+    const int dense_tiles = L->n_dense_rows * L->nxc;
+    const int unit = kRowGroup * L->nxc;                      // dense tiles handed to an XCD at a time
+    const int dense_units = (dense_tiles + unit - 1) / unit;
+    L->sched_cycles = (dense_units + 7) / 8;
+    const int groups_per_xcd = (L->n_groups + 7) / 8;
+    L->sched_light = L->sched_cycles > 0 && groups_per_xcd >= 2 * L->sched_cycles ? 2 : 0;
+    int rest = groups_per_xcd - L->sched_cycles * L->sched_light;
+    if (rest < 0) rest = 0;
+    L->per_xcd = L->sched_cycles * (unit + L->sched_light) + rest;
+  }
   L->sched_heavy = 0; L->sched_ratio = 0;
-  if (L->G > 1 && L->row_base[1] % 4 == 0) {
-    int heavy = L->row_base[1] / 4, light = (L->R - L->row_base[1]) / 4;
+  if (L->G > 1 && L->row_base[1] % kRowGroup == 0) {
+    int heavy = L->row_base[1] / kRowGroup, light = (L->R - L->row_base[1]) / kRowGroup;
     int k = heavy > 0 ? light / heavy : 0;
     // the period k+1 must be odd: row groups go round-robin over the 8 XCDs, an even period would
-    // put every heavy group on the same few XCDs
+    // put every heavy group on the same few XCDs (measured: XCDs {0,4} only)
     if (k > 4) k = 4;
     if (k == 3) k = 2;
     if (k == 1) k = 0;
@@ -371,6 +413,7 @@ __global__ __launch_bounds__(kBlock) void mghs_scatter(Layout L) {
       int pos = L.offset[k] + L.rnk[j * L.P + pid];
       L.s_pid[pos] = pid;
       L.s_pix[pos] = pix;
+      L.s_vox[pos] = k;
     }
   }
 }
@@ -415,7 +458,7 @@ __device__ long long* g_trace = nullptr;  // 8 x int64 per block: tile, t0..t3 (
 #define ABL(bit) ((g_ablate & (bit)) != 0)
 #define TRACE(slot, val)                                                             \
   do {                                                                               \
-    if (g_trace && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)           \
+    if (g_trace && threadIdx.x == 0 && blockIdx.y == 0)           \
       g_trace[(size_t)blockIdx.x * 8 + (slot)] = (long long)(val);                   \
   } while (0)
 #define NOW() wall_clock64()
@@ -427,7 +470,6 @@ __device__ long long* g_trace = nullptr;  // 8 x int64 per block: tile, t0..t3 (
 
 typedef float vfloat4 __attribute__((ext_vector_type(4)));  // native vector: accepted by the nontemporal builtins
 
-constexpr int kRowGroup = 4;   // consecutive output rows handed to one XCD (25 whole cache lines at nx=200)
 constexpr int kGatherUnroll = 16;  // feature rows in flight per wave
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -436,11 +478,14 @@ __device__ __forceinline__ float lane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// blockIdx -> output row: XCD-grouped, then heavy (grid 0) row groups front-loaded 1:k.
-__device__ __forceinline__ int scheduled_row(const Layout& L, int block) {
-  const int pos = xcd_grouped_tile(block, kRowGroup);
-  int grp = pos / kRowGroup;
-  const int within = pos % kRowGroup;
+// blockIdx -> (output row, x chunk) for the row-only schedule: XCD-grouped (all chunks of kRowGroup
+// rows stay on one XCD, back to back), then heavy (grid 0) row groups front-loaded 1:k.
+__device__ __forceinline__ int scheduled_tile(const Layout& L, int block, int* xchunk) {
+  const int pos = xcd_grouped_tile(block, kRowGroup * L.nxc);
+  *xchunk = pos % L.nxc;
+  const int rpos = pos / L.nxc;
+  int grp = rpos / kRowGroup;
+  const int within = rpos % kRowGroup;
   if (L.sched_heavy > 0) {
     const int k1 = L.sched_ratio + 1;
     if (grp < L.sched_heavy * k1) {
@@ -449,6 +494,29 @@ __device__ __forceinline__ int scheduled_row(const Layout& L, int block) {
     }
   }
   return grp * kRowGroup + within;
+}
+
+// blockIdx -> work item of the forward work list (see make_layout): returns 0 = nothing,
+// 1 = dense row tile (*row, *xchunk), 2 = sparse group (*row = first row of the group).
+__device__ __forceinline__ int scheduled_work(const Layout& L, int block, int* row, int* xchunk) {
+  const int xcd = block & 7, i = block >> 3;
+  const int unit = kRowGroup * L.nxc, period = unit + L.sched_light;
+  int group;
+  if (i < L.sched_cycles * period) {
+    const int cycle = i / period, r = i % period;
+    if (r < unit) {
+      const int t = (cycle * 8 + xcd) * unit + r;
+      *row = t / L.nxc;
+      *xchunk = t % L.nxc;
+      return *row < L.n_dense_rows ? 1 : 0;
+    }
+    group = (cycle * L.sched_light + (r - unit)) * 8 + xcd;
+  } else {
+    group = (L.sched_cycles * L.sched_light + (i - L.sched_cycles * period)) * 8 + xcd;
+  }
+  *row = L.n_dense_rows + group * kGroupRows;
+  *xchunk = 0;
+  return group < L.n_groups ? 2 : 0;
 }
 
 // voxel (column of the tile) that sorted point `idx` belongs to: the x with offs[x] <= idx < offs[x+1]
@@ -461,16 +529,6 @@ __device__ __forceinline__ int column_of(const int* offs, int xn, int idx) {
   return lo;
 }
 
-// smallest column x in [0, xn] with offs[x] >= idx (offs is non-decreasing)
-__device__ __forceinline__ int first_column_at_or_after(const int* offs, int xn, int idx) {
-  int lo = 0, hi = xn;
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (offs[mid] < idx) lo = mid + 1; else hi = mid;
-  }
-  return rfl(lo);
-}
-
 // The sorted points of a row are split evenly over the waves of the workgroup (multiples of
 // kGatherUnroll), independent of how they cluster into voxels.
 __device__ __forceinline__ void wave_point_range(const int* offs, int xn, int wv, int* a, int* b) {
@@ -481,84 +539,104 @@ __device__ __forceinline__ void wave_point_range(const int* offs, int xn, int wv
   *b = min(s + n, *a + per);
 }
 
-// FULL: the channel tile is exactly 64 wide -> lane == channel; point indices are wave-uniform and
-// travel through SGPRs (v_readlane); kGatherUnroll feature rows are in flight per wave; products
-// are accumulated straight into the LDS tile with ds_add_f32 (tile_stride is odd: conflict-free).
-template <bool FULL>
-__global__ __launch_bounds__(kPoolBlock) void mghs_pool_fwd(Layout L, const float* __restrict__ depth,
-                                                            const float* __restrict__ feat, OutPtrs out, int tile_stride) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* tile = reinterpret_cast<float*>(smem);                      // [kTileC][tile_stride]
-  int* offs = reinterpret_cast<int*>(smem + (size_t)kTileC * tile_stride * 4);  // [kMaxTileX + 1]
-
-  RowTile rt;
-  if (!decode_row(L, scheduled_row(L, blockIdx.x), &rt)) return;
-  const int c0 = blockIdx.y * kTileC;
-  const int cn = FULL ? kTileC : min(kTileC, L.C - c0);
-  const int x0 = blockIdx.z * kMaxTileX;
-  if (x0 >= rt.nx) return;
-  const int xn = min(kMaxTileX, rt.nx - x0);
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  TRACE(0, rt.vrow); TRACE(1, NOW());
-
-  for (int i = t; i <= xn; i += kPoolBlock) offs[i] = L.offset[rt.vrow + x0 + i];
-  for (int i = t; i < cn * tile_stride; i += kPoolBlock) tile[i] = 0.f;
-  __syncthreads();
-  TRACE(2, NOW()); TRACE(6, offs[xn] - offs[0]);
-  TRACE(5, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)));  // HW_REG_XCC_ID, bits 3:0
-
-  if (offs[xn] != offs[0] && !ABL(8)) {  // rows without any point (most of them) skip the gather entirely
-    if (FULL) {
-      const float* featc = feat + c0 + lane;
-      float* trow = tile + lane * tile_stride;
-      int a, b;
-      wave_point_range(offs, xn, wv, &a, &b);
-      // own the voxels whose first point lies in [a, b): every voxel has exactly one writer
-      a = rfl(offs[first_column_at_or_after(offs, xn, a)]);
-      b = rfl(offs[first_column_at_or_after(offs, xn, b)]);
-      int cur = -1;      // column being accumulated (wave-uniform)
-      float acc = 0.f;
-      int pix_n = 0, pid_n = 0;
-      float dv_n = 0.f;
-      if (a < b) {
-        if (a + lane < b) { pix_n = L.s_pix[a + lane]; pid_n = L.s_pid[a + lane]; }
-        if (a + lane < b) dv_n = depth[pid_n];
-      }
-      for (int a0 = a; a0 < b; a0 += DHD_WAVE) {
-        const int nb = min(DHD_WAVE, b - a0);
-        const int pix = pix_n;
-        const float dv = dv_n;
-        const int col = lane < nb ? column_of(offs, xn, a0 + lane) : 0;
-        const int nxt = a0 + DHD_WAVE + lane;
-        if (nxt < b) { pix_n = L.s_pix[nxt]; pid_n = L.s_pid[nxt]; }  // next batch's indices: in flight during this one
-        int i = 0;
-        for (; i + kGatherUnroll <= nb; i += kGatherUnroll) {
-          float f[kGatherUnroll];
+// ---------------------------------------------------------------------------------------
+// Forward gather.  The sorted entries [S, E) of a row (or row group) are a non-decreasing stream of
+// voxel ids.  Wave `wv` owns the voxels whose FIRST entry lies in its slice [a, b) of the stream
+// (so every voxel has exactly one owner and no atomics are needed), accumulates
+// sum depth * feat[pixel, lane] in a register (lane = channel) and hands each finished voxel to
+// `flush(voxel, acc)`.  Entry indices are wave-uniform and travel through SGPRs (v_readlane);
+// kGatherUnroll feature rows are in flight per wave; the next batch's index words and depth
+// values are fetched while the current batch is processed.
+// ---------------------------------------------------------------------------------------
+template <class Flush>
+__device__ __forceinline__ void gather_owned(const Layout& L, const float* __restrict__ depth,
+                                             const float* __restrict__ featc, int S, int E, int a, int b, int lane,
+                                             Flush&& flush) {
+  if (a >= b) return;
+  const int C = L.C;
+  bool active = false, done = false;
+  int cur = -1;
+  float acc = 0.f;
+  int idx = a + lane;
+  int vox_n = -1, prev_n = -2, pix_n = 0, pid_n = 0;
+  float dv_n = 0.f;
+  if (idx < E) {
+    vox_n = L.s_vox[idx];
+    pix_n = L.s_pix[idx];
+    pid_n = L.s_pid[idx];
+    if (idx > S) prev_n = L.s_vox[idx - 1];
+  }
+  if (idx < E) dv_n = depth[pid_n];
+  for (int a0 = a; a0 < E && !done; a0 += DHD_WAVE) {
+    const int nb = min(DHD_WAVE, E - a0);
+    const int vox = vox_n, pix = pix_n;
+    const float dv = dv_n;
+    const unsigned long long firsts = __ballot(lane < nb && vox != prev_n);
+    idx = a0 + DHD_WAVE + lane;
+    if (idx < E) {  // next batch (it may lie past b: the last owned voxel can run over the slice end)
+      vox_n = L.s_vox[idx];
+      pix_n = L.s_pix[idx];
+      pid_n = L.s_pid[idx];
+      prev_n = L.s_vox[idx - 1];
+    }
+    for (int i0 = 0; i0 < nb && !done; i0 += kGatherUnroll) {
+      float f[kGatherUnroll];
 #pragma unroll
-          for (int j = 0; j < kGatherUnroll; ++j) f[j] = featc[(size_t)lane_i(pix, i + j) * L.C];
+      for (int j = 0; j < kGatherUnroll; ++j) f[j] = featc[(size_t)lane_i(pix, min(i0 + j, nb - 1)) * C];
 #pragma unroll
-          for (int j = 0; j < kGatherUnroll; ++j) {
-            const int cj = lane_i(col, i + j);
-            if (cj != cur) {
-              if (cur >= 0) trow[cur] = acc;
-              acc = 0.f;
-              cur = cj;
-            }
-            acc = fmaf(lane_f(dv, i + j), f[j], acc);
-          }
-        }
-        for (; i < nb; ++i) {
-          const int cj = lane_i(col, i);
-          if (cj != cur) {
-            if (cur >= 0) trow[cur] = acc;
+      for (int j = 0; j < kGatherUnroll; ++j) {
+        const int i = i0 + j;
+        if (i < nb && !done) {
+          if ((firsts >> i) & 1ull) {
+            if (active) flush(cur, acc);
+            active = a0 + i < b;
+            done = !active;
+            cur = lane_i(vox, i);
             acc = 0.f;
-            cur = cj;
           }
-          acc = fmaf(lane_f(dv, i), featc[(size_t)lane_i(pix, i) * L.C], acc);
+          if (active) acc = fmaf(lane_f(dv, i), f[j], acc);
         }
-        if (nxt < b) dv_n = depth[pid_n];  // its latency hides under the next batch's first feature loads
       }
-      if (cur >= 0) trow[cur] = acc;
+    }
+    if (idx < E) dv_n = depth[pid_n];
+  }
+  if (active) flush(cur, acc);
+}
+
+__device__ __forceinline__ void wave_slice(int S, int E, int wv, int* a, int* b) {
+  const int n = E - S;
+  int per = (n + kPoolWaves - 1) / kPoolWaves;
+  per = (per + kGatherUnroll - 1) / kGatherUnroll * kGatherUnroll;
+  *a = min(E, S + wv * per);
+  *b = min(E, *a + per);
+}
+
+// Dense row tile: [cn channels][xn voxels] in LDS, zero-filled, gathered, streamed out as cn rows of
+// xn floats.  Called by every thread of the workgroup (contains barriers).
+template <bool FULL>
+__device__ __forceinline__ void fwd_dense_row(const Layout& L, const RowTile& rt, int c0, int cn, int x0, int xn,
+                                              float* tile, int* offs, int tile_stride, const float* __restrict__ depth,
+                                              const float* __restrict__ feat, float* __restrict__ og) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  __syncthreads();  // the LDS buffers may still be in use by a previous call
+  for (int i = t; i < cn * tile_stride; i += kPoolBlock) tile[i] = 0.f;
+  if (FULL) {
+    if (t < 2) offs[t] = L.offset[rt.vrow + x0 + (t ? xn : 0)];
+  } else {
+    for (int i = t; i <= xn; i += kPoolBlock) offs[i] = L.offset[rt.vrow + x0 + i];
+  }
+  __syncthreads();
+  TRACE(2, NOW());
+  const int S = FULL ? rfl(offs[0]) : offs[0], E = FULL ? rfl(offs[1]) : offs[xn];
+  TRACE(6, E - S);
+
+  if (E != S && !ABL(8)) {  // rows without any point skip the gather entirely
+    if (FULL) {
+      float* trow = tile + lane * tile_stride;
+      const int vbase = rt.vrow + x0;
+      int a, b;
+      wave_slice(S, E, wv, &a, &b);
+      gather_owned(L, depth, feat + c0 + lane, S, E, a, b, lane, [&](int vox, float acc) { trow[vox - vbase] = acc; });
     } else {
       // lane -> (sub-slot, channel): CL lanes cover the channels, 64/CL points are in flight per wave
       const int CL = next_pow2(cn);
@@ -595,25 +673,134 @@ __global__ __launch_bounds__(kPoolBlock) void mghs_pool_fwd(Layout L, const floa
     }
     __syncthreads();
   }
-
   TRACE(3, NOW());
   if (ABL(16)) return;
-  // stream the tile out: one (channel) row of xn floats per wave iteration, 16 bytes per lane
-  float* og = out.p[rt.g];
-  const bool vec = ((rt.nx & 3) == 0) && ((xn & 3) == 0);
+
+  // stream the tile out: one (channel) row of xn floats per wave iteration, 16 bytes per lane,
+  // non-temporal so the 700 MB output stream does not evict the gather's working set from L2
+  const bool vec = ((rt.nx & 3) == 0) && ((xn & 3) == 0) && ((x0 & 3) == 0);
   for (int cc = wv; cc < cn; cc += kPoolWaves) {
     size_t row = ((((size_t)rt.b * rt.nz + rt.z) * L.C + c0 + cc) * rt.ny + rt.y) * rt.nx + x0;
     const float* src = tile + cc * tile_stride;
     if (vec) {
       vfloat4* dst = reinterpret_cast<vfloat4*>(og + row);
-      // streamed once and not re-read here: non-temporal, so the 700 MB output stream does not evict
-      // the gather's working set (features, depth, sorted lists) from L2 (measured: 235 -> 195 us)
       for (int i = lane; i < xn / 4; i += DHD_WAVE) {
         vfloat4 v = {src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]};
         __builtin_nontemporal_store(v, dst + i);
       }
     } else {
       for (int i = lane; i < xn; i += DHD_WAVE) __builtin_nontemporal_store(src[i], og + row + i);
+    }
+  }
+}
+
+// Sparse group: kGroupRows consecutive rows of one (grid, batch, slice), all 64 channels.  Per channel
+// the group is one contiguous, cache-line aligned run of kGroupRows*nx floats in the output, almost
+// all zeros.  The few non-empty voxels are summed into a compact LDS table comp[slot][channel]
+// (slot_of[position] = slot + 1), then every wave streams zero-filled 16-byte vectors for its
+// channels, patching in the table values.  Returns false (uniformly) when the group does not fit
+// the table; the caller then processes its rows through the dense tile.
+struct GroupLds {
+  float* comp;              // [kGroupSlots][kTileC]
+  unsigned short* slot_of;  // [kGroupMaxVox]
+  int* ctl;                 // [0] slots used, [1] overflow, [2] S, [3] E
+};
+
+__device__ __forceinline__ GroupLds group_lds(char* smem) {
+  GroupLds g;
+  g.comp = reinterpret_cast<float*>(smem);
+  g.slot_of = reinterpret_cast<unsigned short*>(smem + (size_t)kGroupSlots * kTileC * 4);
+  g.ctl = reinterpret_cast<int*>(smem + (size_t)kGroupSlots * kTileC * 4 + (size_t)kGroupMaxVox * 2);
+  return g;
+}
+constexpr size_t kGroupLdsBytes = (size_t)kGroupSlots * kTileC * 4 + (size_t)kGroupMaxVox * 2 + 16;
+
+__device__ __forceinline__ bool fwd_sparse_group(const Layout& L, const RowTile& rt, char* smem,
+                                                 const float* __restrict__ depth, const float* __restrict__ feat,
+                                                 float* __restrict__ og) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  GroupLds G = group_lds(smem);
+  const int nvox = kGroupRows * rt.nx;
+  __syncthreads();
+  for (int i = t; i < kGroupMaxVox / 2; i += kPoolBlock) reinterpret_cast<unsigned*>(G.slot_of)[i] = 0u;
+  if (t < 2) G.ctl[t] = 0;
+  if (t == 2) G.ctl[2] = L.offset[rt.vrow];
+  if (t == 3) G.ctl[3] = L.offset[rt.vrow + nvox];
+  __syncthreads();
+  TRACE(2, NOW());
+  const int S = rfl(G.ctl[2]), E = rfl(G.ctl[3]);
+  TRACE(6, E - S);
+  if (E - S > kGroupMaxPts) return false;
+  if (E != S && !ABL(8)) {
+    int a, b;
+    wave_slice(S, E, wv, &a, &b);
+    const int vbase = rt.vrow;
+    gather_owned(L, depth, feat + lane, S, E, a, b, lane, [&](int vox, float acc) {
+      int slot = 0;
+      if (lane == 0) slot = atomicAdd(&G.ctl[0], 1);
+      slot = rfl(slot);
+      if (slot < kGroupSlots) {
+        G.comp[slot * kTileC + lane] = acc;
+        if (lane == 0) G.slot_of[vox - vbase] = (unsigned short)(slot + 1);
+      } else if (lane == 0) {
+        G.ctl[1] = 1;
+      }
+    });
+    __syncthreads();
+    if (rfl(G.ctl[1])) return false;
+  }
+  TRACE(3, NOW());
+  if (ABL(16)) return true;
+
+  // stream out: channel cc is one run of nvox floats starting at row y0 of its plane
+  const int nvec = nvox / 4;
+  for (int cc = wv; cc < kTileC; cc += kPoolWaves) {
+    vfloat4* dst = reinterpret_cast<vfloat4*>(og + ((((size_t)rt.b * rt.nz + rt.z) * L.C + cc) * rt.ny + rt.y) * rt.nx);
+    for (int i = lane; i < nvec; i += DHD_WAVE) {
+      vfloat4 v = {0.f, 0.f, 0.f, 0.f};
+      const uint2 sl = *reinterpret_cast<const uint2*>(G.slot_of + 4 * i);
+      if (sl.x | sl.y) {
+        const unsigned s0 = sl.x & 0xffffu, s1 = sl.x >> 16, s2 = sl.y & 0xffffu, s3 = sl.y >> 16;
+        if (s0) v.x = G.comp[(s0 - 1) * kTileC + cc];
+        if (s1) v.y = G.comp[(s1 - 1) * kTileC + cc];
+        if (s2) v.z = G.comp[(s2 - 1) * kTileC + cc];
+        if (s3) v.w = G.comp[(s3 - 1) * kTileC + cc];
+      }
+      __builtin_nontemporal_store(v, dst + i);
+    }
+  }
+  return true;
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(kPoolBlock) void mghs_pool_fwd(Layout L, const float* __restrict__ depth,
+                                                            const float* __restrict__ feat, OutPtrs out, int tile_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);                                 // dense: [kTileC][tile_stride]
+  int* offs = reinterpret_cast<int*>(smem + (size_t)kTileC * tile_stride * 4);  // dense: [kMaxTileX + 1]
+
+  int row, xchunk;
+  const int kind = scheduled_work(L, blockIdx.x, &row, &xchunk);
+  if (kind == 0) return;
+  RowTile rt;
+  if (!decode_row(L, row, &rt)) return;
+  TRACE(0, rt.vrow); TRACE(1, NOW());
+  TRACE(5, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)));  // HW_REG_XCC_ID, bits 3:0
+  const int c0 = blockIdx.y * kTileC;
+  const int cn = FULL ? kTileC : min(kTileC, L.C - c0);
+  if (kind == 1) {
+    const int x0 = xchunk * kMaxTileX;
+    if (x0 < rt.nx)
+      fwd_dense_row<FULL>(L, rt, c0, cn, x0, min(kMaxTileX, rt.nx - x0), tile, offs, tile_stride, depth, feat, out.p[rt.g]);
+  } else {
+    // groups exist only when FULL, one x chunk and one channel tile (make_layout)
+    if (!fwd_sparse_group(L, rt, smem, depth, feat, out.p[rt.g])) {
+      for (int r = 0; r < kGroupRows; ++r) {
+        RowTile r1 = rt;
+        r1.y = rt.y + r;
+        r1.vrow = rt.vrow + r * rt.nx;
+        fwd_dense_row<FULL>(L, r1, c0, cn, 0, rt.nx, tile, offs, tile_stride, depth, feat, out.p[rt.g]);
+      }
     }
   }
   TRACE(4, NOW());
@@ -628,10 +815,11 @@ __global__ __launch_bounds__(kPoolBlock) void mghs_pool_bwd(Layout L, const floa
   int* offs = reinterpret_cast<int*>(smem + (size_t)kTileC * tile_stride * 4);
 
   RowTile rt;
-  if (!decode_row(L, scheduled_row(L, blockIdx.x), &rt)) return;
+  int xchunk;
+  if (!decode_row(L, scheduled_tile(L, blockIdx.x, &xchunk), &rt)) return;
   const int c0 = blockIdx.y * kTileC;
   const int cn = FULL ? kTileC : min(kTileC, L.C - c0);
-  const int x0 = blockIdx.z * kMaxTileX;
+  const int x0 = xchunk * kMaxTileX;
   if (x0 >= rt.nx) return;
   const int xn = min(kMaxTileX, rt.nx - x0);
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -773,6 +961,7 @@ int pool_smem_and_stride(const Layout& L, int* stride, size_t* smem) {
   int st = xt | 1;  // odd row stride: the transposed (lane = channel) LDS accesses hit 32 distinct banks
   *stride = st;
   *smem = (size_t)kTileC * st * 4 + (size_t)(kMaxTileX + 1) * 4;
+  if (*smem < kGroupLdsBytes) *smem = kGroupLdsBytes;
   return nx_max;
 }
 
@@ -844,7 +1033,8 @@ int dhd_mghs_forward(const dhd_mghs_desc* desc, const float* depth, const float*
   }
   int stride; size_t smem;
   int nx_max = pool_smem_and_stride(L, &stride, &smem);
-  dim3 grid(xcd_grouped_blocks(L.R, kRowGroup), dhd_cdiv(L.C, kTileC), dhd_cdiv(nx_max, kMaxTileX));
+  (void)nx_max;
+  dim3 grid(8 * L.per_xcd, dhd_cdiv(L.C, kTileC), 1);
   if (L.C % kTileC == 0)
     hipLaunchKernelGGL(mghs_pool_fwd<true>, grid, dim3(kPoolBlock), smem, dhd_stream(stream), L, depth, feat_nhwc, o, stride);
   else
@@ -870,7 +1060,8 @@ int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float
   DHD_HIP(hipMemsetAsync(feat_grad_nhwc, 0, (size_t)L.B * L.N * L.hw * L.C * 4, st));
   int stride; size_t smem;
   int nx_max = pool_smem_and_stride(L, &stride, &smem);
-  dim3 grid(xcd_grouped_blocks(L.R, kRowGroup), dhd_cdiv(L.C, kTileC), dhd_cdiv(nx_max, kMaxTileX));
+  (void)nx_max;
+  dim3 grid(xcd_grouped_blocks(L.R * L.nxc, kRowGroup * L.nxc), dhd_cdiv(L.C, kTileC), 1);
   if (L.C % kTileC == 0)
     hipLaunchKernelGGL(mghs_pool_bwd<true>, grid, dim3(kPoolBlock), smem, st, L, depth, feat_nhwc, in, feat_grad_nhwc,
                        stride);

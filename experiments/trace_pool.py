@@ -13,7 +13,7 @@ cfg = hp.cfg
 band = mghs_op.height_band(hp.height, cfg['height_range'], cfg['mask_range'])
 feat = mghs_op._nchw_to_nhwc(hp.feat)
 mghs_op.prepare(hp.plan, hp.calib, band, hp.ws)
-nblk = 13632 * B // 4 + 64
+nblk = 200000
 for mask in (0, 16, 8):
     lib.dhd_debug_set_ablation(mask)
     for _ in range(3): mghs_op.pool_forward(hp.plan, hp.depth, feat, hp.ws)
