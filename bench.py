@@ -12,7 +12,7 @@ D=44, C=64, grids 200x200x{1,4,4,8}, samples_per_gpu=4).  Samples are independen
 shard them with no data-path collective ("weak" scaling); rank 0 prints ONE JSON line.
 
 The line also carries
-  roofline     : achieved HBM GB/s of the dominant kernel (mghs_pool_fwd), algorithmic bytes
+  roofline     : achieved HBM GB/s of the dominant kernel (mghs_stream_fwd), algorithmic bytes
                   / mean launch duration from HIP events on the launch stream
   cpu_baseline : the CPU oracle (numpy MGHS + torch-CPU SFA stage) timed on this box's host cores
                  on a small sample of the same workload (rank 0, N=1 only)
@@ -78,8 +78,9 @@ class HotPath:
             self.x = torch.randn(batch, 512, 200, 200, generator=g).to(dev).requires_grad_()
             self.gy = torch.randn(batch, 256, 200, 200, generator=g).to(dev)
         self.ev = []  # (start, end) HIP events around the dominant kernel, one pair per timed step
-        # algorithmic bytes of one pooling-forward launch (fused form):
-        #   dense outputs written once + depth read once + context read once
+        # algorithmic bytes of the forward pooling per launch (fused form): dense outputs
+        # written once + depth read once + context read once.  The streaming kernel is charged with ALL
+        # of them although depth/context are read by the gather kernel before it (conservative by 1%).
         self.pool_fwd_bytes = batch * (4 * C * 17 * 200 * 200 + 4 * N * D * fh * fw + 4 * N * fh * fw * C)
 
     def step(self, record):
@@ -88,12 +89,13 @@ class HotPath:
         feat_nhwc = mghs_op._nchw_to_nhwc(self.feat)
         mghs_op.prepare(self.plan, self.calib, band, self.ws)
         if record:
+            # HIP events on the launch stream, around the streaming kernel only
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        outs = mghs_op.pool_forward(self.plan, self.depth, feat_nhwc, self.ws)
-        if record:
+            outs = mghs_op.pool_forward_phases(self.plan, self.depth, feat_nhwc, self.ws, between=e0.record)
             e1.record()
             self.ev.append((e0, e1))
+        else:
+            outs = mghs_op.pool_forward(self.plan, self.depth, feat_nhwc, self.ws)
         dg, fg = mghs_op.pool_backward(self.plan, self.depth, feat_nhwc, self.out_grads, self.ws)
         fg_nchw = mghs_op._nhwc_to_nchw(fg)
         if self.with_sfa:
@@ -174,7 +176,7 @@ def main():
                                  + ('' if a.no_sfa else ' + SFA attention stage fwd+bwd') +
                                  '; 6 cams 256x704 -> 16x44, D=44, C=64, grids 200x200x{1,4,4,8}; dense backbone/encoder convs not in the step',
                         samples_per_gpu=a.batch, global_batch=a.batch * world, parallelism=f'sample-sharded x{world}, no data-path collective'),
-            roofline=dict(bound='hbm', kernel='mghs_pool_fwd', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s',
+            roofline=dict(bound='hbm', kernel='mghs_stream_fwd', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s',
                           frac=achieved / HBM_PEAK_GBPS, traffic=None, launch_ms=kern_ms,
                           algorithmic_bytes=hp.pool_fwd_bytes))
         if world == 1 and a.cpu_samples > 0:

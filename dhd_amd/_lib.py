@@ -52,6 +52,8 @@ _PROTOTYPES = {
     'dhd_feat_nhwc_to_nchw': ([_P, _P, _I, _I, _I, _P], _I),
     'dhd_mghs_prepare': ([C.POINTER(MghsDesc), C.POINTER(Calib), _P, _P, C.c_size_t, _P], _I),
     'dhd_mghs_forward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P], _I),
+    'dhd_mghs_forward_gather': ([C.POINTER(MghsDesc), _P, _P, _P, _P], _I),
+    'dhd_mghs_forward_stream': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P], _I),
     'dhd_mghs_backward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P, _P, _P], _I),
     'dhd_mghs_voxel_index': ([C.POINTER(MghsDesc), C.POINTER(Calib), _I, _P, _P, _P], _I),
     'dhd_mghs_stats': ([C.POINTER(MghsDesc), _P, C.POINTER(C.c_int32 * DHD_MAX_GRIDS),

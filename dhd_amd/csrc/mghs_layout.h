@@ -1,0 +1,148 @@
+// Workspace layout and shared device helpers of the fused MGHS kernels (mghs_prepare.hip,
+// mghs_pool.hip).
+#pragma once
+#include "common.h"
+
+namespace dhd {
+
+constexpr int kBlock = 256;                  // geometry / scan / scatter / per-entry kernels
+constexpr int kScanItems = 8;
+constexpr int kChunk = kBlock * kScanItems;  // counters per scan block
+constexpr int kTileC = 64;                   // channels handled by one wave (lane == channel)
+constexpr int kCamFloats = 36;               // sizeof(CamMats)/4 = 33, padded
+constexpr int kSegRows = 4;                  // output rows per streaming segment (3200 contiguous bytes per channel at nx=200)
+constexpr int kSegMaxVox = 1024;             // voxels per segment (kSegRows * nx)
+constexpr int kMaxTileX = 256;               // generic dense-row path: voxels along x per tile
+constexpr int kRowGroup = 4;                 // generic dense-row path: rows handed to one XCD at a time
+
+// Host-derived description, passed to kernels by value.
+struct Layout {
+  int B, N, D, fh, fw, C, G;
+  int dhw;       // D*fh*fw points per camera
+  int hw;        // fh*fw pixels per camera
+  int P;         // B*N*dhw points
+  int V;         // total voxels over all grids
+  int R;         // total output rows (b, z, y) over all grids
+  int n_chunks;  // scan blocks
+  int vox_base[DHD_MAX_GRIDS + 1];
+  int row_base[DHD_MAX_GRIDS + 1];
+  dhd_grid grid[DHD_MAX_GRIDS];
+  // compact path (C == 64, every ny a multiple of kSegRows, nx a multiple of 4): the output is cut
+  // into `n_segs` segments of kSegRows rows; seg_base[g] = first segment of grid g
+  int compact;
+  int n_slots_max;  // capacity of vsum in rows; row n_slots_max is a scratch row
+  int n_segs;
+  int seg_base[DHD_MAX_GRIDS + 1];
+  // generic dense-row path
+  int nxc;                        // x chunks per row
+  int sched_heavy, sched_ratio;   // grid-0 row groups front-loaded 1:ratio among the others
+  // workspace carve (device pointers)
+  int* count;      // [V]     entries per voxel
+  int* offset;     // [V+1]   exclusive prefix of count            (entry index space)
+  int* nzoff;      // [V+1]   exclusive prefix of (count > 0)      (non-empty voxel ordinal, "slot")
+  int* chunk_sum;  // [2*n_chunks]
+  int* key;        // [2P]    voxel id of point p in grid 0 ([p]) and in its band grid ([P+p]); -1 = dropped
+  int* rnk;        // [2P]    arrival rank of the point inside its voxel
+  int* s_pid;      // [2P]    point id of every entry, entries grouped by voxel (index into depth)
+  int* s_pix;      // [2P]    pixel id of every entry (row of feat_nhwc)
+  int* s_slot;     // [2P]    slot (non-empty voxel ordinal) of every entry, non-decreasing
+  int* nzvox;      // [2P]    voxel id of every slot
+  int* p_slot;     // [2P]    slot of point p in grid 0 ([p]) and in its band grid ([P+p]); -1 = dropped
+  float* cam;      // [B*N*kCamFloats] per-camera matrices
+  float* dg_part;  // [2P]    backward scratch of the generic path: depth-gradient parts of grid 0 / band grid
+  float* vsum;     // [2P*kTileC] compact per-voxel rows: forward sums / backward extracted gradients
+                   //            (allocated for min(2P, V) slots, only when `compact`)
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline int make_layout(const dhd_mghs_desc* d, void* ws, Layout* L, size_t* bytes) {
+  if (!d) return DHD_EINVAL;
+  if (d->batch <= 0 || d->n_cams <= 0 || d->n_depth <= 0 || d->fh <= 0 || d->fw <= 0 || d->channels <= 0)
+    return DHD_EINVAL;
+  if (d->n_grids < 1 || d->n_grids > DHD_MAX_GRIDS) return DHD_EINVAL;
+  L->B = d->batch; L->N = d->n_cams; L->D = d->n_depth; L->fh = d->fh; L->fw = d->fw;
+  L->C = d->channels; L->G = d->n_grids;
+  L->hw = d->fh * d->fw;
+  long dhw = (long)d->n_depth * L->hw;
+  long P = (long)d->batch * d->n_cams * dhw;
+  if (P > (1L << 29)) return DHD_EUNSUPPORTED;
+  L->dhw = (int)dhw; L->P = (int)P;
+  long v = 0, r = 0;
+  bool compact = d->channels == kTileC;
+  int nx_max = 0;
+  for (int g = 0; g < DHD_MAX_GRIDS; ++g) {
+    L->vox_base[g] = (int)v; L->row_base[g] = (int)r; L->seg_base[g] = (int)(r / kSegRows);
+    if (g < d->n_grids) {
+      const dhd_grid& gr = d->grid[g];
+      if (gr.n[0] <= 0 || gr.n[1] <= 0 || gr.n[2] <= 0) return DHD_EINVAL;
+      L->grid[g] = gr;
+      v += (long)d->batch * gr.n[2] * gr.n[1] * gr.n[0];
+      r += (long)d->batch * gr.n[2] * gr.n[1];
+      if (v > (1L << 30)) return DHD_EUNSUPPORTED;
+      compact = compact && gr.n[1] % kSegRows == 0 && gr.n[0] % 4 == 0 && gr.n[0] * kSegRows <= kSegMaxVox;
+      nx_max = nx_max > gr.n[0] ? nx_max : gr.n[0];
+    } else {
+      L->grid[g] = d->grid[0];
+    }
+  }
+  L->vox_base[DHD_MAX_GRIDS] = (int)v; L->row_base[DHD_MAX_GRIDS] = (int)r;
+  for (int g = d->n_grids; g < DHD_MAX_GRIDS; ++g) { L->vox_base[g] = (int)v; L->row_base[g] = (int)r; }
+  L->V = (int)v; L->R = (int)r;
+  L->compact = compact ? 1 : 0;
+  L->n_segs = compact ? (int)(r / kSegRows) : 0;
+  for (int g = d->n_grids; g <= DHD_MAX_GRIDS; ++g) L->seg_base[g] = (int)(r / kSegRows);
+  L->n_chunks = dhd_cdiv(v, kChunk);
+  L->nxc = (nx_max + kMaxTileX - 1) / kMaxTileX;
+  L->sched_heavy = 0; L->sched_ratio = 0;
+  if (L->G > 1 && L->row_base[1] % kRowGroup == 0) {
+    int heavy = L->row_base[1] / kRowGroup, light = (L->R - L->row_base[1]) / kRowGroup;
+    int k = heavy > 0 ? light / heavy : 0;
+    // the period k+1 must be odd: row groups go round-robin over the 8 XCDs, an even period would
+    // put every heavy group on the same few XCDs (measured: XCDs {0,4} only)
+    if (k > 4) k = 4;
+    if (k == 3) k = 2;
+    if (k == 1) k = 0;
+    if (k >= 2) { L->sched_heavy = heavy; L->sched_ratio = k; }
+  }
+  size_t off = 0;
+  char* base = static_cast<char*>(ws);
+  auto carve = [&](size_t n_words) { int* p = reinterpret_cast<int*>(base + off); off = align_up(off + n_words * 4, 256); return p; };
+  const size_t P2 = 2 * (size_t)L->P;
+  L->count = carve((size_t)L->V);
+  L->offset = carve((size_t)L->V + 1);
+  L->nzoff = carve((size_t)L->V + 1);
+  L->chunk_sum = carve(2 * (size_t)L->n_chunks);
+  L->key = carve(P2);
+  L->rnk = carve(P2);
+  L->s_pid = carve(P2);
+  L->s_pix = carve(P2);
+  L->s_slot = carve(P2);
+  L->nzvox = carve(P2 < (size_t)L->V ? P2 : (size_t)L->V);
+  L->p_slot = carve(P2);
+  L->cam = reinterpret_cast<float*>(carve((size_t)L->B * L->N * kCamFloats));
+  L->dg_part = reinterpret_cast<float*>(carve(P2));
+  const size_t max_slots = P2 < (size_t)L->V ? P2 : (size_t)L->V;
+  L->n_slots_max = (int)max_slots;
+  L->vsum = reinterpret_cast<float*>(carve(compact ? (max_slots + 1) * kTileC : 0));  // +1: scratch row for discarded stores
+  if (bytes) *bytes = off;
+  return DHD_OK;
+}
+
+// ---- device helpers ------------------------------------------------------------------------
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int lane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float lane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, DHD_WAVE);
+  return v;
+}
+
+typedef float vfloat4 __attribute__((ext_vector_type(4)));  // native vector: accepted by the nontemporal builtins
+
+struct OutPtrs { float* p[DHD_MAX_GRIDS]; };
+struct InPtrs { const float* p[DHD_MAX_GRIDS]; };
+
+}  // namespace dhd

@@ -1,0 +1,658 @@
+// MGHS pooling forward / backward for gfx950 (MI355X).  Replaces 4x bev_pool_v2 + permute + cat
+// (ops/bev_pool_v2/bev_pool.py:86-106, models/necks/lss_heightmap.py:298-299) and
+// QuickCumsumCuda.backward (bev_pool.py:44-83) of the reference, for all grids in one call, on the
+// grouping produced by dhd_mghs_prepare.
+//
+// The outputs are ~176 MB of dense (B, nz*C, ny, nx) tensors per sample of which ~97% are zeros;
+// only ~50 000 voxels per sample receive any point.  Compact path (C == 64):
+//
+//   forward   1. mghs_gather_sums : one wave per 64 grouped entries, perfectly balanced; lane = channel;
+//                                   per-voxel sums -> vsum[slot][64]   (~12 MB per sample, L2/MALL resident)
+//             2. mghs_stream_fwd  : one workgroup per segment of 4 output rows (3200 contiguous,
+//                                   cache-line aligned bytes per channel): streams zero-filled 16-byte
+//                                   vectors, patching in the rows of vsum that fall into the segment
+//   backward  1. mghs_stream_bwd  : same segments; streams out_grad once and extracts the rows of the
+//                                   non-empty voxels -> vsum[slot][64]
+//             2. mghs_pixel_bwd   : one wave per feature pixel: the pixel's <=2D entries are found through
+//                                   the per-point slots; <g, feat> by DPP wave reduction -> depth_grad,
+//                                   sum g * depth -> feat_grad; one writer per element, no atomics
+//
+// Every kernel is HBM/L2-bound integer-and-fp32 streaming; no MFMA.  The streaming kernels have no
+// data-dependent loops: the latency-bound gather lives in the balanced per-entry kernels.
+// A generic dense-row path (any C, any grid shape) is kept for configurations the compact path does
+// not cover.
+#include "mghs_layout.h"
+
+namespace dhd {
+namespace {
+
+constexpr int kStreamBlock = 512;
+constexpr int kStreamWaves = kStreamBlock / DHD_WAVE;
+constexpr int kTableFloats = 8192;  // LDS patch table: up to 128 voxels x 64 channels, or 1024 x 8
+constexpr int kGatherUnroll = 16;   // gradient rows in flight per wave (backward)
+
+#ifdef DHD_ABLATION
+// Experiment-only build (make ablate): phases can be switched off to price them.  Never in libdhd_amd.so.
+__device__ int g_ablate = 0;
+#define ABL(bit) ((g_ablate & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
+
+// ---------------------------------------------------------------------------------------
+// Segments
+// ---------------------------------------------------------------------------------------
+struct Segment {
+  int g, b, z, y0, nx, ny, nz;
+  int v0;    // first voxel id
+  int nvox;  // kSegRows * nx
+};
+
+__device__ __forceinline__ bool decode_segment(const Layout& L, int s, Segment* sg) {
+  if (s >= L.n_segs) return false;
+  int g = 0;
+#pragma unroll
+  for (int k = 1; k < DHD_MAX_GRIDS; ++k)
+    if (k < L.G && s >= L.seg_base[k]) g = k;
+  const dhd_grid& gr = L.grid[g];
+  const int local = s - L.seg_base[g];
+  const int per_plane = gr.n[1] / kSegRows;
+  sg->g = g; sg->nx = gr.n[0]; sg->ny = gr.n[1]; sg->nz = gr.n[2];
+  sg->y0 = (local % per_plane) * kSegRows;
+  const int bz = local / per_plane;
+  sg->z = bz % gr.n[2];
+  sg->b = bz / gr.n[2];
+  sg->nvox = kSegRows * gr.n[0];
+  sg->v0 = L.vox_base[g] + local * sg->nvox;
+  return true;
+}
+
+// channels handled per pass so that nnz * cp <= kTableFloats (cp in {64,32,16,8})
+__device__ __forceinline__ int channels_per_pass(int nnz) {
+  int cp = kTileC;
+  while (cp > 8 && nnz * cp > kTableFloats) cp >>= 1;
+  return cp;
+}
+
+// ---------------------------------------------------------------------------------------
+// 1. forward gather: per-voxel sums.  Wave w covers entries [64w, 64w+64) and owns the voxels whose
+// FIRST entry lies there (it runs past the end of its slice to finish its last voxel), so every
+// slot has exactly one writer.  The kernel is instruction-bound (measured: SALU 680 + VALU 335
+// instructions per wave before this form), so the 64 entries of a batch are processed by fully
+// unrolled code with compile-time lane numbers: per entry one v_readlane + one v_lshl_add_u32 + one
+// global_load (SGPR base + 32-bit VGPR offset), one v_readlane + v_fmac, one s_bitcmp + branch.
+// Entries outside the owned range are neutralised without per-entry range checks: garbage
+// accumulated before the first owned voxel goes to a scratch row, and a terminator bit makes the
+// run end on the scratch row as well, so nothing outside the owned voxels reaches a real slot.
+// ---------------------------------------------------------------------------------------
+template <int J>
+struct GatherStep {
+  static __device__ __forceinline__ void load(float (&f)[DHD_WAVE], __amdgpu_buffer_rsrc_t feat_rsrc, int lane4, int pix,
+                                              int jmax) {
+    if ((J & 7) == 0 && J > jmax) return;  // wave-uniform early exit, checked every 8 positions
+    // buffer load: per-lane byte offset in a VGPR (constant), row offset (pixel * 256 B) in an SGPR:
+    // one v_readlane + one s_lshl + one buffer_load per entry, no vector address arithmetic
+    f[J] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(feat_rsrc, lane4, lane_i(pix, J) << 8, 0));
+    GatherStep<J + 1>::load(f, feat_rsrc, lane4, pix, jmax);
+  }
+  static __device__ __forceinline__ void run(const float (&f)[DHD_WAVE], unsigned long long firsts, int term, int slot,
+                                             float dv, float* vrow, int scratch_row, int jmax, int& cur, float& acc) {
+    if ((J & 7) == 0 && J > jmax) return;
+    if ((firsts >> J) & 1ull) {
+      vrow[(size_t)cur * kTileC] = acc;  // cur == scratch_row while nothing is owned
+      cur = rfl((J == term) ? scratch_row : lane_i(slot, J));
+      acc = 0.f;
+    }
+    acc = fmaf(lane_f(dv, J), f[J], acc);
+    GatherStep<J + 1>::run(f, firsts, term, slot, dv, vrow, scratch_row, jmax, cur, acc);
+  }
+};
+template <>
+struct GatherStep<DHD_WAVE> {
+  static __device__ __forceinline__ void load(float (&)[DHD_WAVE], __amdgpu_buffer_rsrc_t, int, int, int) {}
+  static __device__ __forceinline__ void run(const float (&)[DHD_WAVE], unsigned long long, int, int, float, float*, int, int,
+                                             int&, float&) {}
+};
+
+__global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float* __restrict__ depth,
+                                                            const float* __restrict__ feat) {
+  const int lane = threadIdx.x & 63;
+  const int T = L.offset[L.V];  // total entries (device-side value, scalar load)
+  // everything that steers control flow is forced into SGPRs: the compiler cannot see that
+  // threadIdx.x >> 6 is wave-uniform and would otherwise predicate every branch through EXEC
+  const int a = rfl((blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6)) * DHD_WAVE);
+  if (a >= T) return;
+  const int b = min(T, a + DHD_WAVE);
+  const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(feat), 0, L.B * L.N * L.hw * kTileC * 4, 0x00020000);
+  const int lane4 = 4 * lane;
+  const int scratch_row = L.n_slots_max;
+  float* vrow = L.vsum + lane;
+  bool started = false;
+  int cur = rfl(scratch_row);
+  float acc = 0.f;
+  int idx = a + lane;
+  int slot_n = -1, prev_n = -2, pix_n = 0, pid_n = 0;
+  float dv_n = 0.f;
+  if (idx < T) {
+    slot_n = L.s_slot[idx];
+    pix_n = L.s_pix[idx];
+    pid_n = L.s_pid[idx];
+    if (idx > 0) prev_n = L.s_slot[idx - 1];
+  }
+  if (idx < T) dv_n = depth[pid_n];
+  for (int a0 = a; a0 < T; a0 += DHD_WAVE) {
+    const int nb = min(DHD_WAVE, T - a0);
+    const int slot = slot_n, pix = pix_n;   // lanes >= nb hold slot -1, pixel 0, depth 0
+    const float dv = dv_n;
+    unsigned long long firsts = __ballot(lane < nb && slot != prev_n);
+    int lo = 0;
+    if (!started) {
+      if (firsts == 0ull) lo = nb;                  // still inside a voxel owned by an earlier wave
+      else lo = __builtin_ctzll(firsts);
+      if (a0 + lo >= b) break;                      // the first voxel starting here belongs to the next wave
+      started = lo < nb;
+    }
+    // terminator: the first voxel boundary at or after b (that voxel belongs to the next wave), or
+    // the end of the entry list; 64 = none in this batch
+    int term = DHD_WAVE;
+    {
+      const int s = min(max(b - a0, lo + 1), DHD_WAVE);
+      const unsigned long long m = s >= DHD_WAVE ? 0ull : (firsts >> s) << s;
+      if (m != 0ull) term = __builtin_ctzll(m);
+      else if (nb < DHD_WAVE) term = nb;
+    }
+    const bool last = term < DHD_WAVE;
+    if (last) firsts = (firsts & ((1ull << term) - 1ull)) | (1ull << term);  // nothing is flushed after the terminator
+    if (lo >= nb) firsts = 0ull;
+    idx = a0 + DHD_WAVE + lane;
+    slot_n = -1; pix_n = 0; pid_n = 0;
+    if (!last && idx < T) {  // next batch: its index words travel while this batch is processed
+      slot_n = L.s_slot[idx];
+      pix_n = L.s_pix[idx];
+      pid_n = L.s_pid[idx];
+      prev_n = L.s_slot[idx - 1];
+    }
+    if (lo < nb) {
+      const int jmax = last ? term : DHD_WAVE - 1;
+      float f[DHD_WAVE];
+      GatherStep<0>::load(f, feat_rsrc, lane4, pix, jmax);
+      GatherStep<0>::run(f, firsts, term, slot, dv, vrow, scratch_row, jmax, cur, acc);
+    }
+    if (last) { cur = rfl(scratch_row); break; }
+    dv_n = 0.f;
+    if (idx < T) dv_n = depth[pid_n];
+  }
+  vrow[(size_t)cur * kTileC] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// 2. forward stream.  LDS: table[kTableFloats] + slot_of[kSegMaxVox] (uint16: 1 + index of the
+// voxel's row in this segment's slot range, 0 = empty) + 2 ints.
+// ---------------------------------------------------------------------------------------
+constexpr size_t kStreamLds = (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2 + 16;
+
+__global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtrs out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* table = reinterpret_cast<float*>(smem);
+  unsigned short* slot_of = reinterpret_cast<unsigned short*>(smem + (size_t)kTableFloats * 4);
+  int* ctl = reinterpret_cast<int*>(smem + (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2);
+
+  Segment sg;
+  if (!decode_segment(L, blockIdx.x, &sg)) return;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) ctl[0] = L.nzoff[sg.v0];
+  if (t == 1) ctl[1] = L.nzoff[sg.v0 + sg.nvox];
+  for (int i = t; i < kSegMaxVox / 2; i += kStreamBlock) reinterpret_cast<unsigned*>(slot_of)[i] = 0u;
+  __syncthreads();
+  const int k0 = rfl(ctl[0]), nnz = rfl(ctl[1]) - k0;
+  for (int j = t; j < nnz; j += kStreamBlock) slot_of[L.nzvox[k0 + j] - sg.v0] = (unsigned short)(j + 1);
+  const int cp = channels_per_pass(nnz);
+  const int nvec = sg.nvox / 4;
+  float* og = out.p[sg.g];
+  for (int c_lo = 0; c_lo < kTileC; c_lo += cp) {
+    __syncthreads();  // slot_of complete / previous pass done with the table
+    if (!ABL(8)) {
+      // table[j*cp + cc] = vsum[(k0+j)*64 + c_lo + cc]: runs of cp floats, coalesced
+      for (int i = t; i < nnz * cp; i += kStreamBlock) {
+        const int j = i / cp, cc = i % cp;
+        table[i] = L.vsum[(size_t)(k0 + j) * kTileC + c_lo + cc];
+      }
+    }
+    __syncthreads();
+    if (ABL(16)) continue;
+    for (int cc = wv; cc < cp; cc += kStreamWaves) {
+      // channel c_lo+cc of this segment: nvox contiguous floats starting at row y0 of its plane
+      vfloat4* dst = reinterpret_cast<vfloat4*>(
+          og + ((((size_t)sg.b * sg.nz + sg.z) * kTileC + c_lo + cc) * sg.ny + sg.y0) * sg.nx);
+      for (int i = lane; i < nvec; i += DHD_WAVE) {
+        vfloat4 v = {0.f, 0.f, 0.f, 0.f};
+        const uint2 sl = *reinterpret_cast<const uint2*>(slot_of + 4 * i);
+        if (sl.x | sl.y) {
+          const unsigned s0 = sl.x & 0xffffu, s1 = sl.x >> 16, s2 = sl.y & 0xffffu, s3 = sl.y >> 16;
+          if (s0) v.x = table[(s0 - 1) * cp + cc];
+          if (s1) v.y = table[(s1 - 1) * cp + cc];
+          if (s2) v.z = table[(s2 - 1) * cp + cc];
+          if (s3) v.w = table[(s3 - 1) * cp + cc];
+        }
+        // streamed once, not re-read here: non-temporal, so the output stream does not evict vsum from L2
+        __builtin_nontemporal_store(v, dst + i);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward 1: stream out_grad, extract the rows of the non-empty voxels into vsum[slot][64].
+// Segments without any point are skipped: their out_grad is never needed.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs og_in) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* table = reinterpret_cast<float*>(smem);
+  unsigned short* slot_of = reinterpret_cast<unsigned short*>(smem + (size_t)kTableFloats * 4);
+  int* ctl = reinterpret_cast<int*>(smem + (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2);
+
+  Segment sg;
+  if (!decode_segment(L, blockIdx.x, &sg)) return;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) ctl[0] = L.nzoff[sg.v0];
+  if (t == 1) ctl[1] = L.nzoff[sg.v0 + sg.nvox];
+  for (int i = t; i < kSegMaxVox / 2; i += kStreamBlock) reinterpret_cast<unsigned*>(slot_of)[i] = 0u;
+  __syncthreads();
+  const int k0 = rfl(ctl[0]), nnz = rfl(ctl[1]) - k0;
+  if (nnz == 0) return;
+  for (int j = t; j < nnz; j += kStreamBlock) slot_of[L.nzvox[k0 + j] - sg.v0] = (unsigned short)(j + 1);
+  const int cp = channels_per_pass(nnz);
+  const int nvec = sg.nvox / 4;
+  const float* og = og_in.p[sg.g];
+  for (int c_lo = 0; c_lo < kTileC; c_lo += cp) {
+    __syncthreads();
+    for (int cc = wv; cc < cp; cc += kStreamWaves) {
+      const vfloat4* src = reinterpret_cast<const vfloat4*>(
+          og + ((((size_t)sg.b * sg.nz + sg.z) * kTileC + c_lo + cc) * sg.ny + sg.y0) * sg.nx);
+      for (int i = lane; i < nvec; i += DHD_WAVE) {
+        const uint2 sl = *reinterpret_cast<const uint2*>(slot_of + 4 * i);
+        const vfloat4 v = __builtin_nontemporal_load(src + i);
+        if (sl.x | sl.y) {
+          const unsigned s0 = sl.x & 0xffffu, s1 = sl.x >> 16, s2 = sl.y & 0xffffu, s3 = sl.y >> 16;
+          if (s0) table[(s0 - 1) * cp + cc] = v.x;
+          if (s1) table[(s1 - 1) * cp + cc] = v.y;
+          if (s2) table[(s2 - 1) * cp + cc] = v.z;
+          if (s3) table[(s3 - 1) * cp + cc] = v.w;
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = t; i < nnz * cp; i += kStreamBlock) {
+      const int j = i / cp, cc = i % cp;
+      L.vsum[(size_t)(k0 + j) * kTileC + c_lo + cc] = table[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward 2: one wave per feature pixel (b, n, h, w); lane = channel.  The pixel's D frustum points
+// are entries of at most two voxels each (grid 0 and the pixel's band grid); their slots were
+// recorded per point by prepare (p_slot).  With g = extracted out_grad row of a voxel:
+//   depth_grad[p]     = <g_full(p), feat[q,:]> + <g_band(p), feat[q,:]>     (DPP wave reduction)
+//   feat_grad[q,:]    = sum over the pixel's entries of g * depth[p]         (register accumulation)
+// Every output element has exactly one writer: no atomics, no memset, deterministic.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void mghs_pixel_bwd(Layout L, const float* __restrict__ depth,
+                                                          const float* __restrict__ feat, float* __restrict__ depth_grad,
+                                                          float* __restrict__ feat_grad) {
+  const int lane = threadIdx.x & 63;
+  const int q = rfl(blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6));  // pixel id = row of feat_nhwc (forced scalar)
+  if (q >= L.B * L.N * L.hw) return;
+  const int bn = q / L.hw, pl = q % L.hw;
+  const int p0 = bn * L.dhw + pl;  // point id of depth bin 0; bin d is p0 + d*hw
+  const float f = feat[(size_t)q * kTileC + lane];
+  const float* gc = L.vsum + lane;
+  float fg = 0.f;
+  // 2*D (depth bin, grid class) candidates, 64 at a time: lane e handles bin e/2, class e&1
+  const int n_cand = 2 * L.D;
+  for (int e0 = 0; e0 < n_cand; e0 += DHD_WAVE) {
+    const int nb = min(DHD_WAVE, n_cand - e0);
+    int slot = -1;
+    float dv = 0.f;
+    if (lane < nb) {
+      const int e = e0 + lane;
+      const int pid = p0 + (e >> 1) * L.hw;
+      slot = L.p_slot[(e & 1) * L.P + pid];
+      dv = depth[pid];
+    }
+    float mine = 0.f;  // <g, f> of the candidate this lane loaded
+    const unsigned long long live = __ballot(slot >= 0);
+    for (int i0 = 0; i0 < nb; i0 += kGatherUnroll) {
+      float g[kGatherUnroll];
+#pragma unroll
+      for (int j = 0; j < kGatherUnroll; ++j) {
+        const int i = i0 + j;
+        g[j] = ((live >> i) & 1ull) ? gc[(size_t)lane_i(slot, i) * kTileC] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < kGatherUnroll; ++j) {
+        const int i = i0 + j;
+        if ((live >> i) & 1ull) {
+          fg = fmaf(g[j], lane_f(dv, i), fg);
+          const float tot = wave_sum_bcast(g[j] * f);
+          if (lane == i) mine = tot;
+        }
+      }
+    }
+    // the two classes of a point sit in adjacent lanes: add them and let the even lane write
+    const float other = __shfl_xor(mine, 1, DHD_WAVE);
+    if (lane < nb && !(lane & 1)) depth_grad[p0 + ((e0 + lane) >> 1) * L.hw] = mine + other;
+  }
+  feat_grad[(size_t)q * kTileC + lane] = fg;
+}
+
+// depth_grad = part(grid 0) + part(band grid)
+__global__ __launch_bounds__(kBlock) void mghs_sum_parts(const float* __restrict__ part, int P, float* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < P) out[i] = part[i] + part[P + i];
+}
+
+// =======================================================================================
+// Generic dense-row path (any channel count, any grid shape).  One workgroup per output row tile:
+// [<=64 channels][<=256 voxels] in LDS, gathered voxel by voxel (CL lanes cover the channels, 64/CL
+// points in flight per wave), streamed to/from HBM as whole rows.
+// =======================================================================================
+constexpr int kRowBlock = 512;
+constexpr int kRowWaves = kRowBlock / DHD_WAVE;
+
+struct RowTile {
+  int g, b, z, y, nx, ny, nz;
+  int vrow;  // voxel id of (b,z,y,x=0)
+};
+
+__device__ __forceinline__ bool decode_row(const Layout& L, int r, RowTile* t) {
+  if (r >= L.R) return false;
+  int g = 0;
+#pragma unroll
+  for (int k = 1; k < DHD_MAX_GRIDS; ++k)
+    if (k < L.G && r >= L.row_base[k]) g = k;
+  const dhd_grid& gr = L.grid[g];
+  int local = r - L.row_base[g];
+  t->g = g; t->nx = gr.n[0]; t->ny = gr.n[1]; t->nz = gr.n[2];
+  t->y = local % gr.n[1];
+  int bz = local / gr.n[1];
+  t->z = bz % gr.n[2];
+  t->b = bz / gr.n[2];
+  t->vrow = L.vox_base[g] + local * gr.n[0];
+  return true;
+}
+
+// blockIdx -> (output row, x chunk): XCD-grouped (block b runs on XCD b % 8; all chunks of kRowGroup
+// rows stay on one XCD, back to back), heavy (grid 0) row groups front-loaded 1:k with an odd period.
+__device__ __forceinline__ int scheduled_tile(const Layout& L, int block, int* xchunk) {
+  const int pos = xcd_grouped_tile(block, kRowGroup * L.nxc);
+  *xchunk = pos % L.nxc;
+  const int rpos = pos / L.nxc;
+  int grp = rpos / kRowGroup;
+  const int within = rpos % kRowGroup;
+  if (L.sched_heavy > 0) {
+    const int k1 = L.sched_ratio + 1;
+    if (grp < L.sched_heavy * k1) {
+      const int q = grp / k1, r = grp % k1;
+      grp = (r == 0) ? q : L.sched_heavy + q * L.sched_ratio + (r - 1);
+    }
+  }
+  return grp * kRowGroup + within;
+}
+
+__global__ __launch_bounds__(kRowBlock) void mghs_rows_fwd(Layout L, const float* __restrict__ depth,
+                                                           const float* __restrict__ feat, OutPtrs out, int tile_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);                                 // [kTileC][tile_stride]
+  int* offs = reinterpret_cast<int*>(smem + (size_t)kTileC * tile_stride * 4);  // [kMaxTileX + 1]
+  RowTile rt;
+  int xchunk;
+  if (!decode_row(L, scheduled_tile(L, blockIdx.x, &xchunk), &rt)) return;
+  const int c0 = blockIdx.y * kTileC;
+  const int cn = min(kTileC, L.C - c0);
+  const int x0 = xchunk * kMaxTileX;
+  if (x0 >= rt.nx) return;
+  const int xn = min(kMaxTileX, rt.nx - x0);
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+
+  for (int i = t; i <= xn; i += kRowBlock) offs[i] = L.offset[rt.vrow + x0 + i];
+  for (int i = t; i < cn * tile_stride; i += kRowBlock) tile[i] = 0.f;
+  __syncthreads();
+
+  if (offs[xn] != offs[0]) {
+    const int CL = next_pow2(cn);
+    const int nsub = DHD_WAVE / CL;
+    const int c = lane % CL, sub = lane / CL;
+    const bool c_ok = c < cn;
+    const float* featc = feat + c0 + c;
+    for (int x = wv; x < xn; x += kRowWaves) {
+      const int s = offs[x], e = offs[x + 1];
+      if (e == s) continue;
+      float acc = 0.f;
+      for (int s0 = s; s0 < e; s0 += DHD_WAVE) {
+        const int nb = min(DHD_WAVE, e - s0);
+        int pix = 0;
+        float dv = 0.f;
+        if (lane < nb) {
+          pix = L.s_pix[s0 + lane];
+          dv = depth[L.s_pid[s0 + lane]];
+        }
+        // uniform trip count: the cross-lane reads below must be executed by every lane
+        const int steps = (nb + nsub - 1) / nsub;
+        for (int k = 0; k < steps; ++k) {
+          const int i = k * nsub + sub;
+          const bool live = i < nb;
+          int q = __shfl(pix, live ? i : 0, DHD_WAVE);
+          float d = __shfl(dv, live ? i : 0, DHD_WAVE);
+          float f = (live && c_ok) ? featc[(size_t)q * L.C] : 0.f;
+          acc = fmaf(d, f, acc);
+        }
+      }
+      for (int m = CL; m < DHD_WAVE; m <<= 1) acc += __shfl_xor(acc, m, DHD_WAVE);
+      if (sub == 0 && c_ok) tile[c * tile_stride + x] = acc;
+    }
+    __syncthreads();
+  }
+
+  float* og = out.p[rt.g];
+  const bool vec = ((rt.nx & 3) == 0) && ((xn & 3) == 0) && ((x0 & 3) == 0);
+  for (int cc = wv; cc < cn; cc += kRowWaves) {
+    size_t row = ((((size_t)rt.b * rt.nz + rt.z) * L.C + c0 + cc) * rt.ny + rt.y) * rt.nx + x0;
+    const float* src = tile + cc * tile_stride;
+    if (vec) {
+      vfloat4* dst = reinterpret_cast<vfloat4*>(og + row);
+      for (int i = lane; i < xn / 4; i += DHD_WAVE) {
+        vfloat4 v = {src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]};
+        __builtin_nontemporal_store(v, dst + i);
+      }
+    } else {
+      for (int i = lane; i < xn; i += DHD_WAVE) __builtin_nontemporal_store(src[i], og + row + i);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kRowBlock) void mghs_rows_bwd(Layout L, const float* __restrict__ depth,
+                                                           const float* __restrict__ feat, InPtrs og,
+                                                           float* __restrict__ feat_grad, int tile_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);
+  int* offs = reinterpret_cast<int*>(smem + (size_t)kTileC * tile_stride * 4);
+  RowTile rt;
+  int xchunk;
+  if (!decode_row(L, scheduled_tile(L, blockIdx.x, &xchunk), &rt)) return;
+  const int c0 = blockIdx.y * kTileC;
+  const int cn = min(kTileC, L.C - c0);
+  const int x0 = xchunk * kMaxTileX;
+  if (x0 >= rt.nx) return;
+  const int xn = min(kMaxTileX, rt.nx - x0);
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+
+  for (int i = t; i <= xn; i += kRowBlock) offs[i] = L.offset[rt.vrow + x0 + i];
+  __syncthreads();
+  if (offs[xn] == offs[0]) return;  // no point lands in this row: its out_grad is never read
+
+  const float* gsrc = og.p[rt.g];
+  const bool vec = ((rt.nx & 3) == 0) && ((xn & 3) == 0) && ((x0 & 3) == 0);
+  for (int cc = wv; cc < cn; cc += kRowWaves) {
+    size_t row = ((((size_t)rt.b * rt.nz + rt.z) * L.C + c0 + cc) * rt.ny + rt.y) * rt.nx + x0;
+    float* dst = tile + cc * tile_stride;
+    if (vec) {
+      const float4* src = reinterpret_cast<const float4*>(gsrc + row);
+      for (int i = lane; i < xn / 4; i += DHD_WAVE) {
+        float4 v = src[i];
+        dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+      }
+    } else {
+      for (int i = lane; i < xn; i += DHD_WAVE) dst[i] = gsrc[row + i];
+    }
+  }
+  __syncthreads();
+
+  // depth-gradient parts: with one channel tile every (point, grid class) has one writer (plain
+  // store); with several channel tiles (C > 64) the tiles' partial dot products need atomics
+  float* dgp = L.dg_part + (rt.g == 0 ? 0 : L.P);
+  const bool dg_atomic = L.C > kTileC;
+  const int CL = next_pow2(cn);
+  const int nsub = DHD_WAVE / CL;
+  const int c = lane % CL, sub = lane / CL;
+  const bool c_ok = c < cn;
+  const float* featc = feat + c0 + c;
+  float* fgc = feat_grad + c0 + c;
+  for (int x = wv; x < xn; x += kRowWaves) {
+    const int s = offs[x], e = offs[x + 1];
+    if (e == s) continue;
+    const float g = c_ok ? tile[c * tile_stride + x] : 0.f;
+    for (int s0 = s; s0 < e; s0 += DHD_WAVE) {
+      const int nb = min(DHD_WAVE, e - s0);
+      int pix = 0, pid = 0;
+      float dv = 0.f;
+      if (lane < nb) {
+        pix = L.s_pix[s0 + lane];
+        pid = L.s_pid[s0 + lane];
+        dv = depth[pid];
+      }
+      float mine = 0.f;  // depth-gradient contribution of the point this lane loaded
+      const int steps = (nb + nsub - 1) / nsub;
+      for (int k = 0; k < steps; ++k) {
+        const int i = k * nsub + sub;
+        const bool live = i < nb;
+        int q = __shfl(pix, live ? i : 0, DHD_WAVE);
+        float d = __shfl(dv, live ? i : 0, DHD_WAVE);
+        float prod = 0.f;
+        if (live && c_ok) {
+          float f = featc[(size_t)q * L.C];
+          unsafeAtomicAdd(fgc + (size_t)q * L.C, g * d);
+          prod = g * f;
+        }
+        float tot = group_sum(prod, CL);
+        // hand the sum of point (k*nsub + j) to lane (k*nsub + j): it sits in every lane of sub-slot j
+        int owner_sub = lane - k * nsub;
+        float got = __shfl(tot, (owner_sub >= 0 && owner_sub < nsub) ? owner_sub * CL : 0, DHD_WAVE);
+        if (owner_sub >= 0 && owner_sub < nsub) mine = got;
+      }
+      if (lane < nb) {
+        if (dg_atomic) unsafeAtomicAdd(dgp + pid, mine); else dgp[pid] = mine;
+      }
+    }
+  }
+}
+
+void rows_launch_shape(const Layout& L, int* stride, size_t* smem, dim3* grid) {
+  int nx_max = 0;
+  for (int g = 0; g < L.G; ++g) nx_max = nx_max > L.grid[g].n[0] ? nx_max : L.grid[g].n[0];
+  int xt = nx_max < kMaxTileX ? nx_max : kMaxTileX;
+  *stride = xt | 1;  // odd row stride: the transposed (lane = channel) LDS accesses hit 32 distinct banks
+  *smem = (size_t)kTileC * (*stride) * 4 + (size_t)(kMaxTileX + 1) * 4;
+  *grid = dim3(xcd_grouped_blocks(L.R * L.nxc, kRowGroup * L.nxc), dhd_cdiv(L.C, kTileC), 1);
+}
+
+}  // namespace
+}  // namespace dhd
+
+using namespace dhd;
+
+extern "C" {
+
+#ifdef DHD_ABLATION
+int dhd_debug_set_ablation(int mask) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &mask, sizeof(int)); }
+#endif
+
+int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc, void* workspace,
+                            void* stream) {
+  Layout L;
+  int rc = make_layout(desc, workspace, &L, nullptr);
+  if (rc) return rc;
+  if (!workspace || !depth || !feat_nhwc) return DHD_EINVAL;
+  if (!L.compact) return DHD_OK;  // the generic path gathers inside its row kernel
+  // 2P is an upper bound of the entry count; waves past the real count exit at once
+  hipLaunchKernelGGL(mghs_gather_sums, dim3(dhd_cdiv(2L * L.P, kBlock)), dim3(kBlock), 0, dhd_stream(stream), L, depth,
+                     feat_nhwc);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+int dhd_mghs_forward_stream(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                            float* const out[DHD_MAX_GRIDS], void* workspace, void* stream) {
+  Layout L;
+  int rc = make_layout(desc, workspace, &L, nullptr);
+  if (rc) return rc;
+  if (!workspace || !depth || !feat_nhwc || !out) return DHD_EINVAL;
+  OutPtrs o;
+  for (int g = 0; g < DHD_MAX_GRIDS; ++g) {
+    o.p[g] = g < L.G ? out[g] : nullptr;
+    if (g < L.G && !out[g]) return DHD_EINVAL;
+  }
+  hipStream_t st = dhd_stream(stream);
+  if (L.compact) {
+    hipLaunchKernelGGL(mghs_stream_fwd, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, o);
+    DHD_LAUNCH_CHECK();
+  } else {
+    int stride; size_t smem; dim3 grid;
+    rows_launch_shape(L, &stride, &smem, &grid);
+    hipLaunchKernelGGL(mghs_rows_fwd, grid, dim3(kRowBlock), smem, st, L, depth, feat_nhwc, o, stride);
+    DHD_LAUNCH_CHECK();
+  }
+  return DHD_OK;
+}
+
+int dhd_mghs_forward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                     float* const out[DHD_MAX_GRIDS], void* workspace, void* stream) {
+  int rc = dhd_mghs_forward_gather(desc, depth, feat_nhwc, workspace, stream);
+  if (rc) return rc;
+  return dhd_mghs_forward_stream(desc, depth, feat_nhwc, out, workspace, stream);
+}
+
+int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                      const float* const out_grad[DHD_MAX_GRIDS], float* depth_grad, float* feat_grad_nhwc,
+                      void* workspace, void* stream) {
+  Layout L;
+  int rc = make_layout(desc, workspace, &L, nullptr);
+  if (rc) return rc;
+  if (!workspace || !depth || !feat_nhwc || !out_grad || !depth_grad || !feat_grad_nhwc) return DHD_EINVAL;
+  InPtrs in;
+  for (int g = 0; g < DHD_MAX_GRIDS; ++g) {
+    in.p[g] = g < L.G ? out_grad[g] : nullptr;
+    if (g < L.G && !out_grad[g]) return DHD_EINVAL;
+  }
+  hipStream_t st = dhd_stream(stream);
+  if (L.compact) {
+    hipLaunchKernelGGL(mghs_stream_bwd, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, in);
+    DHD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mghs_pixel_bwd, dim3(dhd_cdiv((long)L.B * L.N * L.hw, kBlock / DHD_WAVE)), dim3(kBlock), 0, st, L,
+                       depth, feat_nhwc, depth_grad, feat_grad_nhwc);
+    DHD_LAUNCH_CHECK();
+    return DHD_OK;
+  }
+  DHD_HIP(hipMemsetAsync(L.dg_part, 0, 2 * (size_t)L.P * 4, st));
+  DHD_HIP(hipMemsetAsync(feat_grad_nhwc, 0, (size_t)L.B * L.N * L.hw * L.C * 4, st));
+  int stride; size_t smem; dim3 grid;
+  rows_launch_shape(L, &stride, &smem, &grid);
+  hipLaunchKernelGGL(mghs_rows_bwd, grid, dim3(kRowBlock), smem, st, L, depth, feat_nhwc, in, feat_grad_nhwc, stride);
+  DHD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mghs_sum_parts, dim3(dhd_cdiv(L.P, kBlock)), dim3(kBlock), 0, st, L.dg_part, L.P, depth_grad);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,376 @@
+// MGHS index preparation for gfx950 (MI355X): geometry -> voxel index -> device counting sort.
+// Replaces 4x MGHS.get_ego_coor (models/necks/lss_heightmap.py:179-231) and 4x
+// voxel_pooling_prepare_v2 (:303-371) of the reference with one geometry pass and one grouping
+// shared by all grids.
+//
+// Output (in the workspace, see mghs_layout.h): the kept (point, grid) pairs ("entries") grouped
+// by voxel, each with its point id, pixel id and slot (ordinal of its voxel among the non-empty
+// voxels); per voxel the entry prefix `offset` and the slot prefix `nzoff`; per slot its voxel id.
+//
+// File:line citations are into /root/reference/projects/mmdet3d_plugin/.
+#include "mghs_layout.h"
+
+namespace dhd {
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// Geometry.  The operation order, the absence of FMA contraction and the IEEE division are
+// part of the contract: voxel indices must be bit-identical to the reference's float32 chain
+// (lss_heightmap.py:206-230 and :331-333).  torch's CPU bmm accumulates acc = 0; acc += a*b
+// with separately rounded products and sums; the explicit _rn intrinsics below are never
+// contracted by the compiler.
+// ---------------------------------------------------------------------------------------
+
+struct CamMats {
+  float ipr[9];    // inverse(post_rot)
+  float comb[9];   // sensor2ego[:3,:3] @ inverse(intrin)
+  float trans[3];  // sensor2ego[:3,3]
+  float ptran[3];  // post_tran
+  float bda[9];
+};
+
+__device__ __forceinline__ float dot3_seq(const float* m, float x, float y, float z) {
+  float acc = __fadd_rn(0.0f, __fmul_rn(m[0], x));
+  acc = __fadd_rn(acc, __fmul_rn(m[1], y));
+  acc = __fadd_rn(acc, __fmul_rn(m[2], z));
+  return acc;
+}
+
+// LU with partial pivoting + substitution on the permuted identity, one thread, float32,
+// every operation rounded separately (LAPACK sgetf2 + strsm with IEEE division; this is what
+// torch.inverse reaches, lss_heightmap.py:209,220).
+__device__ void inv3x3_lu(const float* src, float* dst) {
+  float a[3][3];
+  int perm[3] = {0, 1, 2};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) a[i][j] = src[i * 3 + j];
+  for (int j = 0; j < 3; ++j) {
+    int p = j;
+    for (int i = j + 1; i < 3; ++i)
+      if (fabsf(a[i][j]) > fabsf(a[p][j])) p = i;
+    if (p != j) {
+      for (int k = 0; k < 3; ++k) { float t = a[j][k]; a[j][k] = a[p][k]; a[p][k] = t; }
+      int t = perm[j]; perm[j] = perm[p]; perm[p] = t;
+    }
+    for (int i = j + 1; i < 3; ++i) {
+      a[i][j] = __fdiv_rn(a[i][j], a[j][j]);
+      for (int k = j + 1; k < 3; ++k) a[i][k] = __fsub_rn(a[i][k], __fmul_rn(a[i][j], a[j][k]));
+    }
+  }
+  for (int c = 0; c < 3; ++c) {
+    float b[3];
+    for (int i = 0; i < 3; ++i) b[i] = (perm[i] == c) ? 1.0f : 0.0f;
+    for (int i = 0; i < 3; ++i)
+      for (int k = 0; k < i; ++k) b[i] = __fsub_rn(b[i], __fmul_rn(a[i][k], b[k]));
+    for (int i = 2; i >= 0; --i) {
+      for (int k = i + 1; k < 3; ++k) b[i] = __fsub_rn(b[i], __fmul_rn(a[i][k], b[k]));
+      b[i] = __fdiv_rn(b[i], a[i][i]);
+    }
+    for (int i = 0; i < 3; ++i) dst[i * 3 + c] = b[i];
+  }
+}
+
+__device__ void load_camera(const dhd_calib& cal, int bn, int b, CamMats* m) {
+  const float* s2e = cal.sensor2ego + (size_t)bn * 16;
+  if (cal.inv_post_rot) {
+    for (int i = 0; i < 9; ++i) m->ipr[i] = cal.inv_post_rot[(size_t)bn * 9 + i];
+  } else {
+    inv3x3_lu(cal.post_rot + (size_t)bn * 9, m->ipr);
+  }
+  if (cal.combine) {
+    for (int i = 0; i < 9; ++i) m->comb[i] = cal.combine[(size_t)bn * 9 + i];
+  } else {
+    float ik[9];
+    inv3x3_lu(cal.intrin + (size_t)bn * 9, ik);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        float acc = __fadd_rn(0.0f, __fmul_rn(s2e[i * 4 + 0], ik[0 * 3 + j]));
+        acc = __fadd_rn(acc, __fmul_rn(s2e[i * 4 + 1], ik[1 * 3 + j]));
+        acc = __fadd_rn(acc, __fmul_rn(s2e[i * 4 + 2], ik[2 * 3 + j]));
+        m->comb[i * 3 + j] = acc;
+      }
+  }
+  for (int i = 0; i < 3; ++i) {
+    m->trans[i] = s2e[i * 4 + 3];
+    m->ptran[i] = cal.post_tran[(size_t)bn * 3 + i];
+  }
+  for (int i = 0; i < 9; ++i) m->bda[i] = cal.bda[(size_t)b * 9 + i];
+}
+
+// MGHS.get_ego_coor for one frustum point (u, v, d).
+__device__ __forceinline__ void frustum_to_ego(const CamMats& m, float u, float v, float d, float* e) {
+  float px = __fsub_rn(u, m.ptran[0]);
+  float py = __fsub_rn(v, m.ptran[1]);
+  float pz = __fsub_rn(d, m.ptran[2]);
+  float qx = dot3_seq(m.ipr + 0, px, py, pz);
+  float qy = dot3_seq(m.ipr + 3, px, py, pz);
+  float qz = dot3_seq(m.ipr + 6, px, py, pz);
+  float rx = __fmul_rn(qx, qz);
+  float ry = __fmul_rn(qy, qz);
+  float cx = __fadd_rn(dot3_seq(m.comb + 0, rx, ry, qz), m.trans[0]);
+  float cy = __fadd_rn(dot3_seq(m.comb + 3, rx, ry, qz), m.trans[1]);
+  float cz = __fadd_rn(dot3_seq(m.comb + 6, rx, ry, qz), m.trans[2]);
+  e[0] = dot3_seq(m.bda + 0, cx, cy, cz);
+  e[1] = dot3_seq(m.bda + 3, cx, cy, cz);
+  e[2] = dot3_seq(m.bda + 6, cx, cy, cz);
+}
+
+// voxel_pooling_prepare_v2's index rule (:331-342): idx = trunc_toward_zero((p - lower) / interval),
+// kept iff 0 <= idx and float(idx) < size on all three axes.  Returns the voxel index inside the
+// grid, ((b*nz + z)*ny + y)*nx + x, or -1.
+__device__ __forceinline__ int voxel_of(const dhd_grid& g, const float* e, int b) {
+  int idx[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float t = __fdiv_rn(__fsub_rn(e[a], g.lower[a]), g.interval[a]);
+    float tt = truncf(t);
+    if (!(tt >= 0.0f && tt < g.size[a])) return -1;  // also rejects NaN
+    int ii = (int)tt;
+    if (ii >= g.n[a]) return -1;
+    idx[a] = ii;
+  }
+  return ((b * g.n[2] + idx[2]) * g.n[1] + idx[1]) * g.n[0] + idx[0];
+}
+
+// One thread per camera: the two 3x3 inverses are ~25 serial IEEE divisions, far too slow to
+// repeat in the prologue of every geometry workgroup.
+__global__ __launch_bounds__(64) void mghs_camera(Layout L, dhd_calib cal) {
+  const int bn = blockIdx.x * 64 + threadIdx.x;
+  if (bn >= L.B * L.N) return;
+  CamMats m;
+  load_camera(cal, bn, bn / L.N, &m);
+  float* dst = L.cam + (size_t)bn * kCamFloats;
+  const float* src = reinterpret_cast<const float*>(&m);
+  for (int i = 0; i < (int)(sizeof(CamMats) / 4); ++i) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(kBlock) void mghs_geom_count(Layout L, dhd_calib cal, const uint8_t* __restrict__ band) {
+  __shared__ CamMats cam;
+  const int bn = blockIdx.y;
+  const int b = bn / L.N;
+  if (threadIdx.x < sizeof(CamMats) / 4)
+    reinterpret_cast<float*>(&cam)[threadIdx.x] = L.cam[(size_t)bn * kCamFloats + threadIdx.x];
+  __syncthreads();
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= L.dhw) return;
+  const int w = i % L.fw;
+  const int h = (i / L.fw) % L.fh;
+  const int d = i / L.hw;
+  float e[3];
+  frustum_to_ego(cam, cal.frustum_u[w], cal.frustum_v[h], cal.frustum_d[d], e);
+  const int pid = bn * L.dhw + i;
+  int k0 = -1, r0 = 0, k1 = -1, r1 = 0;
+  int v0 = voxel_of(L.grid[0], e, b);
+  if (v0 >= 0) {
+    k0 = L.vox_base[0] + v0;
+    r0 = atomicAdd(&L.count[k0], 1);
+  }
+  if (L.G > 1) {
+    int g = (int)band[bn * L.hw + (i % L.hw)] + 1;
+    if (g < L.G) {
+      int v1 = voxel_of(L.grid[g], e, b);
+      if (v1 >= 0) {
+        k1 = L.vox_base[g] + v1;
+        r1 = atomicAdd(&L.count[k1], 1);
+      }
+    }
+  }
+  L.key[pid] = k0; L.rnk[pid] = r0;
+  L.key[L.P + pid] = k1; L.rnk[L.P + pid] = r1;
+}
+
+// Introspection twin of the kernel above: one grid, band-independent, optional ego output.
+__global__ __launch_bounds__(kBlock) void mghs_voxel_index_kernel(Layout L, dhd_calib cal, int g, int* __restrict__ rank_map,
+                                                                 float* __restrict__ ego) {
+  __shared__ CamMats cam;
+  const int bn = blockIdx.y;
+  const int b = bn / L.N;
+  if (threadIdx.x == 0) load_camera(cal, bn, b, &cam);
+  __syncthreads();
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= L.dhw) return;
+  const int w = i % L.fw;
+  const int h = (i / L.fw) % L.fh;
+  const int d = i / L.hw;
+  float e[3];
+  frustum_to_ego(cam, cal.frustum_u[w], cal.frustum_v[h], cal.frustum_d[d], e);
+  const size_t pid = (size_t)bn * L.dhw + i;
+  rank_map[pid] = voxel_of(L.grid[g], e, b);
+  if (ego) { ego[pid * 3 + 0] = e[0]; ego[pid * 3 + 1] = e[1]; ego[pid * 3 + 2] = e[2]; }
+}
+
+// ---------------------------------------------------------------------------------------
+// Exclusive scans over the per-voxel counters (two launches: block sums, then scan + carry-in):
+// `offset` = prefix of count (entry index), `nzoff` = prefix of (count > 0) (slot index).
+// ---------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kBlock) void mghs_chunk_sum(const int* __restrict__ count, int V, int n_chunks,
+                                                          int* __restrict__ chunk_sum) {
+  __shared__ int ws[2][kBlock / DHD_WAVE];
+  const int base = blockIdx.x * kChunk;
+  int s = 0, z = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    int i = base + k * kBlock + threadIdx.x;
+    if (i < V) { int c = count[i]; s += c; z += c > 0; }
+  }
+  s = wave_sum_i(s);
+  z = wave_sum_i(z);
+  if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = s; ws[1][threadIdx.x >> 6] = z; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    chunk_sum[blockIdx.x] = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
+    chunk_sum[n_chunks + blockIdx.x] = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void mghs_scan(Layout L) {
+  __shared__ int ws[2][kBlock / DHD_WAVE];
+  __shared__ int ws2[2][kBlock / DHD_WAVE];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int V = L.V;
+  int part = 0, partz = 0;
+  for (int j = t; j < (int)blockIdx.x; j += kBlock) { part += L.chunk_sum[j]; partz += L.chunk_sum[L.n_chunks + j]; }
+  part = wave_sum_i(part);
+  partz = wave_sum_i(partz);
+  if (lane == 0) { ws[0][wv] = part; ws[1][wv] = partz; }
+  const int first = blockIdx.x * kChunk + t * kScanItems;
+  int v[kScanItems];
+  int tsum = 0, tz = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (first + k < V) ? L.count[first + k] : 0;
+    tsum += v[k];
+    tz += v[k] > 0;
+  }
+  int incl = tsum, inclz = tz;
+  for (int d = 1; d < 64; d <<= 1) {
+    int o = __shfl_up(incl, d, DHD_WAVE), oz = __shfl_up(inclz, d, DHD_WAVE);
+    if (lane >= d) { incl += o; inclz += oz; }
+  }
+  if (lane == 63) { ws2[0][wv] = incl; ws2[1][wv] = inclz; }
+  __syncthreads();
+  int run = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
+  int runz = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
+  for (int k = 0; k < wv; ++k) { run += ws2[0][k]; runz += ws2[1][k]; }
+  run += incl - tsum;
+  runz += inclz - tz;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (first + k < V) {
+      L.offset[first + k] = run;
+      L.nzoff[first + k] = runz;
+      if (v[k] > 0) L.nzvox[runz] = first + k;
+    }
+    run += v[k];
+    runz += v[k] > 0;
+    if (first + k == V - 1) { L.offset[V] = run; L.nzoff[V] = runz; }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void mghs_scatter(Layout L) {
+  const int bn = blockIdx.y;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= L.dhw) return;
+  const int pid = bn * L.dhw + i;
+  const int pix = bn * L.hw + (i % L.hw);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int k = L.key[j * L.P + pid];
+    int slot = -1;
+    if (k >= 0) {
+      int pos = L.offset[k] + L.rnk[j * L.P + pid];
+      slot = L.nzoff[k];
+      L.s_pid[pos] = pid;
+      L.s_pix[pos] = pix;
+      L.s_slot[pos] = slot;
+    }
+    L.p_slot[j * L.P + pid] = slot;
+  }
+}
+
+}  // namespace
+}  // namespace dhd
+
+using namespace dhd;
+
+extern "C" {
+
+int dhd_abi_version(void) { return DHD_ABI_VERSION; }
+
+int dhd_mghs_workspace_bytes(const dhd_mghs_desc* desc, size_t* bytes) {
+  if (!bytes) return DHD_EINVAL;
+  Layout L;
+  return make_layout(desc, nullptr, &L, bytes);
+}
+
+static int check_calib(const dhd_calib* c) {
+  if (!c || !c->sensor2ego || !c->post_tran || !c->bda || !c->frustum_u || !c->frustum_v || !c->frustum_d)
+    return DHD_EINVAL;
+  if (!c->inv_post_rot && !c->post_rot) return DHD_EINVAL;
+  if (!c->combine && !c->intrin) return DHD_EINVAL;
+  return DHD_OK;
+}
+
+int dhd_mghs_prepare(const dhd_mghs_desc* desc, const dhd_calib* calib, const uint8_t* band, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  Layout L;
+  size_t need = 0;
+  int rc = make_layout(desc, workspace, &L, &need);
+  if (rc) return rc;
+  if (!workspace) return DHD_EINVAL;
+  if (workspace_bytes < need) return DHD_ENOSPACE;
+  if ((rc = check_calib(calib))) return rc;
+  if (L.G > 1 && !band) return DHD_EINVAL;
+  hipStream_t st = dhd_stream(stream);
+  DHD_HIP(hipMemsetAsync(L.count, 0, (size_t)L.V * 4, st));
+  hipLaunchKernelGGL(mghs_camera, dim3(dhd_cdiv(L.B * L.N, 64)), dim3(64), 0, st, L, *calib);
+  DHD_LAUNCH_CHECK();
+  dim3 gp(dhd_cdiv(L.dhw, kBlock), L.B * L.N);
+  hipLaunchKernelGGL(mghs_geom_count, gp, dim3(kBlock), 0, st, L, *calib, band);
+  DHD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mghs_chunk_sum, dim3(L.n_chunks), dim3(kBlock), 0, st, L.count, L.V, L.n_chunks, L.chunk_sum);
+  DHD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mghs_scan, dim3(L.n_chunks), dim3(kBlock), 0, st, L);
+  DHD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mghs_scatter, gp, dim3(kBlock), 0, st, L);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+int dhd_mghs_voxel_index(const dhd_mghs_desc* desc, const dhd_calib* calib, int grid_index, int32_t* rank_map,
+                         float* ego, void* stream) {
+  Layout L;
+  int rc = make_layout(desc, nullptr, &L, nullptr);
+  if (rc) return rc;
+  if ((rc = check_calib(calib))) return rc;
+  if (!rank_map || grid_index < 0 || grid_index >= L.G) return DHD_EINVAL;
+  dim3 gp(dhd_cdiv(L.dhw, kBlock), L.B * L.N);
+  hipLaunchKernelGGL(mghs_voxel_index_kernel, gp, dim3(kBlock), 0, dhd_stream(stream), L, *calib, grid_index,
+                     rank_map, ego);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+int dhd_mghs_stats(const dhd_mghs_desc* desc, const void* workspace, int32_t n_kept[DHD_MAX_GRIDS],
+                   int32_t n_intervals[DHD_MAX_GRIDS], void* stream) {
+  Layout L;
+  int rc = make_layout(desc, const_cast<void*>(workspace), &L, nullptr);
+  if (rc) return rc;
+  if (!workspace || !n_kept || !n_intervals) return DHD_EINVAL;
+  hipStream_t st = dhd_stream(stream);
+  DHD_HIP(hipStreamSynchronize(st));
+  // not a hot path: read the two prefix arrays at the grid boundaries
+  for (int g = 0; g < DHD_MAX_GRIDS; ++g) {
+    int lo[2], hi[2];
+    DHD_HIP(hipMemcpy(&lo[0], L.offset + L.vox_base[g], 4, hipMemcpyDeviceToHost));
+    DHD_HIP(hipMemcpy(&hi[0], L.offset + L.vox_base[g + 1], 4, hipMemcpyDeviceToHost));
+    DHD_HIP(hipMemcpy(&lo[1], L.nzoff + L.vox_base[g], 4, hipMemcpyDeviceToHost));
+    DHD_HIP(hipMemcpy(&hi[1], L.nzoff + L.vox_base[g + 1], 4, hipMemcpyDeviceToHost));
+    n_kept[g] = hi[0] - lo[0];
+    n_intervals[g] = hi[1] - lo[1];
+  }
+  return DHD_OK;
+}
+
+}  // extern "C"

@@ -151,6 +151,24 @@ def pool_forward(plan, depth, feat_nhwc, workspace):
     return outs
 
 
+def pool_forward_phases(plan, depth, feat_nhwc, workspace, between=None):
+    """pool_forward as its two C-ABI phases; `between()` runs after the gather launch (bench.py
+    records a HIP event there so that the streaming kernel is timed on its own)."""
+    lib = _lib.load()
+    dev = depth.device
+    outs = [torch.empty(s, dtype=torch.float32, device=dev) for s in plan.out_shapes()]
+    arr = _ptr_array(outs)
+    with torch.cuda.device(dev):
+        st = _lib.stream_ptr(dev)
+        _lib.check(lib.dhd_mghs_forward_gather(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc),
+                                               _lib.ptr(workspace), st), 'dhd_mghs_forward_gather')
+        if between is not None:
+            between()
+        _lib.check(lib.dhd_mghs_forward_stream(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
+                                               _lib.ptr(workspace), st), 'dhd_mghs_forward_stream')
+    return outs
+
+
 def pool_backward(plan, depth, feat_nhwc, out_grads, workspace):
     lib = _lib.load()
     dev = depth.device

@@ -20,16 +20,12 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for name, mask in (('full', 0), ('fwd: no gather', 8), ('fwd: gather only, no write-out', 16),
-                   ('bwd: no feat atomics', 1), ('bwd: no dpp reduce', 2), ('bwd: no depth atomics', 4),
-                   ('bwd: no atomics, no reduce', 7), ('bwd: tile load only', 8)):
+for name, mask in (('full', 0), ('fwd stream: no table load', 8), ('fwd stream: no stores', 16), ('bwd entry: no feat atomics', 1)):
     lib.dhd_debug_set_ablation(mask)
     f = timeit(lambda: mghs_op.pool_forward(hp.plan, hp.depth, feat, hp.ws))
     b = timeit(lambda: mghs_op.pool_backward(hp.plan, hp.depth, feat, hp.out_grads, hp.ws))
     print(f'{name:36s} fwd {f:8.1f} us   bwd {b:8.1f} us', flush=True)
 lib.dhd_debug_set_ablation(0)
 for name, fn in (('prepare', lambda: mghs_op.prepare(hp.plan, hp.calib, band, hp.ws)),
-                 ('height_band', lambda: mghs_op.height_band(hp.height, cfg['height_range'], cfg['mask_range'])),
-                 ('memset 704MB', lambda: [o.zero_() for o in hp.out_grads]),
-                 ('copy 704MB', lambda: [o.clone() for o in hp.out_grads])):
+                 ('memset 704MB', lambda: [o.zero_() for o in hp.out_grads])):
     print(f'{name:36s} {timeit(fn):8.1f} us', flush=True)

@@ -141,9 +141,20 @@ int dhd_mghs_prepare(const dhd_mghs_desc* desc, const dhd_calib* calib, const ui
  * out[g] is the FINAL reference layout (B, nz_g*C, ny_g, nx_g) with channel = z*C + c, i.e. the
  * result of bev_pool.py:105 (permute) followed by lss_heightmap.py:298-299 (collapse_z); the same
  * memory viewed as (B, nz_g, C, ny_g, nx_g) serves collapse_z=False.  Every element is written
- * (zeros included); no pre-zeroing needed. */
+ * (zeros included); no pre-zeroing needed.  Uses the workspace's scratch region (per-voxel sums). */
 int dhd_mghs_forward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                     float* const out[DHD_MAX_GRIDS], const void* workspace, void* stream);
+                     float* const out[DHD_MAX_GRIDS], void* workspace, void* stream);
+
+/* The two phases of dhd_mghs_forward, for callers that want to time or overlap them:
+ *   gather : per-voxel sums of depth * context into the workspace's compact table (balanced over the
+ *            grouped entries; instruction-bound)
+ *   stream : the dense writer -- every output tensor once, zero-filled, with the table rows patched in
+ *            (HBM-bound; the dominant kernel of the forward pass)
+ * dhd_mghs_forward == gather then stream on the same stream. */
+int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                            void* workspace, void* stream);
+int dhd_mghs_forward_stream(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                            float* const out[DHD_MAX_GRIDS], void* workspace, void* stream);
 
 /* Pooling backward.  out_grad[g] has the layout of out[g].  depth_grad (B*N,D,fH,fW) and
  * feat_grad_nhwc (B*N,fH,fW,C) are fully overwritten (zero-filled internally).  Pixels outside
