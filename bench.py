@@ -35,6 +35,22 @@ from dhd_amd.mix import channel_spatial_stage  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 
+def pmc_traffic(kernel, batch):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/<round>/pmc_summary.json:
+    separate FETCH_SIZE / WRITE_SIZE runs of this same script, gfx950 correction applied).  PMC
+    counters cannot be read from inside the run, so this is the stored measurement for the same
+    per-GPU batch, or None."""
+    best = None
+    prof = os.path.join(ROOT, 'profiles')
+    for rnd in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        f = os.path.join(prof, rnd, 'pmc_summary.json')
+        if os.path.exists(f):
+            d = json.load(open(f))
+            if d.get('samples_per_gpu') == batch and kernel in d.get('kernels', {}):
+                best = d['kernels'][kernel]['hbm_bytes_per_launch']
+    return best
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
@@ -177,7 +193,7 @@ def main():
                                  '; 6 cams 256x704 -> 16x44, D=44, C=64, grids 200x200x{1,4,4,8}; dense backbone/encoder convs not in the step',
                         samples_per_gpu=a.batch, global_batch=a.batch * world, parallelism=f'sample-sharded x{world}, no data-path collective'),
             roofline=dict(bound='hbm', kernel='mghs_stream_fwd', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s',
-                          frac=achieved / HBM_PEAK_GBPS, traffic=None, launch_ms=kern_ms,
+                          frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic('mghs_stream_fwd', a.batch), launch_ms=kern_ms,
                           algorithmic_bytes=hp.pool_fwd_bytes))
         if world == 1 and a.cpu_samples > 0:
             line['cpu_baseline'] = cpu_baseline(hp, a.cpu_samples)
