@@ -58,6 +58,10 @@ def parse():
     p.add_argument('--warmup', type=int, default=10)
     p.add_argument('--batch', type=int, default=4, help='samples per GPU (DHD-S.py:243 samples_per_gpu=4)')
     p.add_argument('--no-sfa', action='store_true', help='time the MGHS part only')
+    p.add_argument('--workload', choices=['hotpath', 'e2e'], default='hotpath',
+                   help="hotpath: MGHS + SFA stage (default). e2e: the whole DHD-S detector (dense parts on MIOpen/hipBLASLt), "
+                        "forward_train + backward + AdamW step, DDP over RCCL when --gpus > 1")
+    p.add_argument('--amp', choices=['off', 'bf16', 'fp16'], default='off', help='autocast dtype of the dense modules (e2e)')
     p.add_argument('--cpu-samples', type=int, default=2, help='samples for the CPU baseline leg (0 = skip)')
     return p.parse_args()
 
@@ -121,6 +125,85 @@ class HotPath:
         return outs, dg, fg_nchw
 
 
+class EndToEnd:
+    """DHD-S exactly as projects/configs/DHD/DHD-S.py:42-155 (random init, synthetic 6-camera batch,
+    SURVEY.md 8d config 2): forward_train -> sum of the four losses -> backward -> grad clip 5 -> AdamW."""
+
+    def __init__(self, dev, batch, seed, world, amp):
+        import dhd_amd
+        from dhd_amd.detector import dhd_s_model_cfg
+        torch.manual_seed(seed)
+        self.model = dhd_amd.build_detector(dhd_s_model_cfg()).to(dev).train()
+        self.params = [p for p in self.model.parameters() if p.requires_grad]
+        self.n_params = sum(p.numel() for p in self.params)
+        self.net = self.model
+        if world > 1:
+            self.net = torch.nn.parallel.DistributedDataParallel(self.model, device_ids=[dev.index], bucket_cap_mb=64,
+                                                                 gradient_as_bucket_view=True)
+        self.opt = torch.optim.AdamW(self.params, lr=2e-4, weight_decay=1e-2, fused=True)  # DHD-S.py:262
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        N, H, W = 6, 256, 704
+        calib = [t(a) for a in syn.make_calibration(seed, batch, N, (H, W))]
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        imgs = torch.randn(batch, N, 3, H, W, generator=g).to(dev)
+        sel = torch.rand(batch, N, H, W, generator=g) < 0.02
+        self.kw = dict(
+            img_inputs=[imgs] + calib,
+            gt_depth=torch.where(sel, 1 + 44 * torch.rand(batch, N, H, W, generator=g), torch.zeros(())).to(dev),
+            gt_height=torch.where(sel, -1 + 6.4 * torch.rand(batch, N, H, W, generator=g), torch.zeros(())).to(dev),
+            voxel_semantics=torch.randint(0, 18, (batch, 200, 200, 16), generator=g).to(dev),
+            mask_camera=(torch.rand(batch, 200, 200, 16, generator=g) < 0.3).to(dev))
+        self.amp = {'off': None, 'bf16': torch.bfloat16, 'fp16': torch.float16}[amp]
+        self.scaler = torch.amp.GradScaler('cuda') if amp == 'fp16' else None
+        self.B = batch
+
+    def step(self, record):
+        self.opt.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=self.amp, enabled=self.amp is not None):
+            losses = self.net(return_loss=True, **self.kw)
+            loss = sum(losses.values())
+        if self.scaler is not None:
+            self.scaler.scale(loss).backward()
+            self.scaler.unscale_(self.opt)
+            torch.nn.utils.clip_grad_norm_(self.params, 5.0)
+            self.scaler.step(self.opt)
+            self.scaler.update()
+        else:
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(self.params, 5.0)  # DHD-S.py:263
+            self.opt.step()
+        return loss
+
+
+def run_e2e(a, rank, world, dev):
+    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp)
+    for _ in range(a.warmup):
+        job.step(False)
+
+    def fence():
+        torch.cuda.synchronize()
+        ddist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = job.step(True)
+    fence()
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps(dict(
+            metric='samples/sec (6-cam fwd+bwd) DHD-S end-to-end', value=a.batch * world * a.steps / elapsed, unit='samples/s',
+            n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True,
+            scaling='weak', vs_baseline=None, dtype={'off': 'f32', 'bf16': 'bf16', 'fp16': 'f16'}[a.amp], data='synthetic',
+            config=dict(workload='DHD-S (configs[1]/[2]) whole detector: ResNet-50 + FPN, MGHS (HIP), BEV encoder, 3 UNets, SFA '
+                                 '(HIP stage), predictor + losses; forward_train + backward + grad-clip + AdamW; random init',
+                        samples_per_gpu=a.batch, global_batch=a.batch * world, params=job.n_params,
+                        parallelism=f'DDP x{world} (RCCL bucketed all-reduce overlapped with backward)' if world > 1 else 'single GPU',
+                        final_loss=float(loss)))), flush=True)
+    ddist.shutdown()
+
+
 def cpu_baseline(hp, n_samples):
     """Oracle timing on the host: numpy MGHS view_transform fwd+bwd (the reference's op sequence,
     4x geometry + 4x sort + pool + permute) and, for the SFA stage, the reference formula in
@@ -164,6 +247,8 @@ def main():
     dev = torch.device('cuda', local)
     ddist.init_from_env(backend='nccl', device=dev)  # RCCL; used only for the barrier / MAX around the timed region
     _lib.load()
+    if a.workload == 'e2e':
+        return run_e2e(a, rank, world, dev)
     hp = HotPath(dev, a.batch, 1000 + rank, not a.no_sfa)
 
     for _ in range(a.warmup):

@@ -1,0 +1,112 @@
+"""The caller side (DHD detector and its dense modules): shapes, state-dict keys, loss parity
+against the reference's own loss code (golden G6) on CPU; the end-to-end step on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from dhd_amd import synthetic as syn
+
+
+def T(a, dev='cpu'):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_occupancy_losses_match_reference_code():
+    from dhd_amd.detector import geo_scal_loss_with_mask, sem_scal_loss_with_mask
+    g = golden('g6_occ_losses')
+    logits = T(g['logits']).requires_grad_()
+    labels, cam = T(g['labels']), T(g['mask_camera'])
+    ls = sem_scal_loss_with_mask(logits, labels, cam)
+    lg = geo_scal_loss_with_mask(logits, labels, cam, non_empty_idx=17)
+    assert abs(ls.item() - float(g['sem_scal'])) < 1e-5 and abs(lg.item() - float(g['geo_scal'])) < 1e-5
+    (ls + 2.0 * lg).backward()
+    np.testing.assert_allclose(logits.grad.numpy(), g['grad'], atol=1e-7, rtol=1e-4)
+
+
+def test_cross_entropy_with_class_weights_mask_and_avg_factor():
+    from dhd_amd.detector import CrossEntropyLoss
+    torch.manual_seed(0)
+    x, y = torch.randn(50, 18), torch.randint(0, 18, (50,))
+    cw = torch.rand(18) + 0.5
+    m = (torch.rand(50) < 0.5).int()
+    loss = CrossEntropyLoss(class_weight=cw, loss_weight=2.0)(x, y, weight=m, avg_factor=7.0)
+    lp = torch.log_softmax(x, 1)[torch.arange(50), y]
+    assert abs(loss.item() - 2.0 * float((-(lp * cw[y]) * m).sum() / 7.0)) < 1e-5
+
+
+def test_dense_modules_shapes_and_reference_key_names():
+    from dhd_amd import detector as D
+    torch.manual_seed(0)
+    r = D.ResNet(depth=50, out_indices=(2, 3)).eval()
+    c4, c5 = r(torch.randn(1, 3, 64, 96))
+    assert tuple(c4.shape) == (1, 1024, 4, 6) and tuple(c5.shape) == (1, 2048, 2, 3)
+    assert sum(p.numel() for p in r.parameters()) == 23508032  # torchvision/mmdet ResNet-50 trunk
+    assert 'layer3.5.conv3.weight' in r.state_dict() and 'layer1.0.downsample.1.running_var' in r.state_dict()
+    fpn = D.CustomFPN(in_channels=[1024, 2048], out_channels=256, num_outs=1, start_level=0, out_ids=[0]).eval()
+    out = fpn((c4, c5))
+    assert len(out) == 1 and tuple(out[0].shape) == (1, 256, 4, 6)
+    assert set(fpn.state_dict()) == {'lateral_convs.0.conv.weight', 'lateral_convs.0.conv.bias', 'lateral_convs.1.conv.weight',
+                                     'lateral_convs.1.conv.bias', 'fpn_convs.0.conv.weight', 'fpn_convs.0.conv.bias'}
+    bb = D.CustomResNet(numC_input=64, num_channels=[128, 256, 512]).eval()
+    feats = bb(torch.randn(1, 64, 48, 48))
+    assert [tuple(f.shape[1:]) for f in feats] == [(128, 24, 24), (256, 12, 12), (512, 6, 6)]
+    assert 'layers.0.0.downsample.bias' in bb.state_dict()
+    neck = D.FPN_LSS(in_channels=512 + 128, out_channels=256).eval()
+    assert tuple(neck(feats).shape) == (1, 256, 48, 48) and 'up2.4.bias' in neck.state_dict()
+    un = D.UNet(n_channels=256, n_classes=64)
+    assert 31.0e6 < sum(p.numel() for p in un.parameters()) < 31.4e6  # 3 UNets = 93.7 M measured on the reference
+    assert tuple(un.eval()(torch.randn(1, 256, 40, 40)).shape) == (1, 64, 40, 40)
+    assert {'inc.double_conv.0.weight', 'down4.maxpool_conv.1.double_conv.4.running_mean', 'up1.up.weight', 'outc.conv.bias'} <= set(un.state_dict())
+    head = D.predictor(in_dim=256, out_dim=256, Dz=16, num_classes=18, class_balance=True, weight_ce=10.0,
+                       weight_geo=0.2, weight_sem=0.2, loss_occ=dict(type='CrossEntropyLoss', use_sigmoid=False, ignore_index=255))
+    occ = head(torch.randn(1, 256, 20, 12))
+    assert tuple(occ.shape) == (1, 12, 20, 16, 18)
+    losses = head.loss(occ, torch.randint(0, 18, (1, 12, 20, 16)), torch.rand(1, 12, 20, 16) < 0.3)
+    assert set(losses) == {'loss_occ', 'loss_voxel_sem_scal', 'loss_voxel_geo_scal'} and all(torch.isfinite(v) for v in losses.values())
+    assert sum(p.numel() for p in head.parameters()) == 256 * 256 * 9 + 256 + 256 * 512 + 512 + 512 * 288 + 288
+
+
+def test_dhd_s_config_builds_with_reference_parameter_count():
+    import dhd_amd
+    from dhd_amd.detector import dhd_s_model_cfg
+    m = dhd_amd.build_detector(dhd_s_model_cfg())
+    n = sum(p.numel() for p in m.parameters())
+    assert 140e6 < n < 155e6  # ~147 M (3 UNets 93.7 M, ResNet-50 23.5 M, HeightNet 6.8 M, ...)
+    keys = set(m.state_dict())
+    for k in ('img_backbone.layer4.2.conv3.weight', 'img_neck.lateral_convs.1.conv.weight', 'img_view_transformer.depth_net.weight',
+              'img_view_transformer.height_net.reduce_conv.0.weight', 'img_bev_encoder_backbone.layers.2.1.conv2.weight',
+              'img_bev_encoder_neck.up2.4.weight', 'img_voxel_encoder2.inc.double_conv.0.weight', 'mix.mysk_7.fc.0.weight',
+              'mix.mix_shortcut.0.weight', 'occ_head.final_conv.conv.weight', 'occ_head.predicter.2.bias'):
+        assert k in keys, k
+
+
+@pytest.mark.gpu
+def test_dhd_forward_train_and_simple_test_on_gpu(gpu):
+    """Reduced DHD-S (2 cameras, 64x176 images, real 200x200 grids) through forward_train + backward
+    and simple_test: the HIP view transform and SFA inside the detector's own wiring."""
+    import dhd_amd
+    from dhd_amd.detector import dhd_s_model_cfg
+    torch.manual_seed(0)
+    vt = dict(syn.dhd_s_config(), type='MGHS', input_size=(64, 176))
+    m = dhd_amd.build_detector(dhd_s_model_cfg(img_view_transformer=vt)).to(gpu).train()
+    B, N = 1, 2
+    calib = [T(a, gpu) for a in syn.make_calibration(3, B, N, (64, 176))]
+    imgs = torch.randn(B, N, 3, 64, 176, device=gpu)
+    gt_d = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, 1 + 40 * syn.hash_uniform(2, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    gt_h = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, -1 + 6 * syn.hash_uniform(3, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    sem = torch.randint(0, 18, (B, 200, 200, 16), device=gpu)
+    cam = torch.rand(B, 200, 200, 16, device=gpu) < 0.3
+    losses = m(return_loss=True, img_inputs=[imgs] + calib, gt_depth=gt_d, gt_height=gt_h, voxel_semantics=sem, mask_camera=cam)
+    assert set(losses) == {'loss_height', 'loss_occ', 'loss_voxel_sem_scal', 'loss_voxel_geo_scal'}
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    for name in ('img_backbone.conv1.weight', 'img_view_transformer.depth_net.weight', 'img_voxel_encoder0.inc.double_conv.0.weight',
+                 'mix.mysk_7.fc.0.weight', 'mix.mysk_7.spacial_leanring.0.weight', 'occ_head.predicter.0.weight'):
+        g = dict(m.named_parameters())[name].grad
+        assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0, name
+    m.eval()
+    with torch.no_grad():
+        occ = m(return_loss=False, points=None, img_metas=None, img=[imgs] + calib)
+    assert len(occ) == B and occ[0].shape == (200, 200, 16) and occ[0].dtype == np.uint8
