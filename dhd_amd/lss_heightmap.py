@@ -185,7 +185,7 @@ class MGHS(nn.Module):
                 ws = plan.new_workspace(depth.device)
                 mghs_op.prepare(plan, calib, band, ws)
                 self._cached = (ws, plan, band.device)
-            return list(mghs_op._MGHSPool.apply(depth, tran_feat, plan, self._cached[0]))
+            return list(mghs_op._MGHSPool.apply(depth.float(), tran_feat.float(), plan, self._cached[0]))
         return list(mghs_op.mghs_pool(plan, calib, band, depth, tran_feat))
 
     def _split_z(self, x, grid_cfg):

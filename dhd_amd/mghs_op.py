@@ -188,8 +188,10 @@ class _MGHSPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, depth, tran_feat, plan, workspace):
-        depth = _lib.require_gpu_tensor(depth.float().contiguous(), torch.float32, 'depth')
-        tran_feat = _lib.require_gpu_tensor(tran_feat.float().contiguous(), torch.float32, 'tran_feat')
+        # float32 only: callers cast outside the node (see mghs_pool) so that autograd casts the
+        # gradients back to whatever dtype an autocast region produced
+        depth = _lib.require_gpu_tensor(depth.contiguous(), torch.float32, 'depth')
+        tran_feat = _lib.require_gpu_tensor(tran_feat.contiguous(), torch.float32, 'tran_feat')
         feat_nhwc = _nchw_to_nhwc(tran_feat)
         outs = pool_forward(plan, depth, feat_nhwc, workspace)
         ctx.plan = plan
@@ -215,7 +217,7 @@ def mghs_pool(plan, calib, band, depth, tran_feat, workspace=None):
     if workspace is None:
         workspace = plan.new_workspace(depth.device)
     prepare(plan, calib, band, workspace)
-    return _MGHSPool.apply(depth, tran_feat, plan, workspace)
+    return _MGHSPool.apply(depth.float(), tran_feat.float(), plan, workspace)
 
 
 def voxel_index(plan, calib, grid_index, want_ego=False):

@@ -26,7 +26,7 @@ class _AttentionStage(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, stage, *params):
-        x = _lib.require_gpu_tensor(x.float().contiguous(), torch.float32, 'SFA input')
+        x = _lib.require_gpu_tensor(x.contiguous(), torch.float32, 'SFA input')  # cast happens outside the node
         if x.data_ptr() % 16:
             x = x.clone()
         b, c2, h, w = x.shape
@@ -41,13 +41,13 @@ class _AttentionStage(torch.autograd.Function):
             with torch.set_grad_enabled(build_graph):
                 s_in = s.requires_grad_(build_graph)
                 a1 = stage.fc(s_in)  # (B, C), post-sigmoid (mix.py:43)
-            a1d = a1.detach().contiguous()
+            a1d = a1.detach().float().contiguous()  # the inner modules may run under autocast (bf16/fp16)
             u = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
             _call('dhd_sfa_blend1', _lib.ptr(x), _lib.ptr(a1d), _lib.ptr(u), b, c, hw, st)
             with torch.set_grad_enabled(build_graph):
                 u_in = u.requires_grad_(build_graph)
                 s2 = stage.spacial_leanring(u_in)  # pre-sigmoid attention_2 (mix.py:51)
-            s2d = s2.detach().contiguous()
+            s2d = s2.detach().float().contiguous()
             out = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
             _call('dhd_sfa_blend2', _lib.ptr(x), _lib.ptr(a1d), _lib.ptr(s2d), _lib.ptr(out), b, c, hw, st)
         if build_graph:
@@ -73,13 +73,13 @@ class _AttentionStage(torch.autograd.Function):
             _call('dhd_sfa_blend2_backward', _lib.ptr(x), _lib.ptr(a1d), _lib.ptr(s2d), _lib.ptr(go), _lib.ptr(gx),
                   _lib.ptr(gs2), _lib.ptr(ga1), b, c, hw, st)
             # 1x1 conv / BN branch: parameter grads accumulate into .grad, dL/du comes back in u_in.grad
-            torch.autograd.backward([s2], [gs2], inputs=[u_in] + ctx.sp_params)
-            gu = u_in.grad.contiguous()
+            torch.autograd.backward([s2], [gs2.to(s2.dtype)], inputs=[u_in] + ctx.sp_params)
+            gu = u_in.grad.float().contiguous()
             u_in.grad = None
             _call('dhd_sfa_blend1_backward', _lib.ptr(x), _lib.ptr(a1d), _lib.ptr(gu), _lib.ptr(gx), _lib.ptr(ga1),
                   b, c, hw, st)
-            torch.autograd.backward([a1], [ga1], inputs=[s_in] + ctx.fc_params)
-            gs = s_in.grad.contiguous()
+            torch.autograd.backward([a1], [ga1.to(a1.dtype)], inputs=[s_in] + ctx.fc_params)
+            gs = s_in.grad.float().contiguous()
             s_in.grad = None
             _call('dhd_sfa_mean_backward', _lib.ptr(gs), _lib.ptr(gx), b, 2 * c, hw, st)
         ctx.inner = None
@@ -103,7 +103,7 @@ class channel_spatial_stage(nn.Module):
 
     def forward(self, x):
         params = list(self.fc.parameters()) + list(self.spacial_leanring.parameters())
-        return _AttentionStage.apply(x, self, *params)
+        return _AttentionStage.apply(x.float(), self, *params)
 
 
 @NECKS.register_module()

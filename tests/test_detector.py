@@ -110,3 +110,32 @@ def test_dhd_forward_train_and_simple_test_on_gpu(gpu):
     with torch.no_grad():
         occ = m(return_loss=False, points=None, img_metas=None, img=[imgs] + calib)
     assert len(occ) == B and occ[0].shape == (200, 200, 16) and occ[0].dtype == np.uint8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_hip_nodes_under_autocast(gpu, dtype):
+    """Under autocast the dense producers hand bf16/fp16 tensors to the HIP nodes: they must cast
+    outside the node (float32 kernels) and give gradients of the producers' dtype back."""
+    from dhd_amd import SFA, MGHS
+    torch.manual_seed(0)
+    sfa = SFA(32, 16).to(gpu).train()
+    x = torch.randn(2, 32, 12, 20, device=gpu, requires_grad=True)
+    with torch.autocast('cuda', dtype=dtype):
+        y = sfa(x * 1.0)
+        loss = y.float().square().mean()
+    loss.backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    ref = SFA(32, 16).to(gpu).train()
+    ref.load_state_dict(sfa.state_dict())
+    y32 = ref(x.detach())
+    assert (y.float() - y32).abs().max().item() < 0.1  # reduced-precision convs, same function
+    cfg = dict(syn.dhd_s_config(), input_size=(64, 176), in_channels=32, out_channels=64, heightnet_cfg=dict(use_dcn=False))
+    m = MGHS(**cfg).to(gpu).train()
+    calib = [T(a, gpu) for a in syn.make_calibration(5, 1, 2, (64, 176))]
+    feat = torch.randn(1, 2, 32, 4, 11, device=gpu, requires_grad=True)
+    with torch.autocast('cuda', dtype=dtype):
+        outs = m([feat * 1.0] + calib + [m.get_mlp_input(*calib)])
+        loss = sum(o.float().mean() for o in (outs[0], outs[3], outs[4], outs[5]))
+    loss.backward()
+    assert feat.grad is not None and torch.isfinite(feat.grad).all() and m.depth_net.weight.grad.abs().sum() > 0
