@@ -10,5 +10,7 @@ from .bev_pool_v2 import bev_pool_v2, QuickCumsumCuda  # noqa: F401
 from .lss_heightmap import MGHS, MGHS_Depth, MGHS_Stereo  # noqa: F401
 from .mix import SFA, channel_spatial_stage  # noqa: F401
 from .depthnet import HeightNet, DepthNet  # noqa: F401
+from .detector import DHD  # noqa: F401  (also registers ResNet, CustomFPN, CustomResNet, FPN_LSS, UNet, Identity, predictor)
+from .config import Config  # noqa: F401
 
 __version__ = '0.1.0'
