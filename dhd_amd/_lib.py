@@ -34,6 +34,10 @@ class MghsDesc(C.Structure):
                 ('grid', Grid * DHD_MAX_GRIDS)]
 
 
+class TensorView(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('batch_stride', C.c_int64), ('z_stride', C.c_int64), ('channel_stride', C.c_int64)]
+
+
 class Calib(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ('sensor2ego', 'intrin', 'post_rot', 'post_tran', 'bda', 'inv_post_rot', 'combine',
@@ -54,6 +58,8 @@ _PROTOTYPES = {
     'dhd_mghs_forward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P], _I),
     'dhd_mghs_forward_gather': ([C.POINTER(MghsDesc), _P, _P, _P, _P], _I),
     'dhd_mghs_forward_stream': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P], _I),
+    'dhd_mghs_forward_views': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(TensorView * DHD_MAX_GRIDS), _P, _P], _I),
+    'dhd_mghs_backward_views': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(TensorView * DHD_MAX_GRIDS), _P, _P, _P, _P], _I),
     'dhd_mghs_backward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P, _P, _P], _I),
     'dhd_mghs_voxel_index': ([C.POINTER(MghsDesc), C.POINTER(Calib), _I, _P, _P, _P], _I),
     'dhd_mghs_stats': ([C.POINTER(MghsDesc), _P, C.POINTER(C.c_int32 * DHD_MAX_GRIDS),

@@ -3,7 +3,7 @@ projects/mmdet3d_plugin/ops/bev_pool_v2/bev_pool.py (QuickCumsumCuda :11-83, bev
 backed by the gfx950 kernels in csrc/bev_pool_v2.hip through the C ABI.
 
 This is the operator-level seam (the indices are supplied by the caller).  The training hot
-path does not go through here: MGHS uses the fused entry points (csrc/mghs.hip), which also
+path does not go through here: MGHS uses the fused entry points (csrc/mghs_prepare.hip, csrc/mghs_pool.hip), which also
 remove the argsort the reference repeats in every backward (bev_pool.py:47-57).
 """
 import torch

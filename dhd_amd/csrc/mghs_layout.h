@@ -10,8 +10,11 @@ constexpr int kScanItems = 8;
 constexpr int kChunk = kBlock * kScanItems;  // counters per scan block
 constexpr int kTileC = 64;                   // channels handled by one wave (lane == channel)
 constexpr int kCamFloats = 36;               // sizeof(CamMats)/4 = 33, padded
-constexpr int kSegRows = 4;                  // output rows per streaming segment (3200 contiguous bytes per channel at nx=200)
-constexpr int kSegMaxVox = 1024;             // voxels per segment (kSegRows * nx)
+#ifndef DHD_SEG_ROWS
+#define DHD_SEG_ROWS 4
+#endif
+constexpr int kSegRows = DHD_SEG_ROWS;       // output rows per streaming segment (4 rows = 3200 contiguous bytes per channel at nx=200)
+constexpr int kSegMaxVox = 256 * kSegRows;   // voxels per segment (kSegRows * nx, nx <= 256)
 constexpr int kMaxTileX = 256;               // generic dense-row path: voxels along x per tile
 constexpr int kRowGroup = 4;                 // generic dense-row path: rows handed to one XCD at a time
 
@@ -142,7 +145,34 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 
 typedef float vfloat4 __attribute__((ext_vector_type(4)));  // native vector: accepted by the nontemporal builtins
 
-struct OutPtrs { float* p[DHD_MAX_GRIDS]; };
-struct InPtrs { const float* p[DHD_MAX_GRIDS]; };
+// Where grid g's dense tensor lives: element (b, z, c, y, x) is at
+//   p[g] + b*sb[g] + z*sz[g] + c*sc[g] + y*nx + x   (floats).
+// Default (reference layout after permute + collapse_z, (B, nz*C, ny, nx)): sb = nz*C*plane,
+// sz = C*plane, sc = plane.  The un-collapsed (B, C, nz_total, ny, nx) tensor of MGHS_Depth is the
+// same data with sb = C*nz_total*plane, sc = nz_total*plane, sz = plane and p offset by the grid's
+// first z slice.
+struct OutPtrs { float* p[DHD_MAX_GRIDS]; long sb[DHD_MAX_GRIDS], sz[DHD_MAX_GRIDS], sc[DHD_MAX_GRIDS]; };
+struct InPtrs { const float* p[DHD_MAX_GRIDS]; long sb[DHD_MAX_GRIDS], sz[DHD_MAX_GRIDS], sc[DHD_MAX_GRIDS]; };
+
+template <class Ptrs, class T>
+inline int make_views(const Layout& L, T* const bases[DHD_MAX_GRIDS], const dhd_tensor_view* views, Ptrs* o) {
+  for (int g = 0; g < DHD_MAX_GRIDS; ++g) {
+    o->p[g] = nullptr; o->sb[g] = o->sz[g] = o->sc[g] = 0;
+    if (g >= L.G) continue;
+    const long plane = (long)L.grid[g].n[1] * L.grid[g].n[0];
+    if (views) {
+      if (!views[g].ptr) return DHD_EINVAL;
+      o->p[g] = static_cast<T*>(const_cast<void*>(static_cast<const void*>(views[g].ptr)));
+      o->sb[g] = views[g].batch_stride; o->sz[g] = views[g].z_stride; o->sc[g] = views[g].channel_stride;
+      // the 16-byte vector path needs aligned rows
+      if ((o->sb[g] | o->sz[g] | o->sc[g]) & 3) return DHD_EINVAL;
+    } else {
+      if (!bases || !bases[g]) return DHD_EINVAL;
+      o->p[g] = bases[g];
+      o->sb[g] = (long)L.grid[g].n[2] * L.C * plane; o->sz[g] = (long)L.C * plane; o->sc[g] = plane;
+    }
+  }
+  return DHD_OK;
+}
 
 }  // namespace dhd

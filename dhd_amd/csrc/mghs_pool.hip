@@ -26,7 +26,10 @@
 namespace dhd {
 namespace {
 
-constexpr int kStreamBlock = 512;
+#ifndef DHD_STREAM_BLOCK
+#define DHD_STREAM_BLOCK 512
+#endif
+constexpr int kStreamBlock = DHD_STREAM_BLOCK;
 constexpr int kStreamWaves = kStreamBlock / DHD_WAVE;
 constexpr int kTableFloats = 8192;  // LDS patch table: up to 128 voxels x 64 channels, or 1024 x 8
 constexpr int kGatherUnroll = 16;   // gradient rows in flight per wave (backward)
@@ -67,10 +70,10 @@ __device__ __forceinline__ bool decode_segment(const Layout& L, int s, Segment* 
   return true;
 }
 
-// channels handled per pass so that nnz * cp <= kTableFloats (cp in {64,32,16,8})
+// channels handled per pass so that nnz * cp <= kTableFloats (cp in {64,32,...}; kTableFloats >= kSegMaxVox * 4)
 __device__ __forceinline__ int channels_per_pass(int nnz) {
   int cp = kTileC;
-  while (cp > 8 && nnz * cp > kTableFloats) cp >>= 1;
+  while (cp > 4 && nnz * cp > kTableFloats) cp >>= 1;
   return cp;
 }
 
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
   const int cp = channels_per_pass(nnz);
   const int nvec = sg.nvox / 4;
   float* og = out.p[sg.g];
+  const long sb = out.sb[sg.g], sz = out.sz[sg.g], sc = out.sc[sg.g];
   for (int c_lo = 0; c_lo < kTileC; c_lo += cp) {
     __syncthreads();  // slot_of complete / previous pass done with the table
     if (!ABL(8)) {
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
     for (int cc = wv; cc < cp; cc += kStreamWaves) {
       // channel c_lo+cc of this segment: nvox contiguous floats starting at row y0 of its plane
       vfloat4* dst = reinterpret_cast<vfloat4*>(
-          og + ((((size_t)sg.b * sg.nz + sg.z) * kTileC + c_lo + cc) * sg.ny + sg.y0) * sg.nx);
+          og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)(c_lo + cc) * sc + (size_t)sg.y0 * sg.nx);
       for (int i = lane; i < nvec; i += DHD_WAVE) {
         vfloat4 v = {0.f, 0.f, 0.f, 0.f};
         const uint2 sl = *reinterpret_cast<const uint2*>(slot_of + 4 * i);
@@ -235,8 +239,12 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
           if (s2) v.z = table[(s2 - 1) * cp + cc];
           if (s3) v.w = table[(s3 - 1) * cp + cc];
         }
+#ifdef DHD_PLAIN_STORES
+        dst[i] = v;
+#else
         // streamed once, not re-read here: non-temporal, so the output stream does not evict vsum from L2
         __builtin_nontemporal_store(v, dst + i);
+#endif
       }
     }
   }
@@ -265,11 +273,12 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
   const int cp = channels_per_pass(nnz);
   const int nvec = sg.nvox / 4;
   const float* og = og_in.p[sg.g];
+  const long sb = og_in.sb[sg.g], sz = og_in.sz[sg.g], sc = og_in.sc[sg.g];
   for (int c_lo = 0; c_lo < kTileC; c_lo += cp) {
     __syncthreads();
     for (int cc = wv; cc < cp; cc += kStreamWaves) {
       const vfloat4* src = reinterpret_cast<const vfloat4*>(
-          og + ((((size_t)sg.b * sg.nz + sg.z) * kTileC + c_lo + cc) * sg.ny + sg.y0) * sg.nx);
+          og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)(c_lo + cc) * sc + (size_t)sg.y0 * sg.nx);
       for (int i = lane; i < nvec; i += DHD_WAVE) {
         const uint2 sl = *reinterpret_cast<const uint2*>(slot_of + 4 * i);
         const vfloat4 v = __builtin_nontemporal_load(src + i);
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(kRowBlock) void mghs_rows_fwd(Layout L, const float
   float* og = out.p[rt.g];
   const bool vec = ((rt.nx & 3) == 0) && ((xn & 3) == 0) && ((x0 & 3) == 0);
   for (int cc = wv; cc < cn; cc += kRowWaves) {
-    size_t row = ((((size_t)rt.b * rt.nz + rt.z) * L.C + c0 + cc) * rt.ny + rt.y) * rt.nx + x0;
+    size_t row = (size_t)rt.b * out.sb[rt.g] + (size_t)rt.z * out.sz[rt.g] + (size_t)(c0 + cc) * out.sc[rt.g] + (size_t)rt.y * rt.nx + x0;
     const float* src = tile + cc * tile_stride;
     if (vec) {
       vfloat4* dst = reinterpret_cast<vfloat4*>(og + row);
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(kRowBlock) void mghs_rows_bwd(Layout L, const float
   const float* gsrc = og.p[rt.g];
   const bool vec = ((rt.nx & 3) == 0) && ((xn & 3) == 0) && ((x0 & 3) == 0);
   for (int cc = wv; cc < cn; cc += kRowWaves) {
-    size_t row = ((((size_t)rt.b * rt.nz + rt.z) * L.C + c0 + cc) * rt.ny + rt.y) * rt.nx + x0;
+    size_t row = (size_t)rt.b * og.sb[rt.g] + (size_t)rt.z * og.sz[rt.g] + (size_t)(c0 + cc) * og.sc[rt.g] + (size_t)rt.y * rt.nx + x0;
     float* dst = tile + cc * tile_stride;
     if (vec) {
       const float4* src = reinterpret_cast<const float4*>(gsrc + row);
@@ -592,17 +601,15 @@ int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const
   return DHD_OK;
 }
 
-int dhd_mghs_forward_stream(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                            float* const out[DHD_MAX_GRIDS], void* workspace, void* stream) {
+static int forward_stream_impl(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                               float* const out[DHD_MAX_GRIDS], const dhd_tensor_view* views, void* workspace,
+                               void* stream) {
   Layout L;
   int rc = make_layout(desc, workspace, &L, nullptr);
   if (rc) return rc;
-  if (!workspace || !depth || !feat_nhwc || !out) return DHD_EINVAL;
+  if (!workspace || !depth || !feat_nhwc || (!out && !views)) return DHD_EINVAL;
   OutPtrs o;
-  for (int g = 0; g < DHD_MAX_GRIDS; ++g) {
-    o.p[g] = g < L.G ? out[g] : nullptr;
-    if (g < L.G && !out[g]) return DHD_EINVAL;
-  }
+  if ((rc = make_views<OutPtrs, float>(L, out, views, &o))) return rc;
   hipStream_t st = dhd_stream(stream);
   if (L.compact) {
     hipLaunchKernelGGL(mghs_stream_fwd, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, o);
@@ -616,25 +623,35 @@ int dhd_mghs_forward_stream(const dhd_mghs_desc* desc, const float* depth, const
   return DHD_OK;
 }
 
+int dhd_mghs_forward_stream(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                            float* const out[DHD_MAX_GRIDS], void* workspace, void* stream) {
+  return forward_stream_impl(desc, depth, feat_nhwc, out, nullptr, workspace, stream);
+}
+
 int dhd_mghs_forward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                      float* const out[DHD_MAX_GRIDS], void* workspace, void* stream) {
   int rc = dhd_mghs_forward_gather(desc, depth, feat_nhwc, workspace, stream);
   if (rc) return rc;
-  return dhd_mghs_forward_stream(desc, depth, feat_nhwc, out, workspace, stream);
+  return forward_stream_impl(desc, depth, feat_nhwc, out, nullptr, workspace, stream);
 }
 
-int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                      const float* const out_grad[DHD_MAX_GRIDS], float* depth_grad, float* feat_grad_nhwc,
-                      void* workspace, void* stream) {
+int dhd_mghs_forward_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                           const dhd_tensor_view out[DHD_MAX_GRIDS], void* workspace, void* stream) {
+  if (!out) return DHD_EINVAL;
+  int rc = dhd_mghs_forward_gather(desc, depth, feat_nhwc, workspace, stream);
+  if (rc) return rc;
+  return forward_stream_impl(desc, depth, feat_nhwc, nullptr, out, workspace, stream);
+}
+
+static int backward_impl(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                         const float* const out_grad[DHD_MAX_GRIDS], const dhd_tensor_view* views, float* depth_grad,
+                         float* feat_grad_nhwc, void* workspace, void* stream) {
   Layout L;
   int rc = make_layout(desc, workspace, &L, nullptr);
   if (rc) return rc;
-  if (!workspace || !depth || !feat_nhwc || !out_grad || !depth_grad || !feat_grad_nhwc) return DHD_EINVAL;
+  if (!workspace || !depth || !feat_nhwc || (!out_grad && !views) || !depth_grad || !feat_grad_nhwc) return DHD_EINVAL;
   InPtrs in;
-  for (int g = 0; g < DHD_MAX_GRIDS; ++g) {
-    in.p[g] = g < L.G ? out_grad[g] : nullptr;
-    if (g < L.G && !out_grad[g]) return DHD_EINVAL;
-  }
+  if ((rc = make_views<InPtrs, const float>(L, out_grad, views, &in))) return rc;
   hipStream_t st = dhd_stream(stream);
   if (L.compact) {
     hipLaunchKernelGGL(mghs_stream_bwd, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, in);
@@ -653,6 +670,19 @@ int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float
   hipLaunchKernelGGL(mghs_sum_parts, dim3(dhd_cdiv(L.P, kBlock)), dim3(kBlock), 0, st, L.dg_part, L.P, depth_grad);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
+}
+
+int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                      const float* const out_grad[DHD_MAX_GRIDS], float* depth_grad, float* feat_grad_nhwc,
+                      void* workspace, void* stream) {
+  return backward_impl(desc, depth, feat_nhwc, out_grad, nullptr, depth_grad, feat_grad_nhwc, workspace, stream);
+}
+
+int dhd_mghs_backward_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                            const dhd_tensor_view out_grad[DHD_MAX_GRIDS], float* depth_grad, float* feat_grad_nhwc,
+                            void* workspace, void* stream) {
+  if (!out_grad) return DHD_EINVAL;
+  return backward_impl(desc, depth, feat_nhwc, nullptr, out_grad, depth_grad, feat_grad_nhwc, workspace, stream);
 }
 
 }  // extern "C"

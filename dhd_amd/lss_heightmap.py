@@ -169,7 +169,7 @@ class MGHS(nn.Module):
         return out
 
     # ------------------------------------------------------------------ hot path ----------
-    def _pool(self, input, depth, tran_feat, band, grid_cfgs):
+    def _pool(self, input, depth, tran_feat, band, grid_cfgs, layout=None):
         sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
         B, N = sensor2ego.shape[:2]
         fh, fw = depth.shape[-2:]
@@ -177,6 +177,7 @@ class MGHS(nn.Module):
         key = tuple(tuple(tuple(g[a]) for a in 'xyz') for g in grid_cfgs)
         plan = self._plan(B, N, fh, fw, key, grids)
         calib, keep = self._calib(sensor2ego, cam2imgs, post_rots, post_trans, bda)
+        layout = layout or ('collapsed' if self.collapse_z else 'split')
         needs_grad = torch.is_grad_enabled() and (depth.requires_grad or tran_feat.requires_grad)
         if self.accelerate and not needs_grad:
             # static rig at inference: geometry + grouping once, then pooling only (the reference's
@@ -185,21 +186,13 @@ class MGHS(nn.Module):
                 ws = plan.new_workspace(depth.device)
                 mghs_op.prepare(plan, calib, band, ws)
                 self._cached = (ws, plan, band.device)
-            return list(mghs_op._MGHSPool.apply(depth.float(), tran_feat.float(), plan, self._cached[0]))
-        return list(mghs_op.mghs_pool(plan, calib, band, depth, tran_feat))
-
-    def _split_z(self, x, grid_cfg):
-        """(B, nz*C, ny, nx) -> (B, C, nz, ny, nx) when collapse_z is off (reference :296-299)."""
-        if self.collapse_z:
-            return x
-        b, _, ny, nx = x.shape
-        return x.view(b, -1, self.out_channels, ny, nx).transpose(1, 2).contiguous()
+            return list(mghs_op._MGHSPool.apply(depth.float(), tran_feat.float(), plan, self._cached[0], layout))
+        return list(mghs_op.mghs_pool(plan, calib, band, depth, tran_feat, layout=layout))
 
     def view_transform_core(self, input, depth, tran_feat):
         """Single-grid lift-splat on the CURRENT grid_config (reference :380-405)."""
         cfg = {a: self.grid_config[a] for a in 'xyz'}
-        out = self._pool(input, depth, tran_feat, None, [cfg])[0]
-        return self._split_z(out, cfg), depth
+        return self._pool(input, depth, tran_feat, None, [cfg])[0], depth
 
     def _set_grid(self, cfg):
         self.grid_config = cfg
@@ -208,17 +201,17 @@ class MGHS(nn.Module):
     def _band(self, height):
         return mghs_op.height_band(height, self.height_range, self.mask_range)
 
-    def _four_grid_pool(self, input, depth, tran_feat, height):
+    def _four_grid_pool(self, input, depth, tran_feat, height, layout=None):
         band = self._band(height)
         cfgs = [dict(_FULL_GRID), self.mask_1_grid, self.mask_2_grid, self.mask_3_grid]
-        return self._pool(input, depth, tran_feat, band, cfgs)
+        return self._pool(input, depth, tran_feat, band, cfgs, layout)
 
     def view_transform(self, input, depth, tran_feat, height):
         """-> (bev_feat, depth, height, low, mid, high) (reference :407-459)."""
         outs = self._four_grid_pool(input, depth, tran_feat, height)
         self._set_grid(dict(_FULL_GRID))
         self._set_grid(self.mask_3_grid)  # state the reference leaves behind (:455-456)
-        bev, lo, mid, hi = (self._split_z(o, None) for o in outs)
+        bev, lo, mid, hi = outs  # (B, nz*C, ny, nx) each, or (B, C, nz, ny, nx) with collapse_z=False
         return bev, depth, height, lo, mid, hi
 
     def forward(self, input, stereo_metas=None):
@@ -324,14 +317,15 @@ class MGHS_Depth(MGHS):
     def view_transform(self, input, depth, tran_feat, height):
         """-> (bev_feat, bev_feat_w_z (B,C,16,ny,nx), depth, height) (reference :793-856); unlike the
         base class the grid_config is reset to the full grid afterwards (:848-854)."""
-        outs = self._four_grid_pool(input, depth, tran_feat, height)
-        self._set_grid(dict(_FULL_GRID))
-        bev = self._split_z(outs[0], None)
-        bands = [self._split_z(o, None) for o in outs[1:]]
         if self.collapse_z:
-            bev_w_z = torch.cat(bands, dim=2 if bands[0].dim() == 5 else 1)
+            # not used by any shipped config; the reference's cat(dim=2) of 4-D tensors (:845) would
+            # stack the bands along y, which is reproduced literally
+            outs = self._four_grid_pool(input, depth, tran_feat, height)
+            bev, bev_w_z = outs[0], torch.cat(outs[1:], dim=2)
         else:
-            bev_w_z = torch.cat(bands, dim=2)
+            # the three band grids are written straight into one (B, C, 16, ny, nx) tensor
+            bev, bev_w_z = self._four_grid_pool(input, depth, tran_feat, height, layout='stacked')
+        self._set_grid(dict(_FULL_GRID))
         return bev, bev_w_z, depth, height
 
     def get_depth_and_height_loss(self, gt_depth, gt_height, depth, height):

@@ -183,41 +183,118 @@ def pool_backward(plan, depth, feat_nhwc, out_grads, workspace):
     return depth_grad, feat_grad
 
 
+# Output layouts of the pooled tensors
+#   'collapsed' : per grid (B, nz*C, ny, nx), channel = z*C + c   (collapse_z=True, lss_heightmap.py:298-299)
+#   'split'     : per grid (B, C, nz, ny, nx)                     (collapse_z=False, bev_pool.py:105)
+#   'stacked'   : grid 0 as (B, C, nz0, ny, nx) and ALL band grids in one (B, C, sum nz, ny, nx) tensor
+#                 (MGHS_Depth's bev_feat_w_z, lss_heightmap.py:845) -- written in place, no cat
+LAYOUTS = ('collapsed', 'split', 'stacked')
+
+
+def _alloc_outputs(plan, layout, device):
+    d = plan.desc
+    if layout == 'collapsed':
+        return [torch.empty(s, dtype=torch.float32, device=device) for s in plan.out_shapes()]
+    if layout == 'split':
+        return [torch.empty((d.batch, d.channels, g.n[2], g.n[1], g.n[0]), dtype=torch.float32, device=device)
+                for g in plan.grids]
+    bands = plan.grids[1:]
+    if not bands or any((g.n[0], g.n[1]) != (bands[0].n[0], bands[0].n[1]) for g in bands):
+        raise ValueError("layout 'stacked' needs band grids of equal (nx, ny)")
+    g0 = plan.grids[0]
+    return [torch.empty((d.batch, d.channels, g0.n[2], g0.n[1], g0.n[0]), dtype=torch.float32, device=device),
+            torch.empty((d.batch, d.channels, sum(g.n[2] for g in bands), bands[0].n[1], bands[0].n[0]),
+                        dtype=torch.float32, device=device)]
+
+
+def _views(plan, layout, tensors):
+    """dhd_tensor_view per grid for tensors laid out as `layout` (see LAYOUTS)."""
+    d = plan.desc
+    arr = (_lib.TensorView * _lib.DHD_MAX_GRIDS)()
+    zoff = 0
+    for i, g in enumerate(plan.grids):
+        plane = g.n[1] * g.n[0]
+        if layout == 'collapsed':
+            t, v = tensors[i], (g.n[2] * d.channels * plane, d.channels * plane, plane, 0)
+        elif layout == 'split' or i == 0:
+            t, v = tensors[i], (d.channels * g.n[2] * plane, plane, g.n[2] * plane, 0)
+        else:
+            t = tensors[1]
+            zt = t.shape[2]
+            v = (d.channels * zt * plane, plane, zt * plane, zoff * plane)
+            zoff += g.n[2]
+        if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+            raise _lib.DhdError('pooled tensors must be contiguous float32 GPU tensors')
+        arr[i].ptr = t.data_ptr() + 4 * v[3]
+        arr[i].batch_stride, arr[i].z_stride, arr[i].channel_stride = v[0], v[1], v[2]
+    return arr
+
+
 class _MGHSPool(torch.autograd.Function):
-    """depth (B*N,D,fH,fW), tran_feat (B*N,C,fH,fW) -> one (B, nz*C, ny, nx) tensor per grid."""
+    """depth (B*N,D,fH,fW), tran_feat (B*N,C,fH,fW) -> pooled tensors in the requested layout."""
 
     @staticmethod
-    def forward(ctx, depth, tran_feat, plan, workspace):
+    def forward(ctx, depth, tran_feat, plan, workspace, layout='collapsed'):
         # float32 only: callers cast outside the node (see mghs_pool) so that autograd casts the
         # gradients back to whatever dtype an autocast region produced
         depth = _lib.require_gpu_tensor(depth.contiguous(), torch.float32, 'depth')
         tran_feat = _lib.require_gpu_tensor(tran_feat.contiguous(), torch.float32, 'tran_feat')
         feat_nhwc = _nchw_to_nhwc(tran_feat)
-        outs = pool_forward(plan, depth, feat_nhwc, workspace)
-        ctx.plan = plan
+        lib = _lib.load()
+        dev = depth.device
+        outs = _alloc_outputs(plan, layout, dev)
+        arr = _views(plan, layout, outs)
+        with torch.cuda.device(dev):
+            rc = lib.dhd_mghs_forward_views(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
+                                            _lib.ptr(workspace), _lib.stream_ptr(dev))
+        _lib.check(rc, 'dhd_mghs_forward_views')
+        ctx.plan, ctx.layout = plan, layout
         ctx.save_for_backward(depth, feat_nhwc, workspace)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         depth, feat_nhwc, workspace = ctx.saved_tensors
-        plan = ctx.plan
-        gs = []
-        for g, shape in zip(grads, plan.out_shapes()):
-            if g is None:
-                g = torch.zeros(shape, dtype=torch.float32, device=depth.device)
-            gs.append(g.float().contiguous())
-        depth_grad, feat_grad_nhwc = pool_backward(plan, depth, feat_nhwc, gs, workspace)
-        return depth_grad, _nhwc_to_nchw(feat_grad_nhwc), None, None
+        plan, layout = ctx.plan, ctx.layout
+        lib = _lib.load()
+        dev = depth.device
+        shapes = [tuple(t.shape) for t in _alloc_shapes(plan, layout)]
+        gs = [torch.zeros(s, dtype=torch.float32, device=dev) if g is None else g.float().contiguous()
+              for g, s in zip(grads, shapes)]
+        arr = _views(plan, layout, gs)
+        depth_grad = torch.empty_like(depth)
+        feat_grad = torch.empty_like(feat_nhwc)
+        with torch.cuda.device(dev):
+            rc = lib.dhd_mghs_backward_views(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
+                                             _lib.ptr(depth_grad), _lib.ptr(feat_grad), _lib.ptr(workspace),
+                                             _lib.stream_ptr(dev))
+        _lib.check(rc, 'dhd_mghs_backward_views')
+        return depth_grad, _nhwc_to_nchw(feat_grad), None, None, None
 
 
-def mghs_pool(plan, calib, band, depth, tran_feat, workspace=None):
+class _Shape:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+def _alloc_shapes(plan, layout):
+    d = plan.desc
+    if layout == 'collapsed':
+        return [_Shape(s) for s in plan.out_shapes()]
+    if layout == 'split':
+        return [_Shape((d.batch, d.channels, g.n[2], g.n[1], g.n[0])) for g in plan.grids]
+    g0, bands = plan.grids[0], plan.grids[1:]
+    return [_Shape((d.batch, d.channels, g0.n[2], g0.n[1], g0.n[0])),
+            _Shape((d.batch, d.channels, sum(g.n[2] for g in bands), bands[0].n[1], bands[0].n[0]))]
+
+
+def mghs_pool(plan, calib, band, depth, tran_feat, workspace=None, layout='collapsed'):
     """Prepare (geometry + grouping) and pool.  `workspace` may be passed to reuse memory in
     inference; under autograd a fresh one is held by the graph until backward has run."""
     if workspace is None:
         workspace = plan.new_workspace(depth.device)
     prepare(plan, calib, band, workspace)
-    return _MGHSPool.apply(depth.float(), tran_feat.float(), plan, workspace)
+    return _MGHSPool.apply(depth.float(), tran_feat.float(), plan, workspace, layout)
 
 
 def voxel_index(plan, calib, grid_index, want_ego=False):

@@ -156,6 +156,23 @@ int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const
 int dhd_mghs_forward_stream(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                             float* const out[DHD_MAX_GRIDS], void* workspace, void* stream);
 
+/* Strided placement of one grid's dense tensor: element (b, z, c, y, x) lives at
+ *   ptr + b*batch_stride + z*z_stride + c*channel_stride + y*nx + x      (strides in floats, multiples of 4).
+ * The default layout of out[g] above is {nz*C*ny*nx, C*ny*nx, ny*nx}.  MGHS_Depth's un-collapsed
+ * (B, C, 16, ny, nx) tensor (lss_heightmap.py:845, bev_feat_w_z) is written in place by giving every band
+ * grid the view {C*16*ny*nx, ny*nx, 16*ny*nx} with ptr advanced to the band's first z slice: no
+ * permute / cat copies. */
+typedef struct dhd_tensor_view {
+  const float* ptr; /* [dev]; written through by dhd_mghs_forward_views */
+  int64_t batch_stride, z_stride, channel_stride;
+} dhd_tensor_view;
+
+int dhd_mghs_forward_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                           const dhd_tensor_view out[DHD_MAX_GRIDS], void* workspace, void* stream);
+int dhd_mghs_backward_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                            const dhd_tensor_view out_grad[DHD_MAX_GRIDS], float* depth_grad,
+                            float* feat_grad_nhwc, void* workspace, void* stream);
+
 /* Pooling backward.  out_grad[g] has the layout of out[g].  depth_grad (B*N,D,fH,fW) and
  * feat_grad_nhwc (B*N,fH,fW,C) are fully overwritten (zero-filled internally).  Pixels outside
  * a band contribute nothing to that band's grid, matching d(tran_feat * mask), :436-442.

@@ -380,3 +380,89 @@ def test_sfa_stage_full_size_vs_torch(gpu):
     assert (gx - x.grad).abs().max().item() < 1e-4 * max(1.0, x.grad.abs().max().item())
     for a, p in zip(gp, st.parameters()):
         assert (a - p.grad).abs().max().item() < 2e-3 * max(1.0, p.grad.abs().max().item())
+
+
+# --------------------------------------------------------------------------- layouts / API variants
+
+def _small64(seed, n_cams=3):
+    cfg = small_dhds_cfg()
+    cfg['out_channels'] = 64
+    calib_np = syn.make_calibration(seed, 1, n_cams, cfg['input_size'])
+    depth, feat, hidx = syn.lift_inputs(seed + 1, 1, n_cams, 44, 4, 11, 64, 65)
+    return cfg, calib_np, depth, feat, hidx
+
+
+def test_single_grid_view_transform_core_compact_path(gpu):
+    """view_transform_core (reference :380-405) = one grid, C = 64: the compact path with G = 1."""
+    from dhd_amd import MGHS
+    from oracle import mghs_oracle as O
+    cfg, calib_np, depth, feat, hidx = _small64(300)
+    m = MGHS(**dict(cfg, heightnet_cfg=dict(use_dcn=False, use_aspp=False))).to(gpu)
+    calib = [T(a, gpu) for a in calib_np]
+    x = torch.zeros(1, 3, 1, 4, 11, device=gpu)
+    dt, ft = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+    m._set_grid(m.mask_3_grid)
+    out, d2 = m.view_transform_core([x] + calib, dt, ft)
+    axes = O.frustum_axes(cfg['grid_config']['depth'], cfg['input_size'], 16)
+    coor = O.ego_coor(axes, calib_np[0], calib_np[2], calib_np[3], calib_np[4], calib_np[5])
+    grid = {a: cfg['mask_3_grid'][a] for a in 'xyz'}
+    ref = O.voxel_pooling_v2(coor, depth.reshape(1, 3, 44, 4, 11), feat.reshape(1, 3, 64, 4, 11), grid)
+    assert d2 is dt and out.shape == ref.shape == (1, 8 * 64, 200, 200)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=1e-5, rtol=1e-5)
+    out.sum().backward()
+    assert torch.isfinite(dt.grad).all() and ft.grad.abs().sum() > 0
+
+
+def test_uncollapsed_layouts_match_collapsed(gpu):
+    """collapse_z=False: base MGHS returns (B,C,nz,ny,nx) per grid, MGHS_Depth one (B,C,16,ny,nx)
+    tensor for the three bands (lss_heightmap.py:845) -- written in place through strided views."""
+    from dhd_amd import MGHS, MGHS_Depth
+    cfg, calib_np, depth, feat, hidx = _small64(310)
+    calib = [T(a, gpu) for a in calib_np]
+    x = torch.zeros(1, 3, 1, 4, 11, device=gpu)
+    height = T(syn.height_probs_from_index(hidx, 65), gpu)
+    hn = dict(use_dcn=False, use_aspp=False)
+    ref_m = MGHS(**dict(cfg, heightnet_cfg=hn)).to(gpu)
+    d0, f0 = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+    bev, _, _, lo, mid, hi = ref_m.view_transform([x] + calib, d0, f0, height)
+    ws = [T(syn.hash_signed(320 + k, tuple(o.shape)), gpu) for k, o in enumerate((bev, lo, mid, hi))]
+    sum((o * w).sum() for o, w in zip((bev, lo, mid, hi), ws)).backward()
+
+    def split(o):  # (B, nz*C, ny, nx) -> (B, C, nz, ny, nx)
+        return o.view(1, -1, 64, 200, 200).transpose(1, 2)
+
+    m1 = MGHS(**dict(cfg, heightnet_cfg=hn, collapse_z=False)).to(gpu)
+    d1, f1 = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+    outs = m1.view_transform([x] + calib, d1, f1, height)
+    for o, r in zip((outs[0], outs[3], outs[4], outs[5]), (bev, lo, mid, hi)):
+        assert o.dim() == 5 and o.is_contiguous()
+        assert torch.allclose(o, split(r), atol=1e-5)
+    sum((o * split(w)).sum() for o, w in zip((outs[0], outs[3], outs[4], outs[5]), ws)).backward()
+    assert torch.allclose(d1.grad, d0.grad, atol=1e-4) and torch.allclose(f1.grad, f0.grad, atol=1e-4)
+
+    m2 = MGHS_Depth(**dict(cfg, heightnet_cfg=hn, depthnet_cfg=hn, collapse_z=False)).to(gpu)
+    d2, f2 = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+    bev2, bev_w_z, dd, hh = m2.view_transform([x] + calib, d2, f2, height)
+    assert bev2.shape == (1, 64, 1, 200, 200) and bev_w_z.shape == (1, 64, 16, 200, 200) and dd is d2 and hh is height
+    stacked = torch.cat([split(lo), split(mid), split(hi)], dim=2)
+    assert torch.allclose(bev_w_z, stacked, atol=1e-5) and torch.allclose(bev2, split(bev), atol=1e-5)
+    wz = torch.cat([split(w) for w in ws[1:]], dim=2)
+    ((bev2 * split(ws[0])).sum() + (bev_w_z * wz).sum()).backward()
+    assert torch.allclose(d2.grad, d0.grad, atol=1e-4) and torch.allclose(f2.grad, f0.grad, atol=1e-4)
+    assert m2.grid_config['z'] == [-1, 5.4, 6.4]  # MGHS_Depth resets the grid (:848-854)
+
+
+def test_accelerate_reuses_the_grouping_at_inference(gpu):
+    from dhd_amd import MGHS
+    cfg, calib_np, depth, feat, hidx = _small64(330)
+    m = MGHS(**dict(cfg, heightnet_cfg=dict(use_dcn=False, use_aspp=False), accelerate=True)).to(gpu).eval()
+    calib = [T(a, gpu) for a in calib_np]
+    x = torch.zeros(1, 3, 1, 4, 11, device=gpu)
+    height = T(syn.height_probs_from_index(hidx, 65), gpu)
+    with torch.no_grad():
+        a = m.view_transform([x] + calib, T(depth, gpu), T(feat, gpu), height)
+        ws = m._cached[0]
+        b = m.view_transform([x] + calib, T(2 * depth, gpu), T(feat, gpu), height)
+    assert m._cached[0] is ws
+    for k in (0, 3, 4, 5):
+        assert torch.allclose(b[k], 2 * a[k], atol=1e-4)
