@@ -182,7 +182,7 @@ class MGHS(nn.Module):
         if self.accelerate and not needs_grad:
             # static rig at inference: geometry + grouping once, then pooling only (the reference's
             # dormant accelerate/pre_compute idea, :234-258,374-378)
-            if self._cached is None or self._cached[1] is not plan or self._cached[2] is not band.device:
+            if self._cached is None or self._cached[1] is not plan or self._cached[2] != band.device:
                 ws = plan.new_workspace(depth.device)
                 mghs_op.prepare(plan, calib, band, ws)
                 self._cached = (ws, plan, band.device)
