@@ -21,8 +21,6 @@
 // data-dependent loops: the latency-bound gather lives in the balanced per-entry kernels.
 // A generic dense-row path (any C, any grid shape) is kept for configurations the compact path does
 // not cover.
-#include <mutex>
-
 #include "mghs_layout.h"
 
 namespace dhd {
@@ -39,12 +37,9 @@ constexpr int kGatherUnroll = 16;   // gradient rows in flight per wave (backwar
 #ifdef DHD_ABLATION
 // Experiment-only build (make ablate): phases can be switched off to price them.  Never in libdhd_amd.so.
 __device__ int g_ablate = 0;
-int g_ablate_host = 0;
 #define ABL(bit) ((g_ablate & (bit)) != 0)
-#define ABL_HOST(bit) ((dhd::g_ablate_host & (bit)) != 0)
 #else
 #define ABL(bit) false
-#define ABL_HOST(bit) false
 #endif
 
 // ---------------------------------------------------------------------------------------
@@ -122,16 +117,13 @@ struct GatherStep<DHD_WAVE> {
                                              int&, float&) {}
 };
 
-// The kernel covers the entries of the voxels [v_begin, v_end) (both voxel boundaries, so no voxel
-// straddles a part): the forward is issued in parts so that the gather of one part runs under the
-// streaming writer of another.
 __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float* __restrict__ depth,
-                                                            const float* __restrict__ feat, int v_begin, int v_end) {
+                                                            const float* __restrict__ feat) {
   const int lane = threadIdx.x & 63;
-  const int E0 = L.offset[v_begin], T = L.offset[v_end];  // entry range (device-side values, scalar loads)
+  const int T = L.offset[L.V];  // total entries (device-side value, scalar load)
   // everything that steers control flow is forced into SGPRs: the compiler cannot see that
   // threadIdx.x >> 6 is wave-uniform and would otherwise predicate every branch through EXEC
-  const int a = rfl(E0 + (blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6)) * DHD_WAVE);
+  const int a = rfl((blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6)) * DHD_WAVE);
   if (a >= T) return;
   const int b = min(T, a + DHD_WAVE);
   const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -203,14 +195,14 @@ __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float
 // ---------------------------------------------------------------------------------------
 constexpr size_t kStreamLds = (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2 + 16;
 
-__global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtrs out, int seg_begin) {
+__global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtrs out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* table = reinterpret_cast<float*>(smem);
   unsigned short* slot_of = reinterpret_cast<unsigned short*>(smem + (size_t)kTableFloats * 4);
   int* ctl = reinterpret_cast<int*>(smem + (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2);
 
   Segment sg;
-  if (!decode_segment(L, seg_begin + blockIdx.x, &sg)) return;
+  if (!decode_segment(L, blockIdx.x, &sg)) return;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   if (t == 0) ctl[0] = L.nzoff[sg.v0];
   if (t == 1) ctl[1] = L.nzoff[sg.v0 + sg.nvox];
@@ -592,10 +584,7 @@ using namespace dhd;
 extern "C" {
 
 #ifdef DHD_ABLATION
-int dhd_debug_set_ablation(int mask) {
-  dhd::g_ablate_host = mask;
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &mask, sizeof(int));
-}
+int dhd_debug_set_ablation(int mask) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &mask, sizeof(int)); }
 #endif
 
 int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc, void* workspace,
@@ -607,7 +596,7 @@ int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const
   if (!L.compact) return DHD_OK;  // the generic path gathers inside its row kernel
   // 2P is an upper bound of the entry count; waves past the real count exit at once
   hipLaunchKernelGGL(mghs_gather_sums, dim3(dhd_cdiv(2L * L.P, kBlock)), dim3(kBlock), 0, dhd_stream(stream), L, depth,
-                     feat_nhwc, 0, L.V);
+                     feat_nhwc);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
@@ -623,7 +612,7 @@ static int forward_stream_impl(const dhd_mghs_desc* desc, const float* depth, co
   if ((rc = make_views<OutPtrs, float>(L, out, views, &o))) return rc;
   hipStream_t st = dhd_stream(stream);
   if (L.compact) {
-    hipLaunchKernelGGL(mghs_stream_fwd, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, o, 0);
+    hipLaunchKernelGGL(mghs_stream_fwd, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, o);
     DHD_LAUNCH_CHECK();
   } else {
     int stride; size_t smem; dim3 grid;
@@ -639,92 +628,19 @@ int dhd_mghs_forward_stream(const dhd_mghs_desc* desc, const float* depth, const
   return forward_stream_impl(desc, depth, feat_nhwc, out, nullptr, workspace, stream);
 }
 
-// ---- overlapped forward -----------------------------------------------------------------------
-// The gather is instruction-bound and the writer HBM-bound: issued in parts, with the gathers on an
-// internal side stream, part k+1 is gathered while part k is written.  Band grids go first (their
-// entries are few), grid 0 (more than half of all entries) is gathered under the band writers and
-// written last.  Fork/join through events, so the caller's stream sees one ordered operation (and
-// the pattern is stream-capture safe).
-namespace {
-struct SideStream {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, part[3] = {nullptr, nullptr, nullptr};
-};
-constexpr int kMaxDevices = 32;
-SideStream g_side[kMaxDevices];
-std::mutex g_side_mutex;
-
-int side_stream(SideStream** out) {
-  int dev = -1;
-  DHD_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= kMaxDevices) return DHD_EUNSUPPORTED;
-  std::lock_guard<std::mutex> lock(g_side_mutex);
-  SideStream& s = g_side[dev];
-  if (!s.stream) {
-    DHD_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    DHD_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
-    for (auto& e : s.part) DHD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
-  *out = &s;
-  return DHD_OK;
-}
-}  // namespace
-
-static int forward_overlapped(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                              float* const out[DHD_MAX_GRIDS], const dhd_tensor_view* views, void* workspace,
-                              void* stream) {
-  Layout L;
-  int rc = make_layout(desc, workspace, &L, nullptr);
-  if (rc) return rc;
-  if (!workspace || !depth || !feat_nhwc || (!out && !views)) return DHD_EINVAL;
-  if (!L.compact || L.G == 1 || ABL_HOST(256)) {
-    if ((rc = dhd_mghs_forward_gather(desc, depth, feat_nhwc, workspace, stream))) return rc;
-    return forward_stream_impl(desc, depth, feat_nhwc, out, views, workspace, stream);
-  }
-  OutPtrs o;
-  if ((rc = make_views<OutPtrs, float>(L, out, views, &o))) return rc;
-  SideStream* side;
-  if ((rc = side_stream(&side))) return rc;
-  hipStream_t user = dhd_stream(stream);
-  // parts: band segments first half, band segments second half, grid 0
-  const int s1 = L.seg_base[1], mid = s1 + (L.n_segs - s1) / 2;
-  const int seg_lo[3] = {s1, mid, 0}, seg_hi[3] = {mid, L.n_segs, s1};
-  const int nvox0 = kSegRows * L.grid[0].n[0];
-  auto seg_vox = [&](int sidx) {  // first voxel id of segment sidx
-    int g = 0;
-    for (int k = 1; k < L.G; ++k) if (sidx >= L.seg_base[k]) g = k;
-    if (sidx >= L.n_segs) return L.V;
-    (void)nvox0;
-    return L.vox_base[g] + (sidx - L.seg_base[g]) * kSegRows * L.grid[g].n[0];
-  };
-  DHD_HIP(hipEventRecord(side->fork, user));
-  DHD_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
-  for (int p = 0; p < 3; ++p) {
-    // a part holds at most P entries (one per point in grid 0, one per point over all band grids)
-    hipLaunchKernelGGL(mghs_gather_sums, dim3(dhd_cdiv((long)L.P, kBlock)), dim3(kBlock), 0, side->stream, L, depth,
-                       feat_nhwc, seg_vox(seg_lo[p]), seg_vox(seg_hi[p]));
-    DHD_LAUNCH_CHECK();
-    DHD_HIP(hipEventRecord(side->part[p], side->stream));
-  }
-  for (int p = 0; p < 3; ++p) {
-    DHD_HIP(hipStreamWaitEvent(user, side->part[p], 0));
-    if (seg_hi[p] > seg_lo[p]) {
-      hipLaunchKernelGGL(mghs_stream_fwd, dim3(seg_hi[p] - seg_lo[p]), dim3(kStreamBlock), kStreamLds, user, L, o, seg_lo[p]);
-      DHD_LAUNCH_CHECK();
-    }
-  }
-  return DHD_OK;
-}
-
 int dhd_mghs_forward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                      float* const out[DHD_MAX_GRIDS], void* workspace, void* stream) {
-  return forward_overlapped(desc, depth, feat_nhwc, out, nullptr, workspace, stream);
+  int rc = dhd_mghs_forward_gather(desc, depth, feat_nhwc, workspace, stream);
+  if (rc) return rc;
+  return forward_stream_impl(desc, depth, feat_nhwc, out, nullptr, workspace, stream);
 }
 
 int dhd_mghs_forward_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                            const dhd_tensor_view out[DHD_MAX_GRIDS], void* workspace, void* stream) {
   if (!out) return DHD_EINVAL;
-  return forward_overlapped(desc, depth, feat_nhwc, nullptr, out, workspace, stream);
+  int rc = dhd_mghs_forward_gather(desc, depth, feat_nhwc, workspace, stream);
+  if (rc) return rc;
+  return forward_stream_impl(desc, depth, feat_nhwc, nullptr, out, workspace, stream);
 }
 
 static int backward_impl(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
