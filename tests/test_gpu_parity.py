@@ -466,3 +466,41 @@ def test_accelerate_reuses_the_grouping_at_inference(gpu):
     assert m._cached[0] is ws
     for k in (0, 3, 4, 5):
         assert torch.allclose(b[k], 2 * a[k], atol=1e-4)
+
+
+def test_mghs_step_is_graph_capturable(gpu):
+    """prepare + forward + backward are plain launches / async memsets on the caller's stream: the
+    whole view transform can be captured into a HIP graph and replayed on new inputs."""
+    from dhd_amd import mghs_op
+    cfg, calib_np, depth, feat, hidx = _small64(340)
+    plan, axes = make_plan(cfg, 1, 3, channels=64)
+    calib, keep = device_calib(calib_np, axes, gpu)
+    d_in, f_in = T(depth, gpu), T(feat, gpu)
+    height = T(syn.height_probs_from_index(hidx, 65), gpu)
+    ws = plan.new_workspace(gpu)
+    gouts = [T(syn.hash_signed(350 + k, s), gpu) for k, s in enumerate(plan.out_shapes())]
+
+    def step():
+        band = mghs_op.height_band(height, cfg['height_range'], cfg['mask_range'])
+        fn = mghs_op._nchw_to_nhwc(f_in)
+        mghs_op.prepare(plan, calib, band, ws)
+        outs = mghs_op.pool_forward(plan, d_in, fn, ws)
+        dg, fg = mghs_op.pool_backward(plan, d_in, fn, gouts, ws)
+        return outs, dg, mghs_op._nhwc_to_nchw(fg)
+
+    ref = step()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cap = step()
+    d_in.mul_(2.0)  # new input values in the captured buffers
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(cap[0], ref[0]):
+        assert torch.allclose(a, 2 * b, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(cap[1], ref[1], atol=1e-4) and torch.allclose(cap[2], 2 * ref[2], atol=1e-3, rtol=1e-4)
