@@ -31,7 +31,10 @@ namespace {
 #endif
 constexpr int kStreamBlock = DHD_STREAM_BLOCK;
 constexpr int kStreamWaves = kStreamBlock / DHD_WAVE;
-constexpr int kTableFloats = 8192;  // LDS patch table: up to 128 voxels x 64 channels, or 1024 x 8
+#ifndef DHD_TABLE_FLOATS
+#define DHD_TABLE_FLOATS 8192
+#endif
+constexpr int kTableFloats = DHD_TABLE_FLOATS;  // LDS patch table: 128 voxels x 64 channels, or more voxels x fewer channels per pass
 constexpr int kGatherUnroll = 16;   // gradient rows in flight per wave (backward)
 
 #ifdef DHD_ABLATION

@@ -13,6 +13,13 @@
 namespace dhd {
 namespace {
 
+#ifdef DHD_ABLATION
+__device__ int g_prep_ablate = 0;  // experiment-only build: 1 = skip the counting atomics
+#define PABL(bit) ((g_prep_ablate & (bit)) != 0)
+#else
+#define PABL(bit) false
+#endif
+
 // ---------------------------------------------------------------------------------------
 // Geometry.  The operation order, the absence of FMA contraction and the IEEE division are
 // part of the contract: voxel indices must be bit-identical to the reference's float32 chain
@@ -144,6 +151,33 @@ __global__ __launch_bounds__(64) void mghs_camera(Layout L, dhd_calib cal) {
   for (int i = 0; i < (int)(sizeof(CamMats) / 4); ++i) dst[i] = src[i];
 }
 
+// Counting with run aggregation.  A wave holds whole pixel COLUMNS of one depth plane: lane =
+// (column cc, row hh) with HP = next_pow2(fH) lanes per column.  Rows of one column at one depth
+// differ only vertically, so in the full-height grid 0 they almost always share one voxel (this is
+// where its ~17 entries per voxel come from), and in the band grids neighbouring rows often share a
+// z bin.  Runs of equal keys along hh are counted with ONE returning atomic by the run's first lane
+// (+= run length); the members take base + offset.  Measured: the per-entry device-scope atomics
+// were 49 of the 108 us of prepare at B=4.
+__device__ __forceinline__ int count_runs(int* __restrict__ count, int key, int hh, int lane) {
+  const bool valid = key >= 0;
+  const int prev = __shfl_up(key, 1, DHD_WAVE);
+  const bool first = valid && (hh == 0 || prev != key);
+  const unsigned long long F = __ballot(first);
+  const unsigned long long V = __ballot(valid);
+  // leader of this lane's run: nearest first at or below the lane
+  const unsigned long long below = F & ((2ull << lane) - 1ull);
+  const int leader = valid ? 63 - __builtin_clzll(below | 1ull) : lane;
+  int base = 0;
+  if (first) {
+    // run end: next first, or next invalid lane, above the leader
+    const unsigned long long stop = (F | ~V) & ~((2ull << lane) - 1ull);
+    const int end = stop ? __builtin_ctzll(stop) : DHD_WAVE;
+    base = atomicAdd(&count[key], end - lane);
+  }
+  base = __shfl(base, leader, DHD_WAVE);
+  return valid ? base + (lane - leader) : 0;
+}
+
 __global__ __launch_bounds__(kBlock) void mghs_geom_count(Layout L, dhd_calib cal, const uint8_t* __restrict__ band) {
   __shared__ CamMats cam;
   const int bn = blockIdx.y;
@@ -151,32 +185,38 @@ __global__ __launch_bounds__(kBlock) void mghs_geom_count(Layout L, dhd_calib ca
   if (threadIdx.x < sizeof(CamMats) / 4)
     reinterpret_cast<float*>(&cam)[threadIdx.x] = L.cam[(size_t)bn * kCamFloats + threadIdx.x];
   __syncthreads();
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= L.dhw) return;
-  const int w = i % L.fw;
-  const int h = (i / L.fw) % L.fh;
-  const int d = i / L.hw;
+  const int lane = threadIdx.x & 63;
+  const int HP = next_pow2(L.fh);           // lanes per column (fh <= 64 checked on the host)
+  const int hh = lane & (HP - 1), cc = lane / HP;
+  const int wave = blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6);
+  const int col = wave * (DHD_WAVE / HP) + cc;  // column index inside the camera: d * fW + w
+  const bool in_range = hh < L.fh && col < L.D * L.fw;
+  const int w = in_range ? col % L.fw : 0, d = in_range ? col / L.fw : 0, h = in_range ? hh : 0;
   float e[3];
   frustum_to_ego(cam, cal.frustum_u[w], cal.frustum_v[h], cal.frustum_d[d], e);
+  const int i = (d * L.fh + h) * L.fw + w;
   const int pid = bn * L.dhw + i;
-  int k0 = -1, r0 = 0, k1 = -1, r1 = 0;
-  int v0 = voxel_of(L.grid[0], e, b);
-  if (v0 >= 0) {
-    k0 = L.vox_base[0] + v0;
-    r0 = atomicAdd(&L.count[k0], 1);
-  }
-  if (L.G > 1) {
-    int g = (int)band[bn * L.hw + (i % L.hw)] + 1;
-    if (g < L.G) {
-      int v1 = voxel_of(L.grid[g], e, b);
-      if (v1 >= 0) {
-        k1 = L.vox_base[g] + v1;
-        r1 = atomicAdd(&L.count[k1], 1);
+  int k0 = -1, k1 = -1;
+  if (in_range) {
+    const int v0 = voxel_of(L.grid[0], e, b);
+    if (v0 >= 0) k0 = L.vox_base[0] + v0;
+    if (L.G > 1) {
+      const int g = (int)band[bn * L.hw + h * L.fw + w] + 1;
+      if (g < L.G) {
+        const int v1 = voxel_of(L.grid[g], e, b);
+        if (v1 >= 0) k1 = L.vox_base[g] + v1;
       }
     }
   }
-  L.key[pid] = k0; L.rnk[pid] = r0;
-  L.key[L.P + pid] = k1; L.rnk[L.P + pid] = r1;
+  int r0 = 0, r1 = 0;
+  if (!PABL(1)) {
+    r0 = count_runs(L.count, k0, hh, lane);
+    if (L.G > 1) r1 = count_runs(L.count, k1, hh, lane);
+  }
+  if (in_range) {
+    L.key[pid] = k0; L.rnk[pid] = r0;
+    L.key[L.P + pid] = k1; L.rnk[L.P + pid] = r1;
+  }
 }
 
 // Introspection twin of the kernel above: one grid, band-independent, optional ego output.
@@ -296,6 +336,10 @@ using namespace dhd;
 
 extern "C" {
 
+#ifdef DHD_ABLATION
+int dhd_debug_set_prepare_ablation(int mask) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prep_ablate), &mask, sizeof(int)); }
+#endif
+
 int dhd_abi_version(void) { return DHD_ABI_VERSION; }
 
 int dhd_mghs_workspace_bytes(const dhd_mghs_desc* desc, size_t* bytes) {
@@ -327,7 +371,14 @@ int dhd_mghs_prepare(const dhd_mghs_desc* desc, const dhd_calib* calib, const ui
   hipLaunchKernelGGL(mghs_camera, dim3(dhd_cdiv(L.B * L.N, 64)), dim3(64), 0, st, L, *calib);
   DHD_LAUNCH_CHECK();
   dim3 gp(dhd_cdiv(L.dhw, kBlock), L.B * L.N);
-  hipLaunchKernelGGL(mghs_geom_count, gp, dim3(kBlock), 0, st, L, *calib, band);
+  {
+    int hp = 1;
+    while (hp < L.fh) hp <<= 1;
+    if (hp > DHD_WAVE) return DHD_EUNSUPPORTED;  // feature maps taller than 64 rows
+    const long cols_per_block = (long)(kBlock / DHD_WAVE) * (DHD_WAVE / hp);
+    dim3 gc(dhd_cdiv((long)L.D * L.fw, cols_per_block), L.B * L.N);
+    hipLaunchKernelGGL(mghs_geom_count, gc, dim3(kBlock), 0, st, L, *calib, band);
+  }
   DHD_LAUNCH_CHECK();
   hipLaunchKernelGGL(mghs_chunk_sum, dim3(L.n_chunks), dim3(kBlock), 0, st, L.count, L.V, L.n_chunks, L.chunk_sum);
   DHD_LAUNCH_CHECK();
