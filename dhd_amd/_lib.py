@@ -44,6 +44,20 @@ class Calib(C.Structure):
                  'frustum_u', 'frustum_v', 'frustum_d')]
 
 
+class SfaWeights(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in
+                 ('fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'conv1_w', 'conv1_b', 'bn1_w', 'bn1_b', 'bn1_mean', 'bn1_var',
+                  'conv2_w', 'conv2_b', 'bn2_w', 'bn2_b', 'bn2_mean', 'bn2_var')] +
+                [('hidden', C.c_int32), ('training', C.c_int32), ('eps1', C.c_float), ('eps2', C.c_float),
+                 ('momentum1', C.c_float), ('momentum2', C.c_float)])
+
+
+class SfaGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ('fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'conv1_w', 'conv1_b', 'bn1_w', 'bn1_b',
+                 'conv2_w', 'conv2_b', 'bn2_w', 'bn2_b')]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _PROTOTYPES = {
@@ -70,6 +84,11 @@ _PROTOTYPES = {
     'dhd_sfa_blend2_backward': ([_P] * 7 + [_I, _I, _I, _P], _I),
     'dhd_sfa_blend1_backward': ([_P] * 5 + [_I, _I, _I, _P], _I),
     'dhd_sfa_mean_backward': ([_P, _P, _I, _I, _I, _P], _I),
+    'dhd_sfa_stage_supported': ([_I, _I], _I),
+    'dhd_sfa_stage_saved_bytes': ([_I, _I, _I, _I], C.c_size_t),
+    'dhd_sfa_stage_scratch_bytes': ([_I, _I, _I, _I], C.c_size_t),
+    'dhd_sfa_stage_forward': ([_P, C.POINTER(SfaWeights), _P, _P, _P, _I, _I, _I, _P], _I),
+    'dhd_sfa_stage_backward': ([_P, C.POINTER(SfaWeights), _P, _P, _P, C.POINTER(SfaGrads), _P, _I, _I, _I, _P], _I),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

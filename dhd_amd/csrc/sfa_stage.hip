@@ -1,0 +1,977 @@
+// SFA channel/spatial attention stage as ONE operator (forward and backward), for gfx950.
+//
+// Reference: models/necks/mix.py:8-59 (channel_spatial_stage).  With x = cat[x_bev, x_voxel]:
+//   s   = mean_hw(x)                         a = sigmoid(fc(s))                     (mix.py:41-44)
+//   u   = a*x_bev + (1-a)*x_voxel                                                    (mix.py:46-50)
+//   y1  = conv1(u)   z1 = relu(bn1(y1))   y2 = conv2(z1)   s2 = bn2(y2)              (mix.py:51)
+//   out = sigmoid(s2)*(a*x_bev) + (1-sigmoid(s2))*((1-a)*x_voxel)                    (mix.py:52-58)
+//
+// The two 1x1 convolutions are (C x C) x (C x B*HW) float32 GEMMs on NCHW data.  Here they run on
+// the f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate) with everything
+// element-wise FUSED into the operand path, so no intermediate but y1 and y2 is ever stored:
+//   * pw_gemm: a wave owns 32 pixels x 256 output channels (128 accumulator registers).  The
+//     activation operand is loaded straight from NCHW global memory into the MFMA B layout (lane =
+//     (k parity, pixel): two 128-byte row segments per load) and passes through a per-(sample,channel)
+//     affine prologue  act(c0*in0 + c1*in1 + c2)  -- which is blend1 (in0,in1 = x_bev,x_voxel),
+//     BatchNorm+ReLU (in0 = y1) or BatchNorm-backward (in0,in1 = g,y).  The weight operand comes
+//     from LDS images pre-packed so that one ds_read_b128 feeds four MFMAs.
+//   * pw_wgrad: weight gradients, pixels are the reduction dimension: tiles of both operands are
+//     staged through LDS (with the same prologues), 8 waves x (128 x 64) outputs, per-worker
+//     partial matrices reduced by a second small kernel (deterministic, no float atomics).
+//   * BatchNorm statistics / gradient sums are per-plane streaming reductions with double-precision
+//     finalisation; the blends are fused with the BatchNorm affine and the sigmoid.
+// Forward reads x three times and y1/y2 twice; nothing is transposed, there is no NHWC detour.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kEwBlock = 256;     // element-wise / reduction kernels
+constexpr int kPlaneChunks = 4;   // blocks per (b, c) plane
+constexpr int kPwBlock = 256;     // pw_gemm: 4 waves
+constexpr int kPwStep = 16;       // input channels per weight image / pipeline step
+constexpr int kWgBlock = 512;     // pw_wgrad: 8 waves
+constexpr int kWgStride = 33;     // LDS row stride of a 32-pixel operand row (conflict-free column reads)
+constexpr int kWgWorkers = 256;   // total pw_wgrad blocks (one per CU)
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = group_sum(v, DHD_WAVE);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wv] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int k = 0; k < (int)(blockDim.x / DHD_WAVE); ++k) t += sm[k];
+  return t;
+}
+
+// [lo, hi) in float4 units of this block's share of a plane of hw floats (hw % 4 == 0).
+__device__ __forceinline__ void chunk_range4(int hw, int* lo, int* hi) {
+  const int n4 = hw >> 2, per = (n4 + kPlaneChunks - 1) / kPlaneChunks;
+  *lo = blockIdx.x * per;
+  *hi = min(n4, *lo + per);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small dense pieces: channel mean -> fc -> a, and its backward
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kEwBlock) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ part, int hw) {
+  __shared__ float sm[kEwBlock / DHD_WAVE];
+  const size_t plane = blockIdx.y;
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(x + plane * hw);
+  int lo, hi;
+  chunk_range4(hw, &lo, &hi);
+  float a0 = 0.f, a1 = 0.f;
+  int i = lo + threadIdx.x;
+  for (; i + kEwBlock < hi; i += 2 * kEwBlock) {
+    f32x4 v = __builtin_nontemporal_load(p4 + i), w = __builtin_nontemporal_load(p4 + i + kEwBlock);
+    a0 += (v.x + v.y) + (v.z + v.w);
+    a1 += (w.x + w.y) + (w.z + w.w);
+  }
+  if (i < hi) {
+    f32x4 v = __builtin_nontemporal_load(p4 + i);
+    a0 += (v.x + v.y) + (v.z + v.w);
+  }
+  float tot = block_sum(a0 + a1, sm);
+  if (threadIdx.x == 0) part[plane * kPlaneChunks + blockIdx.x] = tot;
+}
+
+// one block per sample: s = mean, h = relu(fc1 s), a = sigmoid(fc2 h); blend table (a, 1-a, 0)
+__global__ __launch_bounds__(kEwBlock) void fc_forward_kernel(const float* __restrict__ part, const float* __restrict__ w1,
+                                                              const float* __restrict__ b1, const float* __restrict__ w2,
+                                                              const float* __restrict__ b2, float* __restrict__ s,
+                                                              float* __restrict__ hbuf, float* __restrict__ a,
+                                                              float* __restrict__ tab, int c, int r, int hw) {
+  extern __shared__ float sh[];  // s (2c) | h (r)
+  float* ss = sh;
+  float* hh = sh + 2 * c;
+  const int b = blockIdx.x, c2 = 2 * c;
+  for (int i = threadIdx.x; i < c2; i += kEwBlock) {
+    const float* q = part + ((size_t)b * c2 + i) * kPlaneChunks;
+    float v = ((q[0] + q[1]) + (q[2] + q[3])) / (float)hw;
+    ss[i] = v;
+    s[(size_t)b * c2 + i] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int j = wv; j < r; j += kEwBlock / DHD_WAVE) {
+    float acc = 0.f;
+    for (int i = lane; i < c2; i += DHD_WAVE) acc = fmaf(w1[(size_t)j * c2 + i], ss[i], acc);
+    acc = group_sum(acc, DHD_WAVE);
+    if (lane == 0) {
+      float v = fmaxf(acc + b1[j], 0.f);
+      hh[j] = v;
+      hbuf[(size_t)b * r + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < c; k += kEwBlock) {
+    float acc = b2[k];
+    for (int j = 0; j < r; ++j) acc = fmaf(w2[(size_t)k * r + j], hh[j], acc);
+    float v = sigmoidf_(acc);
+    a[(size_t)b * c + k] = v;
+    float* t = tab + (size_t)b * 3 * c;
+    t[k] = v;
+    t[c + k] = 1.0f - v;
+    t[2 * c + k] = 0.f;
+  }
+}
+
+// one block per sample: da (from the two partial sets) -> dpre2, dh, ds
+__global__ __launch_bounds__(kEwBlock) void fc_backward_kernel(const float* __restrict__ da_p1, const float* __restrict__ da_p2,
+                                                               const float* __restrict__ a, const float* __restrict__ hbuf,
+                                                               const float* __restrict__ w1, const float* __restrict__ w2,
+                                                               float* __restrict__ dpre2, float* __restrict__ dh,
+                                                               float* __restrict__ ds, int c, int r) {
+  extern __shared__ float sh[];  // dpre2 (c) | dh (r)
+  float* sp = sh;
+  float* sd = sh + c;
+  const int b = blockIdx.x, c2 = 2 * c;
+  for (int k = threadIdx.x; k < c; k += kEwBlock) {
+    float g = 0.f;
+    for (int q = 0; q < kPlaneChunks; ++q)
+      g += da_p1[((size_t)b * kPlaneChunks + q) * c + k] + da_p2[((size_t)b * kPlaneChunks + q) * c + k];
+    const float av = a[(size_t)b * c + k];
+    const float v = g * av * (1.0f - av);
+    sp[k] = v;
+    dpre2[(size_t)b * c + k] = v;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < r; j += kEwBlock) {
+    float acc = 0.f;
+    for (int k = 0; k < c; ++k) acc = fmaf(w2[(size_t)k * r + j], sp[k], acc);
+    const float v = hbuf[(size_t)b * r + j] > 0.f ? acc : 0.f;
+    sd[j] = v;
+    dh[(size_t)b * r + j] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c2; i += kEwBlock) {
+    float acc = 0.f;
+    for (int j = 0; j < r; ++j) acc = fmaf(w1[(size_t)j * c2 + i], sd[j], acc);
+    ds[(size_t)b * c2 + i] = acc;
+  }
+}
+
+// parameter gradients of the two Linear layers: one thread per output element
+__global__ __launch_bounds__(kEwBlock) void fc_param_grad_kernel(const float* __restrict__ dpre2, const float* __restrict__ dh,
+                                                                 const float* __restrict__ hbuf, const float* __restrict__ s,
+                                                                 float* __restrict__ gw1, float* __restrict__ gb1,
+                                                                 float* __restrict__ gw2, float* __restrict__ gb2, int nb,
+                                                                 int c, int r) {
+  const int c2 = 2 * c;
+  const int n_w1 = r * c2, n_w2 = c * r;
+  int i = blockIdx.x * kEwBlock + threadIdx.x;
+  if (i < n_w1) {
+    const int j = i / c2, k = i % c2;
+    float acc = 0.f;
+    for (int b = 0; b < nb; ++b) acc = fmaf(dh[(size_t)b * r + j], s[(size_t)b * c2 + k], acc);
+    gw1[i] = acc;
+    return;
+  }
+  i -= n_w1;
+  if (i < n_w2) {
+    const int k = i / r, j = i % r;
+    float acc = 0.f;
+    for (int b = 0; b < nb; ++b) acc = fmaf(dpre2[(size_t)b * c + k], hbuf[(size_t)b * r + j], acc);
+    gw2[i] = acc;
+    return;
+  }
+  i -= n_w2;
+  if (i < r) {
+    float acc = 0.f;
+    for (int b = 0; b < nb; ++b) acc += dh[(size_t)b * r + i];
+    gb1[i] = acc;
+    return;
+  }
+  i -= r;
+  if (i < c) {
+    float acc = 0.f;
+    for (int b = 0; b < nb; ++b) acc += dpre2[(size_t)b * c + i];
+    gb2[i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm statistics
+// ------------------------------------------------------------------------------------------------
+
+// per plane chunk: sum (y - K), sum (y - K)^2 with K = y[0, ch, 0] (a sample of the channel, so the
+// shifted sums do not cancel).  part: [(b*chunks + chunk)][2][c]
+__global__ __launch_bounds__(kEwBlock) void moments_kernel(const float* __restrict__ y, float* __restrict__ part, int c, int hw) {
+  __shared__ float sm[kEwBlock / DHD_WAVE];
+  const int plane = blockIdx.y, b = plane / c, ch = plane % c;
+  const float k = y[(size_t)ch * hw];
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(y + (size_t)plane * hw);
+  int lo, hi;
+  chunk_range4(hw, &lo, &hi);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
+    f32x4 v = p4[i];
+    const float d0 = v.x - k, d1 = v.y - k, d2 = v.z - k, d3 = v.w - k;
+    s1 += (d0 + d1) + (d2 + d3);
+    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  s1 = block_sum(s1, sm);
+  s2 = block_sum(s2, sm);
+  if (threadIdx.x == 0) {
+    float* q = part + ((size_t)(b * kPlaneChunks + blockIdx.x) * 2) * c;
+    q[ch] = s1;
+    q[c + ch] = s2;
+  }
+}
+
+// Batch statistics -> mean, rstd, (scale, shift), prologue table (scale, 0, shift) per sample;
+// running statistics updated like torch.nn.BatchNorm2d (biased variance normalises, unbiased feeds
+// the running estimate).
+__global__ __launch_bounds__(kEwBlock) void bn_train_finalize_kernel(const float* __restrict__ part, const float* __restrict__ y,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                     float momentum, float eps, float* __restrict__ mean,
+                                                                     float* __restrict__ rstd, float* __restrict__ scsh,
+                                                                     float* __restrict__ tab, int nb, int c, int hw) {
+  const int ch = blockIdx.x * kEwBlock + threadIdx.x;
+  if (ch >= c) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int q = 0; q < nb * kPlaneChunks; ++q) {
+    s1 += (double)part[((size_t)q * 2) * c + ch];
+    s2 += (double)part[((size_t)q * 2 + 1) * c + ch];
+  }
+  const double n = (double)nb * (double)hw;
+  const double md = s1 / n;
+  double var = s2 / n - md * md;
+  if (var < 0.0) var = 0.0;
+  const double mu = (double)y[(size_t)ch * hw] + md;
+  const float rs = (float)(1.0 / sqrt(var + (double)eps));
+  mean[ch] = (float)mu;
+  rstd[ch] = rs;
+  const float sc = gamma[ch] * rs, shf = beta[ch] - (float)mu * sc;
+  scsh[ch] = sc;
+  scsh[c + ch] = shf;
+  for (int b = 0; b < nb; ++b) {
+    float* t = tab + (size_t)b * 3 * c;
+    t[ch] = sc;
+    t[c + ch] = 0.f;
+    t[2 * c + ch] = shf;
+  }
+  if (run_mean) {
+    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+    run_mean[ch] = (float)((1.0 - (double)momentum) * (double)run_mean[ch] + (double)momentum * mu);
+    run_var[ch] = (float)((1.0 - (double)momentum) * (double)run_var[ch] + (double)momentum * unb);
+  }
+}
+
+__global__ __launch_bounds__(kEwBlock) void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                                                float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                                                float* __restrict__ scsh, float* __restrict__ tab, int nb, int c) {
+  const int ch = blockIdx.x * kEwBlock + threadIdx.x;
+  if (ch >= c) return;
+  const float rs = 1.0f / sqrtf(run_var[ch] + eps);
+  mean[ch] = run_mean[ch];
+  rstd[ch] = rs;
+  const float sc = gamma[ch] * rs, shf = beta[ch] - run_mean[ch] * sc;
+  scsh[ch] = sc;
+  scsh[c + ch] = shf;
+  for (int b = 0; b < nb; ++b) {
+    float* t = tab + (size_t)b * 3 * c;
+    t[ch] = sc;
+    t[c + ch] = 0.f;
+    t[2 * c + ch] = shf;
+  }
+}
+
+// sums for BatchNorm backward: S1 = sum g, S2 = sum g*(y - mean).  part: [(b*chunks+chunk)][2][c]
+__global__ __launch_bounds__(kEwBlock) void pair_sums_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                             const float* __restrict__ mean, float* __restrict__ part, int c, int hw) {
+  __shared__ float sm[kEwBlock / DHD_WAVE];
+  const int plane = blockIdx.y, b = plane / c, ch = plane % c;
+  const float mu = mean[ch];
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g + (size_t)plane * hw);
+  const f32x4* y4 = reinterpret_cast<const f32x4*>(y + (size_t)plane * hw);
+  int lo, hi;
+  chunk_range4(hw, &lo, &hi);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
+    f32x4 a = g4[i], v = y4[i];
+    s1 += (a.x + a.y) + (a.z + a.w);
+    s2 += (a.x * (v.x - mu) + a.y * (v.y - mu)) + (a.z * (v.z - mu) + a.w * (v.w - mu));
+  }
+  s1 = block_sum(s1, sm);
+  s2 = block_sum(s2, sm);
+  if (threadIdx.x == 0) {
+    float* q = part + ((size_t)(b * kPlaneChunks + blockIdx.x) * 2) * c;
+    q[ch] = s1;
+    q[c + ch] = s2;
+  }
+}
+
+// BatchNorm backward coefficients: dy = c0*g + c1*y + c2 (per channel), dgamma, dbeta, and the
+// gradient of the bias of the convolution feeding this BatchNorm (sum of dy).
+//   training: dy = gamma*rstd*(g - S1/n - (y-mu)*rstd^2*S2/n);  eval: dy = gamma*rstd*g
+__global__ __launch_bounds__(kEwBlock) void bn_backward_coef_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                    int training, float* __restrict__ tab, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, float* __restrict__ dbias, int nb,
+                                                                    int c, int hw) {
+  const int ch = blockIdx.x * kEwBlock + threadIdx.x;
+  if (ch >= c) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int q = 0; q < nb * kPlaneChunks; ++q) {
+    s1 += (double)part[((size_t)q * 2) * c + ch];
+    s2 += (double)part[((size_t)q * 2 + 1) * c + ch];
+  }
+  const double n = (double)nb * (double)hw;
+  const double rs = (double)rstd[ch], mu = (double)mean[ch], ga = (double)gamma[ch];
+  if (dgamma) dgamma[ch] = (float)(rs * s2);
+  if (dbeta) dbeta[ch] = (float)s1;
+  double c0 = ga * rs, c1 = 0.0, c2 = 0.0, db = c0 * s1;
+  if (training) {
+    c1 = -ga * rs * rs * rs * s2 / n;
+    c2 = -ga * rs * s1 / n - c1 * mu;
+    db = 0.0;  // sum of dy over the batch vanishes identically
+  }
+  if (dbias) dbias[ch] = (float)db;
+  for (int b = 0; b < nb; ++b) {
+    float* t = tab + (size_t)b * 3 * c;
+    t[ch] = (float)c0;
+    t[c + ch] = (float)c1;
+    t[2 * c + ch] = (float)c2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused blends
+// ------------------------------------------------------------------------------------------------
+
+// out = g*(a*xb) + (1-g)*((1-a)*xv),  g = sigmoid(sc*y2 + sh)
+__global__ __launch_bounds__(kEwBlock) void blend2_bn_kernel(const float* __restrict__ x, const float* __restrict__ a1,
+                                                             const float* __restrict__ y2, const float* __restrict__ scsh,
+                                                             float* __restrict__ out, int c, int hw) {
+  const int plane = blockIdx.y, b = plane / c, ch = plane % c;
+  const float a = a1[plane], na = 1.0f - a, sc = scsh[ch], sh = scsh[c + ch];
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + ch) * hw);
+  const f32x4* v4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + c + ch) * hw);
+  const f32x4* y4 = reinterpret_cast<const f32x4*>(y2 + (size_t)plane * hw);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out + (size_t)plane * hw);
+  int lo, hi;
+  chunk_range4(hw, &lo, &hi);
+  for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
+    f32x4 p = __builtin_nontemporal_load(b4 + i), q = __builtin_nontemporal_load(v4 + i), s = y4[i], r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = sigmoidf_(fmaf(sc, s[j], sh));
+      r[j] = g * (a * p[j]) + (1.0f - g) * (na * q[j]);
+    }
+    __builtin_nontemporal_store(r, o4 + i);
+  }
+}
+
+// g2 = dL/d s2 = go*(a*xb - (1-a)*xv)*g*(1-g); sums for BatchNorm-2 backward; the go-part of dL/da:
+// sum go*(g*xb - (1-g)*xv).   part: [(b*chunks+chunk)][2][c];  da_p1: [(b*chunks+chunk)][c]
+__global__ __launch_bounds__(kEwBlock) void blend2_bn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ a1,
+                                                                 const float* __restrict__ y2, const float* __restrict__ scsh,
+                                                                 const float* __restrict__ mean, const float* __restrict__ go,
+                                                                 float* __restrict__ g2, float* __restrict__ part,
+                                                                 float* __restrict__ da_p1, int c, int hw) {
+  __shared__ float sm[kEwBlock / DHD_WAVE];
+  const int plane = blockIdx.y, b = plane / c, ch = plane % c;
+  const float a = a1[plane], na = 1.0f - a, sc = scsh[ch], sh = scsh[c + ch], mu = mean[ch];
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + ch) * hw);
+  const f32x4* v4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + c + ch) * hw);
+  const f32x4* y4 = reinterpret_cast<const f32x4*>(y2 + (size_t)plane * hw);
+  const f32x4* o4 = reinterpret_cast<const f32x4*>(go + (size_t)plane * hw);
+  f32x4* r4 = reinterpret_cast<f32x4*>(g2 + (size_t)plane * hw);
+  int lo, hi;
+  chunk_range4(hw, &lo, &hi);
+  float s1 = 0.f, s2 = 0.f, sa = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
+    f32x4 p = b4[i], q = v4[i], s = y4[i], o = __builtin_nontemporal_load(o4 + i), r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = sigmoidf_(fmaf(sc, s[j], sh));
+      const float v = o[j] * (a * p[j] - na * q[j]) * g * (1.0f - g);
+      r[j] = v;
+      s1 += v;
+      s2 = fmaf(v, s[j] - mu, s2);
+      sa = fmaf(o[j], g * p[j] - (1.0f - g) * q[j], sa);
+    }
+    r4[i] = r;
+  }
+  s1 = block_sum(s1, sm);
+  s2 = block_sum(s2, sm);
+  sa = block_sum(sa, sm);
+  if (threadIdx.x == 0) {
+    const size_t q = (size_t)(b * kPlaneChunks + blockIdx.x);
+    part[(q * 2) * c + ch] = s1;
+    part[(q * 2 + 1) * c + ch] = s2;
+    da_p1[q * c + ch] = sa;
+  }
+}
+
+// the du-part of dL/da: sum du*(xb - xv).   da_p2: [(b*chunks+chunk)][c]
+__global__ __launch_bounds__(kEwBlock) void blend1_da_kernel(const float* __restrict__ x, const float* __restrict__ du,
+                                                             float* __restrict__ da_p2, int c, int hw) {
+  __shared__ float sm[kEwBlock / DHD_WAVE];
+  const int plane = blockIdx.y, b = plane / c, ch = plane % c;
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + ch) * hw);
+  const f32x4* v4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + c + ch) * hw);
+  const f32x4* d4 = reinterpret_cast<const f32x4*>(du + (size_t)plane * hw);
+  int lo, hi;
+  chunk_range4(hw, &lo, &hi);
+  float acc = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
+    f32x4 p = __builtin_nontemporal_load(b4 + i), q = __builtin_nontemporal_load(v4 + i), d = d4[i];
+    acc += (d.x * (p.x - q.x) + d.y * (p.y - q.y)) + (d.z * (p.z - q.z) + d.w * (p.w - q.w));
+  }
+  acc = block_sum(acc, sm);
+  if (threadIdx.x == 0) da_p2[(size_t)(b * kPlaneChunks + blockIdx.x) * c + ch] = acc;
+}
+
+// gx_bev = a*(go*g + du) + ds_bev/hw;  gx_vox = (1-a)*(go*(1-g) + du) + ds_vox/hw
+__global__ __launch_bounds__(kEwBlock) void stage_gx_kernel(const float* __restrict__ a1, const float* __restrict__ y2,
+                                                            const float* __restrict__ scsh, const float* __restrict__ go,
+                                                            const float* __restrict__ du, const float* __restrict__ ds,
+                                                            float* __restrict__ gx, int c, int hw) {
+  const int plane = blockIdx.y, b = plane / c, ch = plane % c;
+  const float a = a1[plane], na = 1.0f - a, sc = scsh[ch], sh = scsh[c + ch];
+  const float kb = ds[(size_t)b * 2 * c + ch] / (float)hw, kv = ds[(size_t)b * 2 * c + c + ch] / (float)hw;
+  const f32x4* y4 = reinterpret_cast<const f32x4*>(y2 + (size_t)plane * hw);
+  const f32x4* o4 = reinterpret_cast<const f32x4*>(go + (size_t)plane * hw);
+  const f32x4* d4 = reinterpret_cast<const f32x4*>(du + (size_t)plane * hw);
+  f32x4* gb4 = reinterpret_cast<f32x4*>(gx + ((size_t)b * 2 * c + ch) * hw);
+  f32x4* gv4 = reinterpret_cast<f32x4*>(gx + ((size_t)b * 2 * c + c + ch) * hw);
+  int lo, hi;
+  chunk_range4(hw, &lo, &hi);
+  for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
+    f32x4 s = __builtin_nontemporal_load(y4 + i), o = __builtin_nontemporal_load(o4 + i), d = __builtin_nontemporal_load(d4 + i), rb, rv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = sigmoidf_(fmaf(sc, s[j], sh));
+      rb[j] = fmaf(a, fmaf(o[j], g, d[j]), kb);
+      rv[j] = fmaf(na, fmaf(o[j], 1.0f - g, d[j]), kv);
+    }
+    __builtin_nontemporal_store(rb, gb4 + i);
+    __builtin_nontemporal_store(rv, gv4 + i);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolution on the f32 MFMA
+// ------------------------------------------------------------------------------------------------
+
+// Weight (rows x k, row-major; or its transpose) -> LDS images for the MFMA A operand, one image
+// per 16 input channels:
+//   packed[((((rb*KC + kc)*COT + t)*2 + s4)*64 + lane)*4 + s] = M[rb*32*COT + 32 t + (lane&31)][16 kc + 8 s4 + 2 s + (lane>>5)]
+// so that a wave reading (t, s4) with one ds_read_b128 per lane gets the A fragments of four
+// consecutive 32x32x2 MFMAs.  M = W (forward, rows = output channels) or W^T (dgrad).
+__global__ __launch_bounds__(kEwBlock) void pack_weight_kernel(const float* __restrict__ w, int transpose, float* __restrict__ packed,
+                                                               int c, int cot) {
+  const int idx = blockIdx.x * kEwBlock + threadIdx.x;
+  if (idx >= c * c) return;
+  const int kcn = c / kPwStep;
+  int q = idx;
+  const int s = q & 3; q >>= 2;
+  const int lane = q & 63; q >>= 6;
+  const int s4 = q & 1; q >>= 1;
+  const int t = q % cot; q /= cot;
+  const int kc = q % kcn;
+  const int rb = q / kcn;
+  const int row = rb * 32 * cot + 32 * t + (lane & 31);
+  const int k = kPwStep * kc + 8 * s4 + 2 * s + (lane >> 5);
+  packed[idx] = transpose ? w[(size_t)k * c + row] : w[(size_t)row * c + k];
+}
+
+// y[b, co, p] = sum_ci W[co, ci] * act(c0[b,ci]*in0[b,ci,p] + c1[b,ci]*in1[b,ci,p] + c2[b,ci])  (+ epilogue)
+// EPI: 0 = + bias, 1 = ReLU mask from aux (keep where aux_sc*aux + aux_sh > 0), 2 = plain.
+// A wave owns 32 pixels x 32*COT output channels; a step is 16 input channels = 8 k-pairs:
+// 8 dword loads per input (issued one step ahead), 2*COT ds_read_b128, 8*COT MFMAs.  Two blocks per
+// CU (<= 256 registers) so that one block's prologue / epilogue / barrier waits run under the other
+// block's MFMAs.
+template <int COT, bool TWO_IN, bool RELU, int EPI>
+__global__ __launch_bounds__(kPwBlock, 2) void pw_gemm_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                              size_t in_bstride, const float* __restrict__ coef,
+                                                              const float* __restrict__ wp, const float* __restrict__ bias,
+                                                              const float* __restrict__ aux, const float* __restrict__ aux_scsh,
+                                                              float* __restrict__ y, int c, int hw) {
+  constexpr int kImg = COT * 2 * 64 * 4;  // floats per weight image (16 k x 32*COT rows)
+  constexpr int kWst = COT / 2;           // float4 per thread per image
+  constexpr int K2 = kPwStep / 2;         // k-pairs per step
+  extern __shared__ float lds[];          // 2 images | coefficient table (3c)
+  float* cf = lds + 2 * kImg;
+  const int b = blockIdx.y, rb = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int p = (blockIdx.x * (kPwBlock / DHD_WAVE) + wv) * 32 + r;
+  const bool live = p < hw;
+  const int pc = live ? p : hw - 1;
+  const int kcn = c / kPwStep;
+
+  for (int i = tid; i < 3 * c; i += kPwBlock) cf[i] = coef[(size_t)b * 3 * c + i];
+
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp) + (size_t)rb * kcn * (kImg / 4);
+  f32x4 wst[kWst];
+#pragma unroll
+  for (int j = 0; j < kWst; ++j) wst[j] = wp4[j * kPwBlock + tid];
+#pragma unroll
+  for (int j = 0; j < kWst; ++j) reinterpret_cast<f32x4*>(lds)[j * kPwBlock + tid] = wst[j];
+
+  const float* i0 = in0 + (size_t)b * in_bstride + pc + (size_t)h * hw;
+  const float* i1 = TWO_IN ? in1 + (size_t)b * in_bstride + pc + (size_t)h * hw : nullptr;
+  const size_t hw2 = (size_t)2 * hw;
+  float raw0[K2], raw1[K2];
+#pragma unroll
+  for (int s = 0; s < K2; ++s) {
+    raw0[s] = i0[s * hw2];
+    if (TWO_IN) raw1[s] = i1[s * hw2];
+  }
+  __syncthreads();
+
+  f32x16 acc[COT];
+#pragma unroll
+  for (int t = 0; t < COT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  for (int kc = 0; kc < kcn; ++kc) {
+    float bv[K2];
+#pragma unroll
+    for (int s = 0; s < K2; ++s) {
+      const int ci = kPwStep * kc + 2 * s + h;
+      float v = fmaf(cf[ci], raw0[s], cf[2 * c + ci]);
+      if (TWO_IN) v = fmaf(cf[c + ci], raw1[s], v);
+      bv[s] = RELU ? fmaxf(v, 0.f) : v;
+    }
+    const bool more = kc + 1 < kcn;
+    if (more) {
+      i0 += (size_t)kPwStep * hw;
+      if (TWO_IN) i1 += (size_t)kPwStep * hw;
+#pragma unroll
+      for (int s = 0; s < K2; ++s) {
+        raw0[s] = i0[s * hw2];
+        if (TWO_IN) raw1[s] = i1[s * hw2];
+      }
+#pragma unroll
+      for (int j = 0; j < kWst; ++j) wst[j] = wp4[(size_t)(kc + 1) * (kImg / 4) + j * kPwBlock + tid];
+    }
+    const f32x4* img = reinterpret_cast<const f32x4*>(lds + (kc & 1) * kImg);
+#pragma unroll
+    for (int s4 = 0; s4 < 2; ++s4) {
+#pragma unroll
+      for (int t = 0; t < COT; ++t) {
+        const f32x4 a4 = img[(t * 2 + s4) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], bv[4 * s4 + s], acc[t], 0, 0, 0);
+      }
+    }
+    if (more) {
+      f32x4* dst = reinterpret_cast<f32x4*>(lds + ((kc + 1) & 1) * kImg);
+#pragma unroll
+      for (int j = 0; j < kWst; ++j) dst[j * kPwBlock + tid] = wst[j];
+    }
+    __syncthreads();
+  }
+
+  if (!live) return;
+  const int co0 = rb * 32 * COT + 4 * h;
+  float* yo = y + (size_t)b * c * hw + p;
+  const float* ao = EPI == 1 ? aux + (size_t)b * c * hw + p : nullptr;
+#pragma unroll
+  for (int t = 0; t < COT; ++t) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = co0 + 32 * t + (e & 3) + 8 * (e >> 2);
+      float v = acc[t][e];
+      if (EPI == 0) v += bias[co];
+      if (EPI == 1) {
+        const float m = fmaf(aux_scsh[co], ao[(size_t)co * hw], aux_scsh[c + co]);
+        v = m > 0.f ? v : 0.f;
+      }
+      yo[(size_t)co * hw] = v;
+    }
+  }
+}
+
+// Weight gradient: G[co][ci] = sum_{b,p} A(co,p) * B(ci,p), A/B with the affine prologues above.
+// Block = 8 waves, output tile OT x OT (wave: OT/2 x OT/4), loops over 32-pixel chunks
+// worker, worker + n_workers, ...; per-worker partial matrices in `partial` [worker][c][c].
+template <int OT, bool A_TWO, bool B_TWO, bool B_RELU>
+__global__ __launch_bounds__(kWgBlock) void pw_wgrad_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
+                                                            const float* __restrict__ acoef, size_t a_bstride,
+                                                            const float* __restrict__ b0, const float* __restrict__ b1,
+                                                            const float* __restrict__ bcoef, size_t b_bstride,
+                                                            float* __restrict__ partial, int c, int hw, int nb, int n_workers) {
+  constexpr int S = kWgStride;
+  constexpr int kTile = OT * S;       // floats per staged operand tile
+  constexpr int RPT = OT / 64;        // rows per thread per operand
+  constexpr int TA = OT / 64, TB = OT / 128;
+  extern __shared__ float lds[];      // [buf 2][operand 2][OT][S]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nob = c / OT;
+  const int ob_co = (blockIdx.y / nob) * OT, ob_ci = (blockIdx.y % nob) * OT;
+  const int wco = (wv >> 2) * (OT / 2), wci = (wv & 3) * (OT / 4);
+  const int cps = (hw + 31) >> 5;     // chunks per sample
+  const int n_chunks = nb * cps;
+  const int srow = tid >> 3, sq = tid & 7;  // staging: row srow + 64 j, float4 column sq
+
+  f32x16 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  f32x4 ra0[RPT], ra1[RPT], rb0[RPT], rb1[RPT];
+  auto fetch = [&](int chunk) {
+    const int b = chunk / cps, p = (chunk % cps) * 32 + 4 * sq;
+    const bool in = p < hw;
+    const size_t off = (size_t)(in ? p : 0);
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const size_t ra = (size_t)b * a_bstride + (size_t)(ob_co + srow + 64 * j) * hw + off;
+      const size_t rbo = (size_t)b * b_bstride + (size_t)(ob_ci + srow + 64 * j) * hw + off;
+      ra0[j] = *reinterpret_cast<const f32x4*>(a0 + ra);
+      if (A_TWO) ra1[j] = *reinterpret_cast<const f32x4*>(a1 + ra);
+      rb0[j] = *reinterpret_cast<const f32x4*>(b0 + rbo);
+      if (B_TWO) rb1[j] = *reinterpret_cast<const f32x4*>(b1 + rbo);
+    }
+  };
+  auto stage = [&](int chunk, int buf) {
+    const int b = chunk / cps, p = (chunk % cps) * 32 + 4 * sq;
+    const bool in = p < hw;
+    float* ta = lds + (buf * 2) * kTile;
+    float* tb = ta + kTile;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int row = srow + 64 * j;
+      const float* ca = acoef + (size_t)b * 3 * c + ob_co + row;
+      const float* cb = bcoef + (size_t)b * 3 * c + ob_ci + row;
+      const float a_c0 = ca[0], a_c1 = ca[c], a_c2 = ca[2 * c];
+      const float b_c0 = cb[0], b_c1 = cb[c], b_c2 = cb[2 * c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float va = fmaf(a_c0, ra0[j][e], a_c2);
+        if (A_TWO) va = fmaf(a_c1, ra1[j][e], va);
+        float vb = fmaf(b_c0, rb0[j][e], b_c2);
+        if (B_TWO) vb = fmaf(b_c1, rb1[j][e], vb);
+        if (B_RELU) vb = fmaxf(vb, 0.f);
+        ta[row * S + 4 * sq + e] = in ? va : 0.f;
+        tb[row * S + 4 * sq + e] = in ? vb : 0.f;
+      }
+    }
+  };
+
+  int chunk = blockIdx.x;
+  int buf = 0;
+  if (chunk < n_chunks) {
+    fetch(chunk);
+    stage(chunk, 0);
+  }
+  __syncthreads();
+  for (; chunk < n_chunks; chunk += n_workers) {
+    const int next = chunk + n_workers;
+    if (next < n_chunks) fetch(next);
+    const float* ta = lds + (buf * 2) * kTile;
+    const float* tb = ta + kTile;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+      float fa[TA], fb[TB];
+#pragma unroll
+      for (int i = 0; i < TA; ++i) fa[i] = ta[(wco + 32 * i + r) * S + 2 * k2 + h];
+#pragma unroll
+      for (int j = 0; j < TB; ++j) fb[j] = tb[(wci + 32 * j + r) * S + 2 * k2 + h];
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (next < n_chunks) stage(next, buf ^ 1);
+    buf ^= 1;
+    __syncthreads();
+  }
+
+  float* po = partial + (size_t)blockIdx.x * c * c;
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = ob_co + wco + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int ci = ob_ci + wci + 32 * j + r;
+        po[(size_t)co * c + ci] = acc[i][j][e];
+      }
+}
+
+__global__ __launch_bounds__(kEwBlock) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int n,
+                                                                int n_workers) {
+  const int i = blockIdx.x * kEwBlock + threadIdx.x;
+  if (i >= n) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int w = 0;
+  for (; w + 3 < n_workers; w += 4) {
+    a0 += partial[(size_t)w * n + i];
+    a1 += partial[(size_t)(w + 1) * n + i];
+    a2 += partial[(size_t)(w + 2) * n + i];
+    a3 += partial[(size_t)(w + 3) * n + i];
+  }
+  for (; w < n_workers; ++w) a0 += partial[(size_t)w * n + i];
+  gw[i] = (a0 + a1) + (a2 + a3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+
+inline size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }  // in floats: 256-byte sections
+
+struct SavedLayout {
+  size_t s, h, a1, tab_a, mean1, rstd1, scsh1, tab1, mean2, rstd2, scsh2, y1, y2, total;
+};
+SavedLayout saved_layout(int b, int c, int hw, int r) {
+  SavedLayout L;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t at = o; o += align_up(n); return at; };
+  L.s = take((size_t)b * 2 * c);
+  L.h = take((size_t)b * r);
+  L.a1 = take((size_t)b * c);
+  L.tab_a = take((size_t)b * 3 * c);
+  L.mean1 = take(c); L.rstd1 = take(c); L.scsh1 = take(2 * c); L.tab1 = take((size_t)b * 3 * c);
+  L.mean2 = take(c); L.rstd2 = take(c); L.scsh2 = take(2 * c);
+  L.y1 = take((size_t)b * c * hw);
+  L.y2 = take((size_t)b * c * hw);
+  L.total = o;
+  return L;
+}
+
+struct ScratchLayout {
+  size_t wp1, wp2, wp1t, wp2t, part, da1, da2, tab_g2, tab_g1, dpre2, dh, ds, mean_part, g2, g1, du, wpart, total;
+};
+ScratchLayout scratch_layout(int b, int c, int hw, int r) {
+  ScratchLayout L;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t at = o; o += align_up(n); return at; };
+  const size_t cc = (size_t)c * c, plane = (size_t)b * c * hw;
+  L.wp1 = take(cc); L.wp2 = take(cc); L.wp1t = take(cc); L.wp2t = take(cc);
+  L.part = take((size_t)b * kPlaneChunks * 2 * c);
+  L.da1 = take((size_t)b * kPlaneChunks * c);
+  L.da2 = take((size_t)b * kPlaneChunks * c);
+  L.tab_g2 = take((size_t)b * 3 * c);
+  L.tab_g1 = take((size_t)b * 3 * c);
+  L.dpre2 = take((size_t)b * c);
+  L.dh = take((size_t)b * r);
+  L.ds = take((size_t)b * 2 * c);
+  L.mean_part = take((size_t)b * 2 * c * kPlaneChunks);
+  L.g2 = take(plane); L.g1 = take(plane); L.du = take(plane);
+  L.wpart = take((size_t)kWgWorkers * cc);
+  L.total = o;
+  return L;
+}
+
+inline bool stage_supported(int c, int hw) { return (c == 128 || (c > 0 && c % 256 == 0)) && hw > 0 && (hw & 3) == 0; }
+
+// in0/in1 prologue GEMM launcher.  mode: 0 forward (+bias), 1 dgrad with ReLU mask, 2 dgrad plain
+int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, const float* coef, bool relu, const float* wp,
+                   const float* bias, const float* aux, const float* aux_scsh, float* y, int epi, int b, int c, int hw,
+                   hipStream_t st) {
+  const int cot = c == 128 ? 4 : 8;
+  const dim3 grid(dhd_cdiv(hw, 32 * (kPwBlock / DHD_WAVE)), b, c / (32 * cot));
+  const size_t shmem = (size_t)(2 * cot * 512 + 3 * c) * sizeof(float);
+#define DHD_PW(COT, TWO, RELU, EPI)                                                                                   \
+  do {                                                                                                                \
+    auto kern = pw_gemm_kernel<COT, TWO, RELU, EPI>;                                                                  \
+    DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                (int)shmem));                                                                         \
+    hipLaunchKernelGGL(kern, grid, dim3(kPwBlock), shmem, st, in0, in1, in_bstride, coef, wp, bias, aux, aux_scsh, y, \
+                       c, hw);                                                                                        \
+  } while (0)
+#define DHD_PW_COT(TWO, RELU, EPI)          \
+  do {                                      \
+    if (cot == 4) DHD_PW(4, TWO, RELU, EPI); \
+    else DHD_PW(8, TWO, RELU, EPI);          \
+  } while (0)
+  const bool two = in1 != nullptr;
+  if (epi == 0 && two && !relu) DHD_PW_COT(true, false, 0);
+  else if (epi == 0 && !two && relu) DHD_PW_COT(false, true, 0);
+  else if (epi == 0 && !two && !relu) DHD_PW_COT(false, false, 0);
+  else if (epi == 1 && two && !relu) DHD_PW_COT(true, false, 1);
+  else if (epi == 2 && two && !relu) DHD_PW_COT(true, false, 2);
+  else return DHD_EUNSUPPORTED;
+#undef DHD_PW_COT
+#undef DHD_PW
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t a_bs, const float* b0, const float* b1,
+                    const float* bcoef, size_t b_bs, bool b_relu, float* partial, float* gw, int b, int c, int hw,
+                    hipStream_t st) {
+  const int ot = c == 128 ? 128 : 256;
+  const int nob = (c / ot) * (c / ot);
+  const int workers = kWgWorkers / nob > 0 ? kWgWorkers / nob : 1;
+  const dim3 grid(workers, nob);
+  const size_t shmem = (size_t)4 * ot * kWgStride * sizeof(float);
+#define DHD_WG(OT, ATWO, BTWO, BRELU)                                                                              \
+  do {                                                                                                             \
+    auto kern = pw_wgrad_kernel<OT, ATWO, BTWO, BRELU>;                                                            \
+    DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)shmem));                                                                      \
+    hipLaunchKernelGGL(kern, grid, dim3(kWgBlock), shmem, st, a0, a1, acoef, a_bs, b0, b1, bcoef, b_bs, partial, c, \
+                       hw, b, workers);                                                                            \
+  } while (0)
+  const bool btwo = b1 != nullptr;
+  if (a1 == nullptr) return DHD_EUNSUPPORTED;
+  if (ot == 128) {
+    if (btwo) DHD_WG(128, true, true, false);
+    else if (b_relu) DHD_WG(128, true, false, true);
+    else return DHD_EUNSUPPORTED;
+  } else {
+    if (btwo) DHD_WG(256, true, true, false);
+    else if (b_relu) DHD_WG(256, true, false, true);
+    else return DHD_EUNSUPPORTED;
+  }
+#undef DHD_WG
+  DHD_LAUNCH_CHECK();
+  const int n = c * c;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dhd_cdiv(n, kEwBlock)), dim3(kEwBlock), 0, st, partial, gw, n, workers);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dhd_sfa_stage_supported(int c, int hw) { return stage_supported(c, hw) ? 1 : 0; }
+
+size_t dhd_sfa_stage_saved_bytes(int b, int c, int hw, int hidden) {
+  if (b <= 0 || hidden <= 0 || !stage_supported(c, hw)) return 0;
+  return saved_layout(b, c, hw, hidden).total * sizeof(float);
+}
+
+size_t dhd_sfa_stage_scratch_bytes(int b, int c, int hw, int hidden) {
+  if (b <= 0 || hidden <= 0 || !stage_supported(c, hw)) return 0;
+  return scratch_layout(b, c, hw, hidden).total * sizeof(float);
+}
+
+int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, void* saved, void* scratch, int b, int c, int hw,
+                          void* stream) {
+  if (!x || !w || !out || !saved || !scratch || b <= 0) return DHD_EINVAL;
+  if (!stage_supported(c, hw) || w->hidden <= 0) return DHD_EUNSUPPORTED;
+  if (!w->fc1_w || !w->fc1_b || !w->fc2_w || !w->fc2_b || !w->conv1_w || !w->conv1_b || !w->bn1_w || !w->bn1_b || !w->conv2_w ||
+      !w->conv2_b || !w->bn2_w || !w->bn2_b)
+    return DHD_EINVAL;
+  if (!w->training && (!w->bn1_mean || !w->bn1_var || !w->bn2_mean || !w->bn2_var)) return DHD_EINVAL;
+  hipStream_t st = dhd_stream(stream);
+  const int r = w->hidden;
+  const SavedLayout S = saved_layout(b, c, hw, r);
+  const ScratchLayout T = scratch_layout(b, c, hw, r);
+  float* sv = static_cast<float*>(saved);
+  float* sc = static_cast<float*>(scratch);
+  const int cot = c == 128 ? 4 : 8;
+  const dim3 planes2(kPlaneChunks, b * 2 * c), planes(kPlaneChunks, b * c);
+  const dim3 per_ch(dhd_cdiv(c, kEwBlock));
+
+  hipLaunchKernelGGL(plane_mean_kernel, planes2, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw);
+  hipLaunchKernelGGL(fc_forward_kernel, dim3(b), dim3(kEwBlock), (size_t)(2 * c + r) * sizeof(float), st, sc + T.mean_part,
+                     w->fc1_w, w->fc1_b, w->fc2_w, w->fc2_b, sv + S.s, sv + S.h, sv + S.a1, sv + S.tab_a, c, r, hw);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(dhd_cdiv(c * c, kEwBlock)), dim3(kEwBlock), 0, st, w->conv1_w, 0, sc + T.wp1, c, cot);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(dhd_cdiv(c * c, kEwBlock)), dim3(kEwBlock), 0, st, w->conv2_w, 0, sc + T.wp2, c, cot);
+  DHD_LAUNCH_CHECK();
+
+  // y1 = conv1(blend1(x))
+  int rc = launch_pw_gemm(x, x + (size_t)c * hw, (size_t)2 * c * hw, sv + S.tab_a, false, sc + T.wp1, w->conv1_b, nullptr, nullptr,
+                          sv + S.y1, 0, b, c, hw, st);
+  if (rc != DHD_OK) return rc;
+  if (w->training) {
+    hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y1, sc + T.part, c, hw);
+    hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, sv + S.y1, w->bn1_w, w->bn1_b,
+                       w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1, sv + S.tab1, b, c, hw);
+  } else {
+    hipLaunchKernelGGL(bn_eval_coef_kernel, per_ch, dim3(kEwBlock), 0, st, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, w->eps1,
+                       sv + S.mean1, sv + S.rstd1, sv + S.scsh1, sv + S.tab1, b, c);
+  }
+  DHD_LAUNCH_CHECK();
+  // y2 = conv2(relu(bn1(y1)))
+  rc = launch_pw_gemm(sv + S.y1, nullptr, (size_t)c * hw, sv + S.tab1, true, sc + T.wp2, w->conv2_b, nullptr, nullptr, sv + S.y2, 0,
+                      b, c, hw, st);
+  if (rc != DHD_OK) return rc;
+  float* tab_unused = sc + T.tab_g2;  // bn2 has no consumer GEMM in forward; table slot reused as a sink
+  if (w->training) {
+    hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y2, sc + T.part, c, hw);
+    hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, sv + S.y2, w->bn2_w, w->bn2_b,
+                       w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, sv + S.mean2, sv + S.rstd2, sv + S.scsh2, tab_unused, b, c, hw);
+  } else {
+    hipLaunchKernelGGL(bn_eval_coef_kernel, per_ch, dim3(kEwBlock), 0, st, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, w->eps2,
+                       sv + S.mean2, sv + S.rstd2, sv + S.scsh2, tab_unused, b, c);
+  }
+  hipLaunchKernelGGL(blend2_bn_kernel, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, out, c, hw);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void* saved, const float* gout, float* gx,
+                           const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw, void* stream) {
+  if (!x || !w || !saved || !gout || !gx || !grads || !scratch || b <= 0) return DHD_EINVAL;
+  if (!stage_supported(c, hw) || w->hidden <= 0) return DHD_EUNSUPPORTED;
+  if (!grads->fc1_w || !grads->fc1_b || !grads->fc2_w || !grads->fc2_b || !grads->conv1_w || !grads->conv1_b || !grads->bn1_w ||
+      !grads->bn1_b || !grads->conv2_w || !grads->conv2_b || !grads->bn2_w || !grads->bn2_b)
+    return DHD_EINVAL;
+  hipStream_t st = dhd_stream(stream);
+  const int r = w->hidden;
+  const SavedLayout S = saved_layout(b, c, hw, r);
+  const ScratchLayout T = scratch_layout(b, c, hw, r);
+  const float* sv = static_cast<const float*>(saved);
+  float* sc = static_cast<float*>(scratch);
+  const int cot = c == 128 ? 4 : 8;
+  const dim3 planes(kPlaneChunks, b * c);
+  const dim3 per_ch(dhd_cdiv(c, kEwBlock));
+  const size_t cs = (size_t)c * hw;
+
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(dhd_cdiv(c * c, kEwBlock)), dim3(kEwBlock), 0, st, w->conv1_w, 1, sc + T.wp1t, c, cot);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(dhd_cdiv(c * c, kEwBlock)), dim3(kEwBlock), 0, st, w->conv2_w, 1, sc + T.wp2t, c, cot);
+  // g2 = dL/ds2, BatchNorm-2 sums, go-part of dL/da
+  hipLaunchKernelGGL(blend2_bn_bwd_kernel, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, sv + S.mean2, gout,
+                     sc + T.g2, sc + T.part, sc + T.da1, c, hw);
+  hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn2_w, sv + S.mean2, sv + S.rstd2,
+                     w->training, sc + T.tab_g2, grads->bn2_w, grads->bn2_b, grads->conv2_b, b, c, hw);
+  DHD_LAUNCH_CHECK();
+  // dW2 = dy2 . z1^T
+  int rc = launch_pw_wgrad(sc + T.g2, sv + S.y2, sc + T.tab_g2, cs, sv + S.y1, nullptr, sv + S.tab1, cs, true, sc + T.wpart,
+                           grads->conv2_w, b, c, hw, st);
+  if (rc != DHD_OK) return rc;
+  // g1 = (W2^T dy2) * [z1 > 0]
+  rc = launch_pw_gemm(sc + T.g2, sv + S.y2, cs, sc + T.tab_g2, false, sc + T.wp2t, nullptr, sv + S.y1, sv + S.scsh1, sc + T.g1, 1, b,
+                      c, hw, st);
+  if (rc != DHD_OK) return rc;
+  hipLaunchKernelGGL(pair_sums_kernel, planes, dim3(kEwBlock), 0, st, sc + T.g1, sv + S.y1, sv + S.mean1, sc + T.part, c, hw);
+  hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn1_w, sv + S.mean1, sv + S.rstd1,
+                     w->training, sc + T.tab_g1, grads->bn1_w, grads->bn1_b, grads->conv1_b, b, c, hw);
+  DHD_LAUNCH_CHECK();
+  // dW1 = dy1 . u^T
+  rc = launch_pw_wgrad(sc + T.g1, sv + S.y1, sc + T.tab_g1, cs, x, x + cs, sv + S.tab_a, 2 * cs, false, sc + T.wpart, grads->conv1_w,
+                       b, c, hw, st);
+  if (rc != DHD_OK) return rc;
+  // du = W1^T dy1
+  rc = launch_pw_gemm(sc + T.g1, sv + S.y1, cs, sc + T.tab_g1, false, sc + T.wp1t, nullptr, nullptr, nullptr, sc + T.du, 2, b, c, hw,
+                      st);
+  if (rc != DHD_OK) return rc;
+  hipLaunchKernelGGL(blend1_da_kernel, planes, dim3(kEwBlock), 0, st, x, sc + T.du, sc + T.da2, c, hw);
+  hipLaunchKernelGGL(fc_backward_kernel, dim3(b), dim3(kEwBlock), (size_t)(c + r) * sizeof(float), st, sc + T.da1, sc + T.da2,
+                     sv + S.a1, sv + S.h, w->fc1_w, w->fc2_w, sc + T.dpre2, sc + T.dh, sc + T.ds, c, r);
+  const int n_fc = r * 2 * c + c * r + r + c;
+  hipLaunchKernelGGL(fc_param_grad_kernel, dim3(dhd_cdiv(n_fc, kEwBlock)), dim3(kEwBlock), 0, st, sc + T.dpre2, sc + T.dh, sv + S.h,
+                     sv + S.s, grads->fc1_w, grads->fc1_b, grads->fc2_w, grads->fc2_b, b, c, r);
+  hipLaunchKernelGGL(stage_gx_kernel, planes, dim3(kEwBlock), 0, st, sv + S.a1, sv + S.y2, sv + S.scsh2, gout, sc + T.du, sc + T.ds, gx,
+                     c, hw);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+}  // extern "C"

@@ -9,6 +9,8 @@ fc and the two 1x1 conv + BatchNorm layers in between stay ordinary PyTorch modu
 library path); their parameter gradients are produced by replaying their own sub-graphs inside the
 node's backward.
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
@@ -86,6 +88,118 @@ class _AttentionStage(torch.autograd.Function):
         return (gx, None) + (None,) * len(ctx.needs_input_grad[2:])
 
 
+_scratch = {}  # (device, bytes) -> reusable scratch buffer of the fused stage (stream-ordered use)
+
+
+def _stage_scratch(dev, nbytes):
+    key = (dev.index, nbytes)
+    buf = _scratch.get(key)
+    if buf is None:
+        for k in [k for k in _scratch if k[0] == dev.index]:
+            del _scratch[k]
+        buf = _scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return buf
+
+
+def _bn_momentum(bn, training):
+    """Update factor nn.BatchNorm2d would use for this call (torch/nn/modules/batchnorm.py: forward)."""
+    if not (training and bn.track_running_stats):
+        return 0.0
+    bn.num_batches_tracked.add_(1)
+    if bn.momentum is None:
+        return 1.0 / float(bn.num_batches_tracked)
+    return float(bn.momentum)
+
+
+_STAGE_PARAMS = ('fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'conv1_w', 'conv1_b', 'bn1_w', 'bn1_b',
+                 'conv2_w', 'conv2_b', 'bn2_w', 'bn2_b')
+
+
+def _stage_params(stage):
+    sp = stage.spacial_leanring
+    return (stage.fc[0].weight, stage.fc[0].bias, stage.fc[2].weight, stage.fc[2].bias,
+            sp[0].weight, sp[0].bias, sp[1].weight, sp[1].bias, sp[3].weight, sp[3].bias, sp[4].weight, sp[4].bias)
+
+
+class _FusedStage(torch.autograd.Function):
+    """The whole stage in libdhd_amd.so (dhd_sfa_stage_forward/backward): the 1x1 convolutions on
+    the f32 MFMA with the blends, BatchNorm and ReLU fused into their operand paths."""
+
+    @staticmethod
+    def forward(ctx, x, stage, *params):
+        x = _lib.require_gpu_tensor(x.contiguous(), torch.float32, 'SFA input')
+        if x.data_ptr() % 16:
+            x = x.clone()
+        b, c2, h, w = x.shape
+        c, hw = c2 // 2, h * w
+        dev = x.device
+        lib = _lib.load()
+        bn1, bn2 = stage.spacial_leanring[1], stage.spacial_leanring[4]
+        ps = [_lib.require_gpu_tensor(p.detach().contiguous(), torch.float32, 'SFA ' + n) for n, p in zip(_STAGE_PARAMS, params)]
+        hidden = ps[0].shape[0]
+        wts = _lib.SfaWeights()
+        for n, p in zip(_STAGE_PARAMS, ps):
+            setattr(wts, n, p.data_ptr())
+        # batch statistics iff nn.BatchNorm2d would use them (train mode, or no running buffers)
+        training = int(bn1.training or bn1.running_mean is None)
+        if training != int(bn2.training or bn2.running_mean is None):
+            raise _lib.DhdError('SFA: the two BatchNorm layers of the stage must be in the same mode')
+        for tag, bn in (('bn1', bn1), ('bn2', bn2)):
+            track = bn.running_mean is not None
+            setattr(wts, tag + '_mean', bn.running_mean.data_ptr() if track else None)
+            setattr(wts, tag + '_var', bn.running_var.data_ptr() if track else None)
+        wts.hidden, wts.training = hidden, training
+        wts.eps1, wts.eps2 = bn1.eps, bn2.eps
+        wts.momentum1, wts.momentum2 = _bn_momentum(bn1, training), _bn_momentum(bn2, training)
+        if training and not bn1.training:
+            wts.bn1_mean = wts.bn1_var = wts.bn2_mean = wts.bn2_var = None
+        with torch.cuda.device(dev):
+            saved = torch.empty(lib.dhd_sfa_stage_saved_bytes(b, c, hw, hidden), dtype=torch.uint8, device=dev)
+            scratch = _stage_scratch(dev, lib.dhd_sfa_stage_scratch_bytes(b, c, hw, hidden))
+            out = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
+            _lib.check(lib.dhd_sfa_stage_forward(_lib.ptr(x), C.byref(wts), _lib.ptr(out), _lib.ptr(saved), _lib.ptr(scratch),
+                                                 b, c, hw, _lib.stream_ptr(dev)), 'dhd_sfa_stage_forward')
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, saved, *ps)
+            ctx.wts = wts
+            ctx.dims = (b, c, hw)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, saved = ctx.saved_tensors[:2]
+        ps = ctx.saved_tensors[2:]
+        b, c, hw = ctx.dims
+        dev = x.device
+        lib = _lib.load()
+        go = go.float().contiguous()
+        with torch.cuda.device(dev):
+            gx = torch.empty_like(x)
+            gps = [torch.empty_like(p) for p in ps]
+            grads = _lib.SfaGrads()
+            for n, g in zip(_STAGE_PARAMS, gps):
+                setattr(grads, n, g.data_ptr())
+            scratch = _stage_scratch(dev, lib.dhd_sfa_stage_scratch_bytes(b, c, hw, ctx.wts.hidden))
+            _lib.check(lib.dhd_sfa_stage_backward(_lib.ptr(x), C.byref(ctx.wts), _lib.ptr(saved), _lib.ptr(go), _lib.ptr(gx),
+                                                  C.byref(grads), _lib.ptr(scratch), b, c, hw, _lib.stream_ptr(dev)),
+                       'dhd_sfa_stage_backward')
+        need = ctx.needs_input_grad
+        return (gx if need[0] else None, None) + tuple(g if n else None for g, n in zip(gps, need[2:]))
+
+
+def fused_stage_supported(stage, x):
+    """True when libdhd_amd.so runs the whole stage itself (float32 parameters, C == 128 or C % 256 == 0)."""
+    if not x.is_cuda or x.dim() != 4:
+        return False
+    params = _stage_params(stage)
+    if any(p is None or p.dtype != torch.float32 for p in params):
+        return False
+    sp = stage.spacial_leanring
+    if sp[0].weight.shape != (stage.channels, stage.channels, 1, 1) or sp[1].weight is None or sp[4].weight is None:
+        return False
+    return bool(_lib.load().dhd_sfa_stage_supported(stage.channels, x.shape[2] * x.shape[3]))
+
+
 class channel_spatial_stage(nn.Module):
     def __init__(self, features):
         """features: channels of cat[x_bev, x_voxel] (mix.py:9-35)."""
@@ -101,7 +215,11 @@ class channel_spatial_stage(nn.Module):
             nn.BatchNorm2d(self.channels))
         self.sigmoid = nn.Sigmoid()
 
+    fused = True  # set False to force the generic path (library convolutions between the blend kernels)
+
     def forward(self, x):
+        if self.fused and fused_stage_supported(self, x):
+            return _FusedStage.apply(x.float(), self, *_stage_params(self))
         params = list(self.fc.parameters()) + list(self.spacial_leanring.parameters())
         return _AttentionStage.apply(x.float(), self, *params)
 

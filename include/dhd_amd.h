@@ -223,6 +223,59 @@ int dhd_sfa_blend1_backward(const float* x, const float* a1, const float* gu, fl
 /* gx[b,ch,:] += gs[b,ch] / hw   (backward of the channel mean). */
 int dhd_sfa_mean_backward(const float* gs, float* gx, int b, int c2, int hw, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * 4. The whole SFA attention stage as one operator (models/necks/mix.py:8-59,
+ *    channel_spatial_stage): channel mean -> fc -> blend1 -> conv1x1 -> BatchNorm -> ReLU ->
+ *    conv1x1 -> BatchNorm -> sigmoid -> blend2, forward and backward, float32.  The two 1x1
+ *    convolutions run on the f32 MFMA with the blends / BatchNorm / ReLU fused into their operand
+ *    paths (csrc/sfa_stage.hip); only conv outputs y1, y2 are kept for backward.
+ *    Supported: C == 128 or C % 256 == 0, hw % 4 == 0 (dhd_sfa_stage_supported); other shapes
+ *    return DHD_EUNSUPPORTED and callers use the section-3 kernels around library convolutions.
+ * ------------------------------------------------------------------------------------ */
+
+typedef struct dhd_sfa_weights { /* [dev] float32 */
+  const float* fc1_w;   /* (hidden, 2C)  channel_spatial_stage.fc[0]  (mix.py:14-19) */
+  const float* fc1_b;   /* (hidden) */
+  const float* fc2_w;   /* (C, hidden)   fc[2] */
+  const float* fc2_b;   /* (C) */
+  const float* conv1_w; /* (C, C)        spacial_leanring[0]  (mix.py:21-33) */
+  const float* conv1_b; /* (C) */
+  const float* bn1_w;   /* (C)           spacial_leanring[1] */
+  const float* bn1_b;
+  float* bn1_mean;      /* running statistics; updated in place when training, may be NULL then */
+  float* bn1_var;
+  const float* conv2_w; /* spacial_leanring[3] */
+  const float* conv2_b;
+  const float* bn2_w;   /* spacial_leanring[4] */
+  const float* bn2_b;
+  float* bn2_mean;
+  float* bn2_var;
+  int32_t hidden;       /* 2C / 16 in the reference */
+  int32_t training;     /* 1: batch statistics (nn.Module.train()), 0: running statistics */
+  float eps1, eps2;
+  float momentum1, momentum2; /* update factor of the running statistics */
+} dhd_sfa_weights;
+
+typedef struct dhd_sfa_grads { /* [dev] float32 outputs, shapes as in dhd_sfa_weights, overwritten */
+  float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  float *conv1_w, *conv1_b, *bn1_w, *bn1_b;
+  float *conv2_w, *conv2_b, *bn2_w, *bn2_b;
+} dhd_sfa_grads;
+
+int dhd_sfa_stage_supported(int c, int hw);
+/* `saved` carries forward state to backward (a1, BatchNorm batch statistics, y1, y2);
+ * `scratch` is reusable between calls on one stream.  0 if the shape is unsupported. */
+size_t dhd_sfa_stage_saved_bytes(int b, int c, int hw, int hidden);
+size_t dhd_sfa_stage_scratch_bytes(int b, int c, int hw, int hidden);
+
+/* x (B,2C,H,W) -> out (B,C,H,W) = x_fuse of mix.py:58. */
+int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, void* saved,
+                          void* scratch, int b, int c, int hw, void* stream);
+/* gout (B,C,H,W) -> gx (B,2C,H,W) and every parameter gradient. */
+int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void* saved,
+                           const float* gout, float* gx, const dhd_sfa_grads* grads, void* scratch,
+                           int b, int c, int hw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
