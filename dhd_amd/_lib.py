@@ -85,6 +85,7 @@ _PROTOTYPES = {
     'dhd_sfa_blend1_backward': ([_P] * 5 + [_I, _I, _I, _P], _I),
     'dhd_sfa_mean_backward': ([_P, _P, _I, _I, _I, _P], _I),
     'dhd_sfa_stage_supported': ([_I, _I], _I),
+    'dhd_sfa_set_gemm_mode': ([_I], _I),
     'dhd_sfa_stage_saved_bytes': ([_I, _I, _I, _I], C.c_size_t),
     'dhd_sfa_stage_scratch_bytes': ([_I, _I, _I, _I], C.c_size_t),
     'dhd_sfa_stage_forward': ([_P, C.POINTER(SfaWeights), _P, _P, _P, _I, _I, _I, _P], _I),

@@ -21,6 +21,8 @@
 //   * BatchNorm statistics / gradient sums are per-plane streaming reductions with double-precision
 //     finalisation; the blends are fused with the BatchNorm affine and the sigmoid.
 // Forward reads x three times and y1/y2 twice; nothing is transposed, there is no NHWC detour.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -31,6 +33,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kEwBlock = 256;     // element-wise / reduction kernels
 constexpr int kPlaneChunks = 4;   // blocks per (b, c) plane
 constexpr int kPwBlock = 256;     // pw_gemm: 4 waves
+#ifndef DHD_PW_COT_SEL
+#define DHD_PW_COT_SEL 8
+#endif
 constexpr int kPwStep = 16;       // input channels per weight image / pipeline step
 constexpr int kWgBlock = 512;     // pw_wgrad: 8 waves
 constexpr int kWgStride = 33;     // LDS row stride of a 32-pixel operand row (conflict-free column reads)
@@ -503,10 +508,15 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm_kernel(const float* __res
   constexpr int K2 = kPwStep / 2;         // k-pairs per step
   extern __shared__ float lds[];          // 2 images | coefficient table (3c)
   float* cf = lds + 2 * kImg;
-  const int b = blockIdx.y, rb = blockIdx.z;
+  // blockIdx.x = (tile group of 8, row block, tile in group): the c/(32 COT) blocks that read the same
+  // pixels are 8 apart in dispatch order, i.e. on the same XCD (shared L2) and close in time
+  const int nrb = c / (32 * COT);
+  const int b = blockIdx.y, rb = (blockIdx.x >> 3) % nrb;
+  const int tile = (blockIdx.x / (8 * nrb)) * 8 + (blockIdx.x & 7);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int p = (blockIdx.x * (kPwBlock / DHD_WAVE) + wv) * 32 + r;
+  if (tile * (kPwBlock / DHD_WAVE) * 32 >= hw) return;  // padding tile of the last group (block-uniform)
+  const int p = (tile * (kPwBlock / DHD_WAVE) + wv) * 32 + r;
   const bool live = p < hw;
   const int pc = live ? p : hw - 1;
   const int kcn = c / kPwStep;
@@ -592,6 +602,236 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm_kernel(const float* __res
         v = m > 0.f ? v : 0.f;
       }
       yo[(size_t)co * hw] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same GEMMs on the bf16 MFMA with a three-way split of every float32 operand ("bf16x6").
+//
+// A float32 x is cut by truncation into x = h + m + l, each part carrying 8 significand bits, i.e.
+// each exactly a bfloat16 (h = x & 0xffff0000, m = (x - h) & 0xffff0000, l = x - h - m; the
+// subtractions are exact).  Then a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm) + O(2^-25 |ab|):
+// six bf16 products, each exact in float32, accumulated in float32 by v_mfma_f32_32x32x16_bf16.  That is
+// float32-level accuracy (the dropped terms are below half an ulp of the product) at 6/16 of the
+// f32-MFMA cost, which moves these K = C = 256 GEMMs from MFMA-bound to HBM-bound.
+// NaN/Inf inputs propagate as NaN (Inf - Inf in the split) rather than Inf.
+// ------------------------------------------------------------------------------------------------
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+// two floats -> packed bf16 pairs (a in the low half = lower k) of the three terms
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned ha = __float_as_uint(a) & 0xffff0000u, hb = __float_as_uint(b) & 0xffff0000u;
+  const float ra = a - __uint_as_float(ha), rb = b - __uint_as_float(hb);
+  const unsigned ma = __float_as_uint(ra) & 0xffff0000u, mb = __float_as_uint(rb) & 0xffff0000u;
+  const float la = ra - __uint_as_float(ma), lb = rb - __uint_as_float(mb);
+  h = (ha >> 16) | hb;
+  m = (ma >> 16) | mb;
+  l = (__float_as_uint(la) >> 16) | (__float_as_uint(lb) & 0xffff0000u);
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// Weight (rows x k; or its transpose) -> LDS images of the MFMA B operand, one image per 16 input
+// channels, three bf16 terms:  packed16[(((rb*KC + kc)*COT + t)*3 + term)*64 + lane] (16-byte units) holds
+//   term(M[rb*32*COT + 32 t + (lane&31)][16 kc + 8 (lane>>5) + j]),  j = 0..7
+__global__ __launch_bounds__(kEwBlock) void pack_weight6_kernel(const float* __restrict__ w, int transpose, u32x4* __restrict__ packed,
+                                                                int c, int cot) {
+  const int idx = blockIdx.x * kEwBlock + threadIdx.x;  // (rb, kc, t, lane)
+  const int kcn = c / 16;
+  if (idx >= (c / 32) * kcn * 64) return;
+  int q = idx;
+  const int lane = q & 63; q >>= 6;
+  const int t = q % cot; q /= cot;
+  const int kc = q % kcn;
+  const int rb = q / kcn;
+  const int row = rb * 32 * cot + 32 * t + (lane & 31);
+  const int k0 = 16 * kc + 8 * (lane >> 5);
+  u32x4 h, m, l;
+#pragma unroll
+  for (int jp = 0; jp < 4; ++jp) {
+    const int k = k0 + 2 * jp;
+    const float a = transpose ? w[(size_t)k * c + row] : w[(size_t)row * c + k];
+    const float b = transpose ? w[(size_t)(k + 1) * c + row] : w[(size_t)row * c + k + 1];
+    unsigned hh, mm, ll;
+    split2(a, b, hh, mm, ll);
+    h[jp] = hh; m[jp] = mm; l[jp] = ll;
+  }
+  u32x4* dst = packed + ((size_t)((rb * kcn + kc) * cot + t) * 3) * 64 + lane;
+  dst[0] = h;
+  dst[64] = m;
+  dst[128] = l;
+}
+
+// y[b, co, p] = sum_ci W[co, ci] * act(c0[b,ci]*in0[b,ci,p] + c1[b,ci]*in1[b,ci,p] + c2[b,ci])  (+ epilogue),
+// EPI as in pw_gemm_kernel.  MFMA orientation D[pixel][channel]: the activation is the A operand (lane =
+// pixel, 8 consecutive channels per half-wave, loaded as 8 dwords from NCHW rows: two 128-byte segments
+// per load) and the weights the B operand, so a lane ends up with 4 consecutive pixels of one output
+// channel per accumulator quad -> 16-byte stores along the pixel axis.
+template <int COT, bool TWO_IN, bool RELU, int EPI>
+__global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                               size_t in_bstride, unsigned in_bytes, const float* __restrict__ coef,
+                                                               const u32x4* __restrict__ wp, const float* __restrict__ bias,
+                                                               unsigned* __restrict__ relu_mask, float* __restrict__ y, int c, int hw) {
+  constexpr int kImg = COT * 3 * 64;  // 16-byte units per weight image
+  constexpr int kWst = kImg / kPwBlock;
+  static_assert(kImg % kPwBlock == 0, "image must split evenly over the block");
+  extern __shared__ u32x4 lds6[];     // 2 images | coefficient table (3c floats)
+  float* cf = reinterpret_cast<float*>(lds6 + 2 * kImg);
+  const int nrb = c / (32 * COT);
+  const int b = blockIdx.y, rb = (blockIdx.x >> 3) % nrb;
+  const int tile = (blockIdx.x / (8 * nrb)) * 8 + (blockIdx.x & 7);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  if (tile * (kPwBlock / DHD_WAVE) * 32 >= hw) return;  // padding tile of the last group (block-uniform)
+  const int wt = tile * (kPwBlock / DHD_WAVE) + wv;     // 32-pixel wave tile
+  const int nwt = (hw + 31) >> 5;
+  const int p0 = wt * 32;
+  const int pc = min(p0 + r, hw - 1);
+  const int kcn = c / 16;
+
+  for (int i = tid; i < 3 * c; i += kPwBlock) cf[i] = coef[(size_t)b * 3 * c + i];
+
+  const u32x4* wsrc = wp + (size_t)rb * kcn * kImg;
+  u32x4 wst[kWst];
+#pragma unroll
+  for (int j = 0; j < kWst; ++j) wst[j] = wsrc[j * kPwBlock + tid];
+#pragma unroll
+  for (int j = 0; j < kWst; ++j) lds6[j * kPwBlock + tid] = wst[j];
+
+  // activation rows through buffer loads: per-lane byte offset (pixel, half-wave's first channel) in a
+  // VGPR, the channel row offset in an SGPR.  Loads run TWO steps ahead of their use (three register
+  // sets): at ~2 us of loaded HBM latency one step of lookahead keeps only ~2 TB/s in flight.
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in0 + (size_t)b * in_bstride), 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((TWO_IN ? in1 : in0) + (size_t)b * in_bstride), 0, in_bytes, 0x00020000);
+  const int voff = (pc + 8 * h * hw) * 4;
+  const int row_bytes = hw * 4;
+  float raw0[3][8], raw1[3][8];
+  auto issue = [&](auto set, int kc) {
+    constexpr int S = decltype(set)::value;
+    const int so = 16 * kc * row_bytes;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      raw0[S][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, voff, so + j * row_bytes, 0));
+      if (TWO_IN) raw1[S][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, voff, so + j * row_bytes, 0));
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  issue(I0{}, 0);
+  if (kcn > 1) issue(I1{}, 1);
+  __syncthreads();
+
+  f32x16 acc[COT];
+#pragma unroll
+  for (int t = 0; t < COT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  auto step = [&](auto cset, auto lset, int kc) {
+    constexpr int CS = decltype(cset)::value;
+    u32x4 ah, am, al;
+    {
+      const int ci = 16 * kc + 8 * h;
+      const f32x4* c0 = reinterpret_cast<const f32x4*>(cf + ci);
+      const f32x4* c1 = reinterpret_cast<const f32x4*>(cf + c + ci);
+      const f32x4* c2 = reinterpret_cast<const f32x4*>(cf + 2 * c + ci);
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 k0 = c0[q], k2 = c2[q];
+        f32x4 k1;
+        if (TWO_IN) k1 = c1[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = fmaf(k0[e], raw0[CS][4 * q + e], k2[e]);
+          if (TWO_IN) t = fmaf(k1[e], raw1[CS][4 * q + e], t);
+          v[4 * q + e] = RELU ? fmaxf(t, 0.f) : t;
+        }
+      }
+      if (RELU && relu_mask != nullptr && rb == 0 && wt < nwt) {  // wave-uniform
+        // bit p of word (channel, wave tile) = this pixel's activation passed the ReLU; a ballot gives
+        // the words of channels 16kc + j (low half-wave) and 16kc + 8 + j (high half-wave)
+        unsigned word = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned long long bal = __ballot(v[j] > 0.f);
+          if (lane == j) word = (unsigned)bal;
+          if (lane == 8 + j) word = (unsigned)(bal >> 32);
+        }
+        if (lane < 16) relu_mask[((size_t)b * c + 16 * kc + lane) * nwt + wt] = word;
+      }
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        unsigned hh, mm, ll;
+        split2(v[2 * jp], v[2 * jp + 1], hh, mm, ll);
+        ah[jp] = hh; am[jp] = mm; al[jp] = ll;
+      }
+    }
+    const bool more = kc + 1 < kcn;
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < kWst; ++j) wst[j] = wsrc[(size_t)(kc + 1) * kImg + j * kPwBlock + tid];
+    }
+    if (kc + 2 < kcn) issue(lset, kc + 2);
+    const u32x4* img = lds6 + (kc & 1) * kImg + lane;
+#pragma unroll
+    for (int t = 0; t < COT; t += 2) {
+      const u32x4 bh0 = img[(t * 3 + 0) * 64], bm0 = img[(t * 3 + 1) * 64], bl0 = img[(t * 3 + 2) * 64];
+      const u32x4 bh1 = img[(t * 3 + 3) * 64], bm1 = img[(t * 3 + 4) * 64], bl1 = img[(t * 3 + 5) * 64];
+      // smallest terms first; two accumulators alternate so that no MFMA waits on its predecessor
+      acc[t] = mfma_bf16(al, bh0, acc[t]);
+      acc[t + 1] = mfma_bf16(al, bh1, acc[t + 1]);
+      acc[t] = mfma_bf16(ah, bl0, acc[t]);
+      acc[t + 1] = mfma_bf16(ah, bl1, acc[t + 1]);
+      acc[t] = mfma_bf16(am, bm0, acc[t]);
+      acc[t + 1] = mfma_bf16(am, bm1, acc[t + 1]);
+      acc[t] = mfma_bf16(am, bh0, acc[t]);
+      acc[t + 1] = mfma_bf16(am, bh1, acc[t + 1]);
+      acc[t] = mfma_bf16(ah, bm0, acc[t]);
+      acc[t + 1] = mfma_bf16(ah, bm1, acc[t + 1]);
+      acc[t] = mfma_bf16(ah, bh0, acc[t]);
+      acc[t + 1] = mfma_bf16(ah, bh1, acc[t + 1]);
+    }
+    if (more) {
+      u32x4* dst = lds6 + ((kc + 1) & 1) * kImg;
+#pragma unroll
+      for (int j = 0; j < kWst; ++j) dst[j * kPwBlock + tid] = wst[j];
+    }
+    __syncthreads();
+  };
+  for (int kc = 0; kc < kcn; kc += 3) {
+    step(I0{}, I2{}, kc);
+    if (kc + 1 < kcn) step(I1{}, I0{}, kc + 1);
+    if (kc + 2 < kcn) step(I2{}, I1{}, kc + 2);
+  }
+
+  // acc[t][4q + e] = pixel p0 + 8q + 4h + e, channel rb*32*COT + 32t + r
+  const int co0 = rb * 32 * COT + r;
+#pragma unroll
+  for (int t = 0; t < COT; ++t) {
+    const int co = co0 + 32 * t;
+    const size_t row = ((size_t)b * c + co) * hw;
+    float bs = 0.f;
+    unsigned word = 0;
+    if (EPI == 0) bs = bias[co];
+    if (EPI == 1 && wt < nwt) word = relu_mask[((size_t)b * c + co) * nwt + wt] >> (4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = p0 + 8 * q + 4 * h;
+      if (p >= hw) continue;
+      f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+      if (EPI == 0) { v.x += bs; v.y += bs; v.z += bs; v.w += bs; }
+      if (EPI == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((word >> (8 * q + e)) & 1u) ? v[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(y + row + p) = v;
     }
   }
 }
@@ -732,7 +972,7 @@ __global__ __launch_bounds__(kEwBlock) void wgrad_reduce_kernel(const float* __r
 inline size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }  // in floats: 256-byte sections
 
 struct SavedLayout {
-  size_t s, h, a1, tab_a, mean1, rstd1, scsh1, tab1, mean2, rstd2, scsh2, y1, y2, total;
+  size_t s, h, a1, tab_a, mean1, rstd1, scsh1, tab1, mean2, rstd2, scsh2, mask, y1, y2, total;
 };
 SavedLayout saved_layout(int b, int c, int hw, int r) {
   SavedLayout L;
@@ -744,6 +984,7 @@ SavedLayout saved_layout(int b, int c, int hw, int r) {
   L.tab_a = take((size_t)b * 3 * c);
   L.mean1 = take(c); L.rstd1 = take(c); L.scsh1 = take(2 * c); L.tab1 = take((size_t)b * 3 * c);
   L.mean2 = take(c); L.rstd2 = take(c); L.scsh2 = take(2 * c);
+  L.mask = take((size_t)b * c * ((hw + 31) / 32));  // ReLU pass bits, one word per (channel, 32 pixels)
   L.y1 = take((size_t)b * c * hw);
   L.y2 = take((size_t)b * c * hw);
   L.total = o;
@@ -758,7 +999,7 @@ ScratchLayout scratch_layout(int b, int c, int hw, int r) {
   size_t o = 0;
   auto take = [&](size_t n) { size_t at = o; o += align_up(n); return at; };
   const size_t cc = (size_t)c * c, plane = (size_t)b * c * hw;
-  L.wp1 = take(cc); L.wp2 = take(cc); L.wp1t = take(cc); L.wp2t = take(cc);
+  L.wp1 = take(2 * cc); L.wp2 = take(2 * cc); L.wp1t = take(2 * cc); L.wp2t = take(2 * cc);  // f32 images: cc, bf16x6 images: 1.5 cc
   L.part = take((size_t)b * kPlaneChunks * 2 * c);
   L.da1 = take((size_t)b * kPlaneChunks * c);
   L.da2 = take((size_t)b * kPlaneChunks * c);
@@ -774,32 +1015,58 @@ ScratchLayout scratch_layout(int b, int c, int hw, int r) {
   return L;
 }
 
+// output channels per block = 32 * cot
+inline int pw_cot(int c) { return (DHD_PW_COT_SEL == 8 && c % 256 == 0) ? 8 : 4; }
+
 inline bool stage_supported(int c, int hw) { return (c == 128 || (c > 0 && c % 256 == 0)) && hw > 0 && (hw & 3) == 0; }
 
-// in0/in1 prologue GEMM launcher.  mode: 0 forward (+bias), 1 dgrad with ReLU mask, 2 dgrad plain
-int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, const float* coef, bool relu, const float* wp,
-                   const float* bias, const float* aux, const float* aux_scsh, float* y, int epi, int b, int c, int hw,
-                   hipStream_t st) {
-  const int cot = c == 128 ? 4 : 8;
-  const dim3 grid(dhd_cdiv(hw, 32 * (kPwBlock / DHD_WAVE)), b, c / (32 * cot));
-  const size_t shmem = (size_t)(2 * cot * 512 + 3 * c) * sizeof(float);
-#define DHD_PW(COT, TWO, RELU, EPI)                                                                                   \
-  do {                                                                                                                \
-    auto kern = pw_gemm_kernel<COT, TWO, RELU, EPI>;                                                                  \
-    DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                (int)shmem));                                                                         \
-    hipLaunchKernelGGL(kern, grid, dim3(kPwBlock), shmem, st, in0, in1, in_bstride, coef, wp, bias, aux, aux_scsh, y, \
-                       c, hw);                                                                                        \
+int g_gemm_mode = 1;  // 1: bf16x6 split on the bf16 MFMA (default), 0: f32 MFMA
+
+int launch_pack(const float* w, int transpose, float* packed, int c, hipStream_t st) {
+  const int cot = pw_cot(c);
+  if (g_gemm_mode == 1)
+    hipLaunchKernelGGL(pack_weight6_kernel, dim3(dhd_cdiv((c / 32) * (c / 16) * 64, kEwBlock)), dim3(kEwBlock), 0, st, w, transpose,
+                       reinterpret_cast<u32x4*>(packed), c, cot);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(dhd_cdiv(c * c, kEwBlock)), dim3(kEwBlock), 0, st, w, transpose, packed, c, cot);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+// in0/in1 prologue GEMM launcher.  epi: 0 forward (+bias), 1 dgrad with ReLU mask, 2 dgrad plain
+int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in_channels, const float* coef, bool relu, const float* wp,
+                   const float* bias, const float* aux, const float* aux_scsh, unsigned* relu_mask, float* y, int epi, int b, int c,
+                   int hw, hipStream_t st) {
+  const int cot = pw_cot(c);
+  const int tiles8 = dhd_cdiv(dhd_cdiv(hw, 32 * (kPwBlock / DHD_WAVE)), 8) * 8;  // whole groups of 8; surplus tiles exit at once
+  const dim3 grid(tiles8 * (c / (32 * cot)), b);
+  const bool two = in1 != nullptr;
+  const unsigned in_bytes = (unsigned)((size_t)in_channels * hw * sizeof(float));  // one sample of in0 (and of in1, which follows it for x)
+  const size_t shmem = g_gemm_mode == 1 ? (size_t)2 * cot * 3 * 64 * 16 + (size_t)3 * c * sizeof(float)
+                                        : (size_t)(2 * cot * 512 + 3 * c) * sizeof(float);
+#define DHD_PW(COT, TWO, RELU, EPI)                                                                                    \
+  do {                                                                                                                 \
+    if (g_gemm_mode == 1) {                                                                                            \
+      auto kern = pw_gemm6_kernel<COT, TWO, RELU, EPI>;                                                                \
+      DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                  (int)shmem));                                                                        \
+      hipLaunchKernelGGL(kern, grid, dim3(kPwBlock), shmem, st, in0, in1, in_bstride, in_bytes, coef,                  \
+                         reinterpret_cast<const u32x4*>(wp), bias, relu_mask, y, c, hw);                           \
+    } else {                                                                                                           \
+      auto kern = pw_gemm_kernel<COT, TWO, RELU, EPI>;                                                                 \
+      DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                  (int)shmem));                                                                        \
+      hipLaunchKernelGGL(kern, grid, dim3(kPwBlock), shmem, st, in0, in1, in_bstride, coef, wp, bias, aux, aux_scsh, y, \
+                         c, hw);                                                                                       \
+    }                                                                                                                  \
   } while (0)
-#define DHD_PW_COT(TWO, RELU, EPI)          \
-  do {                                      \
+#define DHD_PW_COT(TWO, RELU, EPI)           \
+  do {                                       \
     if (cot == 4) DHD_PW(4, TWO, RELU, EPI); \
     else DHD_PW(8, TWO, RELU, EPI);          \
   } while (0)
-  const bool two = in1 != nullptr;
   if (epi == 0 && two && !relu) DHD_PW_COT(true, false, 0);
   else if (epi == 0 && !two && relu) DHD_PW_COT(false, true, 0);
-  else if (epi == 0 && !two && !relu) DHD_PW_COT(false, false, 0);
   else if (epi == 1 && two && !relu) DHD_PW_COT(true, false, 1);
   else if (epi == 2 && two && !relu) DHD_PW_COT(true, false, 2);
   else return DHD_EUNSUPPORTED;
@@ -848,6 +1115,12 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
 
 extern "C" {
 
+int dhd_sfa_set_gemm_mode(int mode) {
+  if (mode != 0 && mode != 1) return DHD_EINVAL;
+  g_gemm_mode = mode;
+  return DHD_OK;
+}
+
 int dhd_sfa_stage_supported(int c, int hw) { return stage_supported(c, hw) ? 1 : 0; }
 
 size_t dhd_sfa_stage_saved_bytes(int b, int c, int hw, int hidden) {
@@ -874,20 +1147,21 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
   const ScratchLayout T = scratch_layout(b, c, hw, r);
   float* sv = static_cast<float*>(saved);
   float* sc = static_cast<float*>(scratch);
-  const int cot = c == 128 ? 4 : 8;
   const dim3 planes2(kPlaneChunks, b * 2 * c), planes(kPlaneChunks, b * c);
   const dim3 per_ch(dhd_cdiv(c, kEwBlock));
 
   hipLaunchKernelGGL(plane_mean_kernel, planes2, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw);
   hipLaunchKernelGGL(fc_forward_kernel, dim3(b), dim3(kEwBlock), (size_t)(2 * c + r) * sizeof(float), st, sc + T.mean_part,
                      w->fc1_w, w->fc1_b, w->fc2_w, w->fc2_b, sv + S.s, sv + S.h, sv + S.a1, sv + S.tab_a, c, r, hw);
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(dhd_cdiv(c * c, kEwBlock)), dim3(kEwBlock), 0, st, w->conv1_w, 0, sc + T.wp1, c, cot);
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(dhd_cdiv(c * c, kEwBlock)), dim3(kEwBlock), 0, st, w->conv2_w, 0, sc + T.wp2, c, cot);
   DHD_LAUNCH_CHECK();
+  int rc = launch_pack(w->conv1_w, 0, sc + T.wp1, c, st);
+  if (rc != DHD_OK) return rc;
+  rc = launch_pack(w->conv2_w, 0, sc + T.wp2, c, st);
+  if (rc != DHD_OK) return rc;
 
   // y1 = conv1(blend1(x))
-  int rc = launch_pw_gemm(x, x + (size_t)c * hw, (size_t)2 * c * hw, sv + S.tab_a, false, sc + T.wp1, w->conv1_b, nullptr, nullptr,
-                          sv + S.y1, 0, b, c, hw, st);
+  rc = launch_pw_gemm(x, x + (size_t)c * hw, (size_t)2 * c * hw, c, sv + S.tab_a, false, sc + T.wp1, w->conv1_b, nullptr, nullptr,
+                      nullptr, sv + S.y1, 0, b, c, hw, st);
   if (rc != DHD_OK) return rc;
   if (w->training) {
     hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y1, sc + T.part, c, hw);
@@ -899,7 +1173,8 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
   }
   DHD_LAUNCH_CHECK();
   // y2 = conv2(relu(bn1(y1)))
-  rc = launch_pw_gemm(sv + S.y1, nullptr, (size_t)c * hw, sv + S.tab1, true, sc + T.wp2, w->conv2_b, nullptr, nullptr, sv + S.y2, 0,
+  rc = launch_pw_gemm(sv + S.y1, nullptr, (size_t)c * hw, c, sv + S.tab1, true, sc + T.wp2, w->conv2_b, nullptr, nullptr,
+                      reinterpret_cast<unsigned*>(sv + S.mask), sv + S.y2, 0,
                       b, c, hw, st);
   if (rc != DHD_OK) return rc;
   float* tab_unused = sc + T.tab_g2;  // bn2 has no consumer GEMM in forward; table slot reused as a sink
@@ -929,13 +1204,14 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
   const ScratchLayout T = scratch_layout(b, c, hw, r);
   const float* sv = static_cast<const float*>(saved);
   float* sc = static_cast<float*>(scratch);
-  const int cot = c == 128 ? 4 : 8;
   const dim3 planes(kPlaneChunks, b * c);
   const dim3 per_ch(dhd_cdiv(c, kEwBlock));
   const size_t cs = (size_t)c * hw;
 
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(dhd_cdiv(c * c, kEwBlock)), dim3(kEwBlock), 0, st, w->conv1_w, 1, sc + T.wp1t, c, cot);
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(dhd_cdiv(c * c, kEwBlock)), dim3(kEwBlock), 0, st, w->conv2_w, 1, sc + T.wp2t, c, cot);
+  int rc = launch_pack(w->conv1_w, 1, sc + T.wp1t, c, st);
+  if (rc != DHD_OK) return rc;
+  rc = launch_pack(w->conv2_w, 1, sc + T.wp2t, c, st);
+  if (rc != DHD_OK) return rc;
   // g2 = dL/ds2, BatchNorm-2 sums, go-part of dL/da
   hipLaunchKernelGGL(blend2_bn_bwd_kernel, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, sv + S.mean2, gout,
                      sc + T.g2, sc + T.part, sc + T.da1, c, hw);
@@ -943,11 +1219,12 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
                      w->training, sc + T.tab_g2, grads->bn2_w, grads->bn2_b, grads->conv2_b, b, c, hw);
   DHD_LAUNCH_CHECK();
   // dW2 = dy2 . z1^T
-  int rc = launch_pw_wgrad(sc + T.g2, sv + S.y2, sc + T.tab_g2, cs, sv + S.y1, nullptr, sv + S.tab1, cs, true, sc + T.wpart,
+  rc = launch_pw_wgrad(sc + T.g2, sv + S.y2, sc + T.tab_g2, cs, sv + S.y1, nullptr, sv + S.tab1, cs, true, sc + T.wpart,
                            grads->conv2_w, b, c, hw, st);
   if (rc != DHD_OK) return rc;
   // g1 = (W2^T dy2) * [z1 > 0]
-  rc = launch_pw_gemm(sc + T.g2, sv + S.y2, cs, sc + T.tab_g2, false, sc + T.wp2t, nullptr, sv + S.y1, sv + S.scsh1, sc + T.g1, 1, b,
+  rc = launch_pw_gemm(sc + T.g2, sv + S.y2, cs, c, sc + T.tab_g2, false, sc + T.wp2t, nullptr, sv + S.y1, sv + S.scsh1,
+                      reinterpret_cast<unsigned*>(const_cast<float*>(sv + S.mask)), sc + T.g1, 1, b,
                       c, hw, st);
   if (rc != DHD_OK) return rc;
   hipLaunchKernelGGL(pair_sums_kernel, planes, dim3(kEwBlock), 0, st, sc + T.g1, sv + S.y1, sv + S.mean1, sc + T.part, c, hw);
@@ -959,7 +1236,7 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
                        b, c, hw, st);
   if (rc != DHD_OK) return rc;
   // du = W1^T dy1
-  rc = launch_pw_gemm(sc + T.g1, sv + S.y1, cs, sc + T.tab_g1, false, sc + T.wp1t, nullptr, nullptr, nullptr, sc + T.du, 2, b, c, hw,
+  rc = launch_pw_gemm(sc + T.g1, sv + S.y1, cs, c, sc + T.tab_g1, false, sc + T.wp1t, nullptr, nullptr, nullptr, nullptr, sc + T.du, 2, b, c, hw,
                       st);
   if (rc != DHD_OK) return rc;
   hipLaunchKernelGGL(blend1_da_kernel, planes, dim3(kEwBlock), 0, st, x, sc + T.du, sc + T.da2, c, hw);

@@ -1,7 +1,7 @@
 """Debug aid: where does the fused SFA stage's input gradient differ from plain PyTorch, and is every
 such pixel a ReLU tie (a pre-activation within rounding of zero)?"""
 import copy, sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dhd_amd.mix import channel_spatial_stage
 gpu = torch.device('cuda:0')
 for (c, b, h, w, seed) in [(128, 3, 36, 40, 164), (256, 1, 200, 200, 1)]:

@@ -263,6 +263,11 @@ typedef struct dhd_sfa_grads { /* [dev] float32 outputs, shapes as in dhd_sfa_we
 } dhd_sfa_grads;
 
 int dhd_sfa_stage_supported(int c, int hw);
+/* How the stage's C x C GEMMs are computed (process-wide, not thread-safe against running calls):
+ *   1 (default) bf16 MFMA on a three-way split of every float32 operand, six products per a*b --
+ *     float32-level accuracy (dropped terms < 2^-25 |a*b|) at 6/16 of the f32-MFMA cost;
+ *   0 f32 MFMA (v_mfma_f32_32x32x2_f32), a plain float32 fma chain. */
+int dhd_sfa_set_gemm_mode(int mode);
 /* `saved` carries forward state to backward (a1, BatchNorm batch statistics, y1, y2);
  * `scratch` is reusable between calls on one stream.  0 if the shape is unsupported. */
 size_t dhd_sfa_stage_saved_bytes(int b, int c, int hw, int hidden);
