@@ -95,6 +95,7 @@ class HotPath:
         if with_sfa:
             torch.manual_seed(seed)
             self.stage = channel_spatial_stage(512).to(dev).train()
+            self.stage_params = list(self.stage.parameters())
             self.x = torch.randn(batch, 512, 200, 200, generator=g).to(dev).requires_grad_()
             self.gy = torch.randn(batch, 256, 200, 200, generator=g).to(dev)
         self.ev = []  # (start, end) HIP events around the dominant kernel, one pair per timed step
@@ -120,6 +121,8 @@ class HotPath:
         fg_nchw = mghs_op._nhwc_to_nchw(fg)
         if self.with_sfa:
             self.x.grad = None
+            for prm in self.stage_params:  # optimizer.zero_grad(set_to_none=True), the PyTorch default
+                prm.grad = None
             y = self.stage(self.x)
             y.backward(self.gy)
         return outs, dg, fg_nchw

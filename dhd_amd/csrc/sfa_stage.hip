@@ -104,19 +104,29 @@ __global__ __launch_bounds__(kEwBlock) void fc_forward_kernel(const float* __res
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int j = wv; j < r; j += kEwBlock / DHD_WAVE) {
-    float acc = 0.f;
-    for (int i = lane; i < c2; i += DHD_WAVE) acc = fmaf(w1[(size_t)j * c2 + i], ss[i], acc);
-    acc = group_sum(acc, DHD_WAVE);
-    if (lane == 0) {
-      float v = fmaxf(acc + b1[j], 0.f);
-      hh[j] = v;
-      hbuf[(size_t)b * r + j] = v;
+  // four rows per pass so that their loads are in flight together
+  for (int j0 = wv * 4; j0 < r; j0 += 4 * (kEwBlock / DHD_WAVE)) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < c2; i += DHD_WAVE) {
+      const float sv = ss[i];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j0 + q < r) acc[q] = fmaf(w1[(size_t)(j0 + q) * c2 + i], sv, acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float t = group_sum(acc[q], DHD_WAVE);
+      if (lane == 0 && j0 + q < r) {
+        const float v = fmaxf(t + b1[j0 + q], 0.f);
+        hh[j0 + q] = v;
+        hbuf[(size_t)b * r + j0 + q] = v;
+      }
     }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < c; k += kEwBlock) {
     float acc = b2[k];
+#pragma unroll 8
     for (int j = 0; j < r; ++j) acc = fmaf(w2[(size_t)k * r + j], hh[j], acc);
     float v = sigmoidf_(acc);
     a[(size_t)b * c + k] = v;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(kEwBlock) void fc_backward_kernel(const float* __re
                                                                const float* __restrict__ w1, const float* __restrict__ w2,
                                                                float* __restrict__ dpre2, float* __restrict__ dh,
                                                                float* __restrict__ ds, int c, int r) {
-  extern __shared__ float sh[];  // dpre2 (c) | dh (r)
+  extern __shared__ float sh[];  // dpre2 (c) | dh (r) | partials (kEwBlock)
   float* sp = sh;
   float* sd = sh + c;
   const int b = blockIdx.x, c2 = 2 * c;
@@ -147,16 +157,35 @@ __global__ __launch_bounds__(kEwBlock) void fc_backward_kernel(const float* __re
     dpre2[(size_t)b * c + k] = v;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < r; j += kEwBlock) {
+  if (r <= kEwBlock && kEwBlock % r == 0) {
+    // all threads: thread (group, j) sums k = group, group + groups, ...; partials through LDS
+    float* pp = sh + c + r;  // groups * r partials
+    const int groups = kEwBlock / r, j = threadIdx.x % r, grp = threadIdx.x / r;
     float acc = 0.f;
-    for (int k = 0; k < c; ++k) acc = fmaf(w2[(size_t)k * r + j], sp[k], acc);
-    const float v = hbuf[(size_t)b * r + j] > 0.f ? acc : 0.f;
-    sd[j] = v;
-    dh[(size_t)b * r + j] = v;
+#pragma unroll 8
+    for (int k = grp; k < c; k += groups) acc = fmaf(w2[(size_t)k * r + j], sp[k], acc);
+    pp[grp * r + j] = acc;
+    __syncthreads();
+    if (threadIdx.x < r) {
+      float t = 0.f;
+      for (int q = 0; q < groups; ++q) t += pp[q * r + threadIdx.x];
+      const float v = hbuf[(size_t)b * r + threadIdx.x] > 0.f ? t : 0.f;
+      sd[threadIdx.x] = v;
+      dh[(size_t)b * r + threadIdx.x] = v;
+    }
+  } else {
+    for (int j = threadIdx.x; j < r; j += kEwBlock) {
+      float acc = 0.f;
+      for (int k = 0; k < c; ++k) acc = fmaf(w2[(size_t)k * r + j], sp[k], acc);
+      const float v = hbuf[(size_t)b * r + j] > 0.f ? acc : 0.f;
+      sd[j] = v;
+      dh[(size_t)b * r + j] = v;
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < c2; i += kEwBlock) {
     float acc = 0.f;
+#pragma unroll 8
     for (int j = 0; j < r; ++j) acc = fmaf(w1[(size_t)j * c2 + i], sd[j], acc);
     ds[(size_t)b * c2 + i] = acc;
   }
@@ -618,6 +647,10 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm_kernel(const float* __res
 // NaN/Inf inputs propagate as NaN (Inf - Inf in the split) rather than Inf.
 // ------------------------------------------------------------------------------------------------
 
+#ifndef PWABL
+#define PWABL 0  // timing experiments only (results wrong when non-zero): 1 no weight refill/barrier, 2 no split, 4 no activation prefetch
+#endif
+
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
@@ -633,6 +666,7 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& 
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  if (PWABL & 16) { c[0] += __uint_as_float(a[0] ^ b[0]); return c; }
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
@@ -769,16 +803,17 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
         unsigned hh, mm, ll;
+        if (PWABL & 2) { hh = mm = ll = __float_as_uint(v[2 * jp]) ^ __float_as_uint(v[2 * jp + 1]); } else
         split2(v[2 * jp], v[2 * jp + 1], hh, mm, ll);
         ah[jp] = hh; am[jp] = mm; al[jp] = ll;
       }
     }
-    const bool more = kc + 1 < kcn;
+    const bool more = (kc + 1 < kcn) && !(PWABL & 1);
     if (more) {
 #pragma unroll
       for (int j = 0; j < kWst; ++j) wst[j] = wsrc[(size_t)(kc + 1) * kImg + j * kPwBlock + tid];
     }
-    if (kc + 2 < kcn) issue(lset, kc + 2);
+    if (kc + 2 < kcn && !(PWABL & 4)) issue(lset, kc + 2);
     const u32x4* img = lds6 + (kc & 1) * kImg + lane;
 #pragma unroll
     for (int t = 0; t < COT; t += 2) {
@@ -803,7 +838,7 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
 #pragma unroll
       for (int j = 0; j < kWst; ++j) dst[j * kPwBlock + tid] = wst[j];
     }
-    __syncthreads();
+    if (!(PWABL & 1)) __syncthreads();
   };
   for (int kc = 0; kc < kcn; kc += 3) {
     step(I0{}, I2{}, kc);
@@ -831,6 +866,7 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ((word >> (8 * q + e)) & 1u) ? v[e] : 0.f;
       }
+      if ((PWABL & 8) && v.x != 12345.678f) continue;
       *reinterpret_cast<f32x4*>(y + row + p) = v;
     }
   }
@@ -933,6 +969,163 @@ __global__ __launch_bounds__(kWgBlock) void pw_wgrad_kernel(const float* __restr
     }
     if (next < n_chunks) stage(next, buf ^ 1);
     buf ^= 1;
+    __syncthreads();
+  }
+
+  float* po = partial + (size_t)blockIdx.x * c * c;
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = ob_co + wco + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int ci = ob_ci + wci + 32 * j + r;
+        po[(size_t)co * c + ci] = acc[i][j][e];
+      }
+}
+
+// Weight gradient on the bf16 MFMA (bf16x6 split, see above): G[co][ci] = sum_{b,p} A(co,p) * B(ci,p).
+// Pixels are the MFMA k dimension, 16 per step.  An "item" is 8 consecutive pixels of one channel row:
+// exactly one lane's operand fragment, and 32 contiguous bytes of NCHW memory per input.  The thread
+// that loads an item applies the affine prologue, splits it into the three bf16 terms ONCE and writes
+// them to LDS in MFMA fragment order (lane-linear ds_write_b128 / ds_read_b128, no bank conflicts, no
+// per-wave re-splitting).  Block = 8 waves, output tile OT x OT (wave: OT/2 x OT/4), double-buffered
+// LDS, one barrier per step; the staging VALU work of step s+1 sits between the MFMAs of step s.
+// Workers own contiguous step ranges; per-worker partial matrices are reduced by wgrad_reduce_kernel.
+template <int OT, bool A_TWO, bool B_TWO, bool B_RELU>
+__global__ __launch_bounds__(kWgBlock, 2) void pw_wgrad6_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
+                                                                const float* __restrict__ acoef, size_t a_bstride,
+                                                                const float* __restrict__ b0, const float* __restrict__ b1,
+                                                                const float* __restrict__ bcoef, size_t b_bstride,
+                                                                float* __restrict__ partial, int c, int hw, int nb, int n_workers) {
+  constexpr int TA = OT / 64, TB = OT / 128;   // 32x32 tiles per wave
+  constexpr int kOp = (OT / 32) * 3 * 64;      // 16-byte units of one staged operand
+  constexpr int kItems = OT == 256 ? 2 : 1;    // items per thread per step: OT = 256 one of A and one of B
+  extern __shared__ u32x4 ldsw[];              // [buf 2][operand 2][tile][term][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nob = c / OT;
+  const int ob_co = (blockIdx.y / nob) * OT, ob_ci = (blockIdx.y % nob) * OT;
+  const int wco = (wv >> 2) * (OT / 2), wci = (wv & 3) * (OT / 4);
+  const int sps = (hw + 15) >> 4;              // steps per sample
+  const long n_steps = (long)nb * sps;
+  const int s0 = (int)(n_steps * blockIdx.x / n_workers), s1 = (int)(n_steps * (blockIdx.x + 1) / n_workers);
+
+  // this thread's items: (operand, row, half)
+  const int it_row = OT == 256 ? (tid >> 1) : ((tid & 255) >> 1);
+  const int it_h = tid & 1;
+  const bool second_is_b = true;               // OT = 256: item 0 = A, item 1 = B
+  const bool single_is_b = tid >= 256;         // OT = 128: waves 0-3 stage A, waves 4-7 stage B (wave-uniform)
+  const int it_slot = (it_row >> 5) * 192 + (it_row & 31) + 32 * it_h;  // + term * 64
+
+  f32x16 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // raw registers of the step being fetched: [item][input][2 x float4]
+  f32x4 raw[kItems][2][2];
+  float cfa[3], cfb[3];
+  int cur_b = -1;
+  auto load_coefs = [&](int b) {
+    const float* ca = acoef + (size_t)b * 3 * c + ob_co + it_row;
+    const float* cb = bcoef + (size_t)b * 3 * c + ob_ci + it_row;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { cfa[q] = ca[q * c]; cfb[q] = cb[q * c]; }
+    cur_b = b;
+  };
+  auto fetch = [&](int s) {
+    const int b = s / sps, p = (s % sps) * 16 + 8 * it_h;
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const bool is_b = OT == 256 ? (it == 1 && second_is_b) : single_is_b;
+      const float* src0 = is_b ? b0 : a0;
+      const float* src1 = is_b ? b1 : a1;
+      const bool two = is_b ? B_TWO : A_TWO;
+      const size_t base = (size_t)b * (is_b ? b_bstride : a_bstride) + (size_t)((is_b ? ob_ci : ob_co) + it_row) * hw;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int pq = p + 4 * q;
+        const size_t off = base + (pq < hw ? pq : 0);
+        raw[it][0][q] = *reinterpret_cast<const f32x4*>(src0 + off);
+        if (two) raw[it][1][q] = *reinterpret_cast<const f32x4*>(src1 + off);
+      }
+    }
+  };
+  auto stage = [&](int s, int buf) {
+    const int b = s / sps, p = (s % sps) * 16 + 8 * it_h;
+    if (b != cur_b) load_coefs(b);  // block-uniform, at most twice per worker
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const bool is_b = OT == 256 ? (it == 1 && second_is_b) : single_is_b;
+      const bool two = is_b ? B_TWO : A_TWO;
+      const float k0 = is_b ? cfb[0] : cfa[0], k1 = is_b ? cfb[1] : cfa[1], k2 = is_b ? cfb[2] : cfa[2];
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const bool in = p + 4 * q < hw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = fmaf(k0, raw[it][0][q][e], k2);
+          if (two) t = fmaf(k1, raw[it][1][q][e], t);
+          if (is_b && B_RELU) t = fmaxf(t, 0.f);
+          v[4 * q + e] = in ? t : 0.f;
+        }
+      }
+      u32x4 th, tm, tl;
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        unsigned hh, mm, ll;
+        split2(v[2 * jp], v[2 * jp + 1], hh, mm, ll);
+        th[jp] = hh; tm[jp] = mm; tl[jp] = ll;
+      }
+      u32x4* dst = ldsw + (buf * 2 + (is_b ? 1 : 0)) * kOp + it_slot;
+      dst[0] = th;
+      dst[64] = tm;
+      dst[128] = tl;
+    }
+  };
+
+  if (s0 < s1) {
+    fetch(s0);
+    stage(s0, 0);
+    if (s0 + 1 < s1) fetch(s0 + 1);
+  }
+  __syncthreads();
+  for (int s = s0; s < s1; ++s) {
+    const int buf = (s - s0) & 1;
+    if (s + 1 < s1) stage(s + 1, buf ^ 1);
+    if (s + 2 < s1) fetch(s + 2);
+    const u32x4* ta = ldsw + (buf * 2) * kOp + lane;
+    const u32x4* tb = ta + kOp;
+    u32x4 fb[TB][3];
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) fb[j][t] = tb[(((wci >> 5) + j) * 3 + t) * 64];
+#pragma unroll
+    for (int i = 0; i < TA; ++i) {
+      u32x4 fa[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) fa[t] = ta[(((wco >> 5) + i) * 3 + t) * 64];
+      // terms: 0 = high, 1 = mid, 2 = low; smallest products first, accumulators alternate
+#pragma unroll
+      for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(fa[2], fb[j][0], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(fa[0], fb[j][2], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(fa[1], fb[j][1], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(fa[1], fb[j][0], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(fa[0], fb[j][1], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(fa[0], fb[j][0], acc[i][j]);
+    }
     __syncthreads();
   }
 
@@ -1094,7 +1287,27 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
   } while (0)
   const bool btwo = b1 != nullptr;
   if (a1 == nullptr) return DHD_EUNSUPPORTED;
-  if (ot == 128) {
+  if (g_gemm_mode == 1) {
+    const size_t shmem6 = (size_t)2 * 2 * (ot / 32) * 3 * 64 * 16;
+#define DHD_WG6(OT, ATWO, BTWO, BRELU)                                                                             \
+  do {                                                                                                             \
+    auto kern = pw_wgrad6_kernel<OT, ATWO, BTWO, BRELU>;                                                           \
+    DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)shmem6));                                                                     \
+    hipLaunchKernelGGL(kern, grid, dim3(kWgBlock), shmem6, st, a0, a1, acoef, a_bs, b0, b1, bcoef, b_bs, partial,  \
+                       c, hw, b, workers);                                                                         \
+  } while (0)
+    if (ot == 128) {
+      if (btwo) DHD_WG6(128, true, true, false);
+      else if (b_relu) DHD_WG6(128, true, false, true);
+      else return DHD_EUNSUPPORTED;
+    } else {
+      if (btwo) DHD_WG6(256, true, true, false);
+      else if (b_relu) DHD_WG6(256, true, false, true);
+      else return DHD_EUNSUPPORTED;
+    }
+#undef DHD_WG6
+  } else if (ot == 128) {
     if (btwo) DHD_WG(128, true, true, false);
     else if (b_relu) DHD_WG(128, true, false, true);
     else return DHD_EUNSUPPORTED;
@@ -1240,7 +1453,7 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
                       st);
   if (rc != DHD_OK) return rc;
   hipLaunchKernelGGL(blend1_da_kernel, planes, dim3(kEwBlock), 0, st, x, sc + T.du, sc + T.da2, c, hw);
-  hipLaunchKernelGGL(fc_backward_kernel, dim3(b), dim3(kEwBlock), (size_t)(c + r) * sizeof(float), st, sc + T.da1, sc + T.da2,
+  hipLaunchKernelGGL(fc_backward_kernel, dim3(b), dim3(kEwBlock), (size_t)(c + r + kEwBlock) * sizeof(float), st, sc + T.da1, sc + T.da2,
                      sv + S.a1, sv + S.h, w->fc1_w, w->fc2_w, sc + T.dpre2, sc + T.dh, sc + T.ds, c, r);
   const int n_fc = r * 2 * c + c * r + r + c;
   hipLaunchKernelGGL(fc_param_grad_kernel, dim3(dhd_cdiv(n_fc, kEwBlock)), dim3(kEwBlock), 0, st, sc + T.dpre2, sc + T.dh, sv + S.h,
