@@ -17,7 +17,7 @@ HEADER = os.path.join(ROOT, 'include', 'dhd_amd.h')
 def declared_symbols():
     src = open(HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\bint\s+(dhd_[a-z0-9_]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(?:int|size_t)\s+(dhd_[a-z0-9_]+)\s*\(', src)))
 
 
 def test_header_and_binding_table_agree():
@@ -35,6 +35,28 @@ def test_library_loads_and_exports_every_declared_symbol():
     out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r' T (dhd_[a-z0-9_]+)', out))
     assert exported == set(declared_symbols()), exported ^ set(declared_symbols())
+
+
+def test_sfa_stage_shape_support_and_validation():
+    """dhd_sfa_stage_*: supported channel counts, sizes, and argument checks that run before any launch."""
+    from dhd_amd import _lib
+    lib = _lib.load()
+    assert lib.dhd_sfa_stage_supported(256, 40000) == 1 and lib.dhd_sfa_stage_supported(128, 400) == 1
+    assert lib.dhd_sfa_stage_supported(512, 40000) == 1
+    assert lib.dhd_sfa_stage_supported(64, 40000) == 0 and lib.dhd_sfa_stage_supported(256, 402) == 0
+    assert lib.dhd_sfa_stage_saved_bytes(4, 64, 40000, 8) == 0
+    saved = lib.dhd_sfa_stage_saved_bytes(4, 256, 40000, 32)
+    # y1 + y2 (2 x 164 MB) + one pass bit per activation (5 MB) + small tables
+    assert 2 * 4 * 256 * 40000 * 4 < saved < 2 * 4 * 256 * 40000 * 4 + 8e6
+    assert lib.dhd_sfa_stage_scratch_bytes(4, 256, 40000, 32) > 3 * 4 * 256 * 40000 * 4
+    w, g = _lib.SfaWeights(), _lib.SfaGrads()
+    one = C.c_void_p(16)
+    assert lib.dhd_sfa_stage_forward(None, C.byref(w), one, one, one, 4, 256, 40000, None) == -1
+    assert lib.dhd_sfa_stage_forward(one, C.byref(w), one, one, one, 4, 64, 40000, None) == -3   # unsupported C
+    w.hidden = 32
+    assert lib.dhd_sfa_stage_forward(one, C.byref(w), one, one, one, 4, 256, 40000, None) == -1  # null weights
+    assert lib.dhd_sfa_stage_backward(one, C.byref(w), one, one, one, C.byref(g), one, 4, 256, 40000, None) == -1
+    assert lib.dhd_sfa_set_gemm_mode(2) == -1 and lib.dhd_sfa_set_gemm_mode(1) == 0
 
 
 def test_library_is_a_gfx950_code_object():
