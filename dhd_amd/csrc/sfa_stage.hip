@@ -40,6 +40,7 @@ constexpr int kPwStep = 16;       // input channels per weight image / pipeline 
 constexpr int kWgBlock = 512;     // pw_wgrad: 8 waves
 constexpr int kWgStride = 33;     // LDS row stride of a 32-pixel operand row (conflict-free column reads)
 constexpr int kWgWorkers = 256;   // total pw_wgrad blocks (one per CU)
+constexpr int kStatGroups = 64;   // rows left by the first level of the statistics reduction
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
@@ -262,7 +263,8 @@ __global__ __launch_bounds__(kEwBlock) void moments_kernel(const float* __restri
 // Batch statistics -> mean, rstd, (scale, shift), prologue table (scale, 0, shift) per sample;
 // running statistics updated like torch.nn.BatchNorm2d (biased variance normalises, unbiased feeds
 // the running estimate).
-__global__ __launch_bounds__(kEwBlock) void bn_train_finalize_kernel(const float* __restrict__ part, const float* __restrict__ y,
+__global__ __launch_bounds__(kEwBlock) void bn_train_finalize_kernel(const float* __restrict__ part, int n_part,
+                                                                     const float* __restrict__ shift, int shift_stride,
                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                      float* __restrict__ run_mean, float* __restrict__ run_var,
                                                                      float momentum, float eps, float* __restrict__ mean,
@@ -271,7 +273,8 @@ __global__ __launch_bounds__(kEwBlock) void bn_train_finalize_kernel(const float
   const int ch = blockIdx.x * kEwBlock + threadIdx.x;
   if (ch >= c) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int q = 0; q < nb * kPlaneChunks; ++q) {
+#pragma unroll 8
+  for (int q = 0; q < n_part; ++q) {
     s1 += (double)part[((size_t)q * 2) * c + ch];
     s2 += (double)part[((size_t)q * 2 + 1) * c + ch];
   }
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(kEwBlock) void bn_train_finalize_kernel(const float
   const double md = s1 / n;
   double var = s2 / n - md * md;
   if (var < 0.0) var = 0.0;
-  const double mu = (double)y[(size_t)ch * hw] + md;
+  const double mu = (double)shift[(size_t)ch * shift_stride] + md;
   const float rs = (float)(1.0 / sqrt(var + (double)eps));
   mean[ch] = (float)mu;
   rstd[ch] = rs;
@@ -710,7 +713,8 @@ template <int COT, bool TWO_IN, bool RELU, int EPI>
 __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
                                                                size_t in_bstride, unsigned in_bytes, const float* __restrict__ coef,
                                                                const u32x4* __restrict__ wp, const float* __restrict__ bias,
-                                                               unsigned* __restrict__ relu_mask, float* __restrict__ y, int c, int hw) {
+                                                               unsigned* __restrict__ relu_mask, float* __restrict__ stat_part,
+                                                               float* __restrict__ y, int c, int hw) {
   constexpr int kImg = COT * 3 * 64;  // 16-byte units per weight image
   constexpr int kWst = kImg / kPwBlock;
   static_assert(kImg % kPwBlock == 0, "image must split evenly over the block");
@@ -852,7 +856,7 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
   for (int t = 0; t < COT; ++t) {
     const int co = co0 + 32 * t;
     const size_t row = ((size_t)b * c + co) * hw;
-    float bs = 0.f;
+    float bs = 0.f, s1 = 0.f, s2 = 0.f;
     unsigned word = 0;
     if (EPI == 0) bs = bias[co];
     if (EPI == 1 && wt < nwt) word = relu_mask[((size_t)b * c + co) * nwt + wt] >> (4 * h);
@@ -861,7 +865,12 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
       const int p = p0 + 8 * q + 4 * h;
       if (p >= hw) continue;
       f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-      if (EPI == 0) { v.x += bs; v.y += bs; v.z += bs; v.w += bs; }
+      if (EPI == 0) {
+        // BatchNorm batch statistics of this output, shifted by the bias (the raw accumulator)
+        s1 += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        v.x += bs; v.y += bs; v.z += bs; v.w += bs;
+      }
       if (EPI == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ((word >> (8 * q + e)) & 1u) ? v[e] : 0.f;
@@ -869,6 +878,49 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
       if ((PWABL & 8) && v.x != 12345.678f) continue;
       *reinterpret_cast<f32x4*>(y + row + p) = v;
     }
+    if (EPI == 0 && stat_part != nullptr) {  // block-uniform
+      s1 += __shfl_xor(s1, 32, DHD_WAVE);
+      s2 += __shfl_xor(s2, 32, DHD_WAVE);
+      if (h == 0 && wt < nwt) {
+        float* q = stat_part + ((size_t)(b * nwt + wt) * 2) * c;  // [(sample, wave tile)][2][c]
+        q[co] = s1;
+        q[c + co] = s2;
+      }
+    }
+  }
+}
+
+// partial rows [n][c2] -> kStatGroups rows: first level of the statistics reduction.  Thread =
+// (float4 column, row phase); four independent accumulators keep 64 bytes per thread in flight.
+__global__ __launch_bounds__(kEwBlock) void stat_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int c2) {
+  __shared__ f32x4 sm[kEwBlock];
+  const int g = blockIdx.x, groups = gridDim.x;
+  const int lo = (int)((long)n * g / groups), hi = (int)((long)n * (g + 1) / groups);
+  const int ncol4 = c2 >> 2;
+  const int nsub = ncol4 < kEwBlock ? kEwBlock / ncol4 : 1;  // c2 is a multiple of 256: ncol4 divides or is divided by 256
+  for (int col0 = 0; col0 < ncol4; col0 += kEwBlock) {
+    const int col = col0 + threadIdx.x % (ncol4 < kEwBlock ? ncol4 : kEwBlock);
+    const int sub = ncol4 < kEwBlock ? threadIdx.x / ncol4 : 0;
+    const f32x4* src = reinterpret_cast<const f32x4*>(part) + col;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    int i = lo + sub;
+    for (; i + 3 * nsub < hi; i += 4 * nsub) {
+      a0 += src[(size_t)i * ncol4];
+      a1 += src[(size_t)(i + nsub) * ncol4];
+      a2 += src[(size_t)(i + 2 * nsub) * ncol4];
+      a3 += src[(size_t)(i + 3 * nsub) * ncol4];
+    }
+    for (; i < hi; i += nsub) a0 += src[(size_t)i * ncol4];
+    f32x4 t = (a0 + a1) + (a2 + a3);
+    if (nsub > 1) {
+      __syncthreads();
+      sm[threadIdx.x] = t;
+      __syncthreads();
+      if (sub == 0) {
+        for (int q = 1; q < nsub; ++q) t += sm[q * ncol4 + col];
+      }
+    }
+    if (sub == 0) reinterpret_cast<f32x4*>(out)[(size_t)g * ncol4 + col] = t;
   }
 }
 
@@ -1185,7 +1237,7 @@ SavedLayout saved_layout(int b, int c, int hw, int r) {
 }
 
 struct ScratchLayout {
-  size_t wp1, wp2, wp1t, wp2t, part, da1, da2, tab_g2, tab_g1, dpre2, dh, ds, mean_part, g2, g1, du, wpart, total;
+  size_t wp1, wp2, wp1t, wp2t, part, da1, da2, tab_g2, tab_g1, dpre2, dh, ds, mean_part, stat_part, g2, g1, du, wpart, total;
 };
 ScratchLayout scratch_layout(int b, int c, int hw, int r) {
   ScratchLayout L;
@@ -1193,7 +1245,8 @@ ScratchLayout scratch_layout(int b, int c, int hw, int r) {
   auto take = [&](size_t n) { size_t at = o; o += align_up(n); return at; };
   const size_t cc = (size_t)c * c, plane = (size_t)b * c * hw;
   L.wp1 = take(2 * cc); L.wp2 = take(2 * cc); L.wp1t = take(2 * cc); L.wp2t = take(2 * cc);  // f32 images: cc, bf16x6 images: 1.5 cc
-  L.part = take((size_t)b * kPlaneChunks * 2 * c);
+  L.part = take((size_t)(b * kPlaneChunks > kStatGroups ? b * kPlaneChunks : kStatGroups) * 2 * c);
+  L.stat_part = take((size_t)b * ((hw + 31) / 32) * 2 * c);
   L.da1 = take((size_t)b * kPlaneChunks * c);
   L.da2 = take((size_t)b * kPlaneChunks * c);
   L.tab_g2 = take((size_t)b * 3 * c);
@@ -1228,8 +1281,8 @@ int launch_pack(const float* w, int transpose, float* packed, int c, hipStream_t
 
 // in0/in1 prologue GEMM launcher.  epi: 0 forward (+bias), 1 dgrad with ReLU mask, 2 dgrad plain
 int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in_channels, const float* coef, bool relu, const float* wp,
-                   const float* bias, const float* aux, const float* aux_scsh, unsigned* relu_mask, float* y, int epi, int b, int c,
-                   int hw, hipStream_t st) {
+                   const float* bias, const float* aux, const float* aux_scsh, unsigned* relu_mask, float* stat_part, float* y, int epi, int b,
+                   int c, int hw, hipStream_t st) {
   const int cot = pw_cot(c);
   const int tiles8 = dhd_cdiv(dhd_cdiv(hw, 32 * (kPwBlock / DHD_WAVE)), 8) * 8;  // whole groups of 8; surplus tiles exit at once
   const dim3 grid(tiles8 * (c / (32 * cot)), b);
@@ -1244,7 +1297,7 @@ int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in
       DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                   (int)shmem));                                                                        \
       hipLaunchKernelGGL(kern, grid, dim3(kPwBlock), shmem, st, in0, in1, in_bstride, in_bytes, coef,                  \
-                         reinterpret_cast<const u32x4*>(wp), bias, relu_mask, y, c, hw);                           \
+                         reinterpret_cast<const u32x4*>(wp), bias, relu_mask, stat_part, y, c, hw);                           \
     } else {                                                                                                           \
       auto kern = pw_gemm_kernel<COT, TWO, RELU, EPI>;                                                                 \
       DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
@@ -1362,6 +1415,8 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
   float* sc = static_cast<float*>(scratch);
   const dim3 planes2(kPlaneChunks, b * 2 * c), planes(kPlaneChunks, b * c);
   const dim3 per_ch(dhd_cdiv(c, kEwBlock));
+  const bool fused_stats = w->training && g_gemm_mode == 1;  // BatchNorm sums come out of the GEMM epilogue
+  const int nwt = (hw + 31) / 32;
 
   hipLaunchKernelGGL(plane_mean_kernel, planes2, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw);
   hipLaunchKernelGGL(fc_forward_kernel, dim3(b), dim3(kEwBlock), (size_t)(2 * c + r) * sizeof(float), st, sc + T.mean_part,
@@ -1374,12 +1429,20 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
 
   // y1 = conv1(blend1(x))
   rc = launch_pw_gemm(x, x + (size_t)c * hw, (size_t)2 * c * hw, c, sv + S.tab_a, false, sc + T.wp1, w->conv1_b, nullptr, nullptr,
-                      nullptr, sv + S.y1, 0, b, c, hw, st);
+                      nullptr, fused_stats ? sc + T.stat_part : nullptr, sv + S.y1, 0, b, c, hw, st);
   if (rc != DHD_OK) return rc;
   if (w->training) {
-    hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y1, sc + T.part, c, hw);
-    hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, sv + S.y1, w->bn1_w, w->bn1_b,
-                       w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1, sv + S.tab1, b, c, hw);
+    if (fused_stats) {  // the GEMM epilogue left per-(sample, wave tile) sums shifted by the bias
+      hipLaunchKernelGGL(stat_reduce_kernel, dim3(kStatGroups), dim3(kEwBlock), 0, st, sc + T.stat_part, sc + T.part, b * nwt, 2 * c);
+      hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, kStatGroups, w->conv1_b, 1, w->bn1_w,
+                         w->bn1_b, w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1,
+                         sv + S.tab1, b, c, hw);
+    } else {
+      hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y1, sc + T.part, c, hw);
+      hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, b * kPlaneChunks, sv + S.y1, hw, w->bn1_w,
+                         w->bn1_b, w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1,
+                         sv + S.tab1, b, c, hw);
+    }
   } else {
     hipLaunchKernelGGL(bn_eval_coef_kernel, per_ch, dim3(kEwBlock), 0, st, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, w->eps1,
                        sv + S.mean1, sv + S.rstd1, sv + S.scsh1, sv + S.tab1, b, c);
@@ -1387,14 +1450,22 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
   DHD_LAUNCH_CHECK();
   // y2 = conv2(relu(bn1(y1)))
   rc = launch_pw_gemm(sv + S.y1, nullptr, (size_t)c * hw, c, sv + S.tab1, true, sc + T.wp2, w->conv2_b, nullptr, nullptr,
-                      reinterpret_cast<unsigned*>(sv + S.mask), sv + S.y2, 0,
+                      reinterpret_cast<unsigned*>(sv + S.mask), fused_stats ? sc + T.stat_part : nullptr, sv + S.y2, 0,
                       b, c, hw, st);
   if (rc != DHD_OK) return rc;
   float* tab_unused = sc + T.tab_g2;  // bn2 has no consumer GEMM in forward; table slot reused as a sink
   if (w->training) {
-    hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y2, sc + T.part, c, hw);
-    hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, sv + S.y2, w->bn2_w, w->bn2_b,
-                       w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, sv + S.mean2, sv + S.rstd2, sv + S.scsh2, tab_unused, b, c, hw);
+    if (fused_stats) {  // the GEMM epilogue left per-(sample, wave tile) sums shifted by the bias
+      hipLaunchKernelGGL(stat_reduce_kernel, dim3(kStatGroups), dim3(kEwBlock), 0, st, sc + T.stat_part, sc + T.part, b * nwt, 2 * c);
+      hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, kStatGroups, w->conv2_b, 1, w->bn2_w,
+                         w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, sv + S.mean2, sv + S.rstd2, sv + S.scsh2,
+                         tab_unused, b, c, hw);
+    } else {
+      hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y2, sc + T.part, c, hw);
+      hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, b * kPlaneChunks, sv + S.y2, hw, w->bn2_w,
+                         w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, sv + S.mean2, sv + S.rstd2, sv + S.scsh2,
+                         tab_unused, b, c, hw);
+    }
   } else {
     hipLaunchKernelGGL(bn_eval_coef_kernel, per_ch, dim3(kEwBlock), 0, st, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, w->eps2,
                        sv + S.mean2, sv + S.rstd2, sv + S.scsh2, tab_unused, b, c);
@@ -1437,7 +1508,7 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
   if (rc != DHD_OK) return rc;
   // g1 = (W2^T dy2) * [z1 > 0]
   rc = launch_pw_gemm(sc + T.g2, sv + S.y2, cs, c, sc + T.tab_g2, false, sc + T.wp2t, nullptr, sv + S.y1, sv + S.scsh1,
-                      reinterpret_cast<unsigned*>(const_cast<float*>(sv + S.mask)), sc + T.g1, 1, b,
+                      reinterpret_cast<unsigned*>(const_cast<float*>(sv + S.mask)), nullptr, sc + T.g1, 1, b,
                       c, hw, st);
   if (rc != DHD_OK) return rc;
   hipLaunchKernelGGL(pair_sums_kernel, planes, dim3(kEwBlock), 0, st, sc + T.g1, sv + S.y1, sv + S.mean1, sc + T.part, c, hw);
@@ -1449,8 +1520,8 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
                        b, c, hw, st);
   if (rc != DHD_OK) return rc;
   // du = W1^T dy1
-  rc = launch_pw_gemm(sc + T.g1, sv + S.y1, cs, c, sc + T.tab_g1, false, sc + T.wp1t, nullptr, nullptr, nullptr, nullptr, sc + T.du, 2, b, c, hw,
-                      st);
+  rc = launch_pw_gemm(sc + T.g1, sv + S.y1, cs, c, sc + T.tab_g1, false, sc + T.wp1t, nullptr, nullptr, nullptr, nullptr, nullptr, sc + T.du, 2, b, c,
+                      hw, st);
   if (rc != DHD_OK) return rc;
   hipLaunchKernelGGL(blend1_da_kernel, planes, dim3(kEwBlock), 0, st, x, sc + T.du, sc + T.da2, c, hw);
   hipLaunchKernelGGL(fc_backward_kernel, dim3(b), dim3(kEwBlock), (size_t)(c + r + kEwBlock) * sizeof(float), st, sc + T.da1, sc + T.da2,
