@@ -332,12 +332,22 @@ __global__ __launch_bounds__(kEwBlock) void pair_sums_kernel(const float* __rest
   const f32x4* y4 = reinterpret_cast<const f32x4*>(y + (size_t)plane * hw);
   int lo, hi;
   chunk_range4(hw, &lo, &hi);
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
+  float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;
+  int i = lo + threadIdx.x;
+  for (; i + kEwBlock < hi; i += 2 * kEwBlock) {  // two independent 16-byte streams per thread
+    f32x4 a = g4[i], v = y4[i], a2 = g4[i + kEwBlock], v2 = y4[i + kEwBlock];
+    s1 += (a.x + a.y) + (a.z + a.w);
+    s2 += (a.x * (v.x - mu) + a.y * (v.y - mu)) + (a.z * (v.z - mu) + a.w * (v.w - mu));
+    t1 += (a2.x + a2.y) + (a2.z + a2.w);
+    t2 += (a2.x * (v2.x - mu) + a2.y * (v2.y - mu)) + (a2.z * (v2.z - mu) + a2.w * (v2.w - mu));
+  }
+  if (i < hi) {
     f32x4 a = g4[i], v = y4[i];
     s1 += (a.x + a.y) + (a.z + a.w);
     s2 += (a.x * (v.x - mu) + a.y * (v.y - mu)) + (a.z * (v.z - mu) + a.w * (v.w - mu));
   }
+  s1 += t1;
+  s2 += t2;
   s1 = block_sum(s1, sm);
   s2 = block_sum(s2, sm);
   if (threadIdx.x == 0) {

@@ -1,0 +1,49 @@
+#!/bin/bash
+# Regenerates the rocprofv3 evidence under gpurun_out/profiles_new/ (run on the GPU box through gpurun,
+# from the repo root); copy the results into profiles/<round>/ afterwards.
+#   1. kernel stats of the default bench (MGHS + SFA stage) and of --no-sfa
+#   2. PMC passes (counters only, FETCH_SIZE and WRITE_SIZE separately) of the default bench
+#   3. a plain bench line outside the profiler
+set -u
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/profiles_new
+rm -rf $OUT && mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --steps 20 --warmup 3 --cpu-samples 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hp -o hp -- $B 2>/dev/null | grep '^{' > $OUT/bench_hotpath_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mo -o mo -- $B --no-sfa 2>/dev/null | grep '^{' > $OUT/bench_mghs_only_under_rocprof.json
+P="python $R/bench.py --steps 5 --warmup 2 --cpu-samples 0"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o pf -- $P > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pw -o pw -- $P > /dev/null 2>&1
+cp $(find $OUT/hp -name 'hp_kernel_stats.csv') $OUT/hotpath_kernel_stats.csv
+cp $(find $OUT/mo -name 'mo_kernel_stats.csv') $OUT/mghs_only_kernel_stats.csv
+cp $(find $OUT/pf -name 'pf_counter_collection.csv') $OUT/pmc_fetch_size.csv
+cp $(find $OUT/pw -name 'pw_counter_collection.csv') $OUT/pmc_write_size.csv
+rm -rf $OUT/hp $OUT/mo $OUT/pf $OUT/pw
+cd $R && python bench.py > $OUT/bench_default.json 2>/dev/null
+python - <<'PY'
+import collections, csv, json, os, re
+out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/profiles_new'
+def means(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter:
+            name = re.sub(r'^.*?([A-Za-z_0-9]+)(<.*)?\(.*$', r'\1', r['Kernel_Name'].split('(')[0] + '(') if False else r['Kernel_Name']
+            m = re.search(r'([A-Za-z_0-9]+)(?:<[^(]*>)?\(', name)
+            key = (m.group(1) if m else name)
+            t = re.search(r'<([^(]*)>\(', name)
+            if t and key.startswith('pw_'): key += '<' + t.group(1).replace(' ', '') + '>'
+            acc[key].append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+f, w = means(out + '/pmc_fetch_size.csv', 'FETCH_SIZE'), means(out + '/pmc_write_size.csv', 'WRITE_SIZE')
+ks = {}
+for k in sorted(set(f) | set(w)):
+    if k.startswith('Cijk') or 'at::native' in k or k.startswith('__amd'): continue
+    ks[k] = dict(FETCH_SIZE_KB=f.get(k, 0.0), WRITE_SIZE_KB=w.get(k, 0.0), hbm_bytes_per_launch=int((2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024))
+json.dump(dict(samples_per_gpu=4,
+               command='rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 5 --warmup 2 --cpu-samples 0 (two separate passes)',
+               correction='bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of a wide coalesced read)',
+               kernels=ks), open(out + '/pmc_summary.json', 'w'), indent=1)
+print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in ks.items()}, indent=0)[:3000])
+PY
+ls -la $OUT
