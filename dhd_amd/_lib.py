@@ -90,6 +90,9 @@ _PROTOTYPES = {
     'dhd_sfa_stage_scratch_bytes': ([_I, _I, _I, _I], C.c_size_t),
     'dhd_sfa_stage_forward': ([_P, C.POINTER(SfaWeights), _P, _P, _P, _I, _I, _I, _P], _I),
     'dhd_sfa_stage_backward': ([_P, C.POINTER(SfaWeights), _P, _P, _P, C.POINTER(SfaGrads), _P, _I, _I, _I, _P], _I),
+    'dhd_occ_loss_workspace_bytes': ([], C.c_size_t),
+    'dhd_occ_loss_forward': ([_P, _P, _P, _P, C.c_int64, _I, _I, _I, _P, _P, _P], _I),
+    'dhd_occ_loss_backward': ([_P, _P, _P, _P, C.c_int64, _I, _I, _I, _P, _P, _P, _P], _I),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -373,11 +373,19 @@ class predictor(nn.Module):
     def loss(self, occ_pred, voxel_semantics, mask_camera):
         if not (self.use_mask and self.class_balance):
             raise NotImplementedError
+        preds = occ_pred.reshape(-1, self.num_classes)
+        from . import occ_loss
+        if occ_loss.supported(preds):
+            # one HIP operator: two streaming passes, no host round trips (csrc/occ_loss.hip)
+            scale = getattr(self.loss_occ, 'loss_weight', 1.0)
+            l_ce, l_sem, l_geo = occ_loss.occ_losses(preds, voxel_semantics, mask_camera, self.cls_weights,
+                                                     ignore_index=self.loss_occ.ignore_index, non_empty_idx=17)
+            return dict(loss_occ=self.weight_ce * scale * l_ce, loss_voxel_sem_scal=self.weight_sem * l_sem,
+                        loss_voxel_geo_scal=self.weight_geo * l_geo)
         sem = voxel_semantics.long().reshape(-1)
         mask = mask_camera.to(torch.int32).reshape(-1)
-        preds = occ_pred.reshape(-1, self.num_classes)
         # sum_i (#valid voxels of class i) * w_i, without a Python loop of host-visible sums
-        counts = torch.bincount(sem[mask.bool()].clamp(0, self.num_classes - 1), minlength=self.num_classes)
+        counts = torch.bincount(sem[mask.bool()], minlength=256)[:self.num_classes]
         avg = (counts.double() * self.cls_weights.to(counts.device)).sum()
         return dict(
             loss_occ=self.weight_ce * self.loss_occ(preds, sem, weight=mask, avg_factor=avg.float()),

@@ -1,0 +1,65 @@
+"""predictor.loss (models/dense_heads/occ_head.py:102-139) as one HIP operator: class-balanced,
+camera-masked cross entropy + sem_scal + geo_scal losses of the (M, 18) occupancy logits in two
+streaming passes (csrc/occ_loss.hip), no (M, 18) temporaries, no device->host round trips."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+NUM_CLASSES = 18
+
+
+class _OccLosses(torch.autograd.Function):
+    """logits (M,18) f32, labels (M) u8, mask (M) u8, class_weight (18) f32 -> losses (3,) f32."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, mask, class_weight, ignore_index, non_empty_idx):
+        logits = _lib.require_gpu_tensor(logits.contiguous(), torch.float32, 'occupancy logits')
+        labels = _lib.require_gpu_tensor(labels.contiguous(), torch.uint8, 'voxel labels')
+        mask = _lib.require_gpu_tensor(mask.contiguous(), torch.uint8, 'camera mask')
+        cw = _lib.require_gpu_tensor(class_weight.contiguous(), torch.float32, 'class weights')
+        m, k = logits.shape
+        if labels.numel() != m or mask.numel() != m or cw.numel() != k:
+            raise _lib.DhdError('occupancy losses: inconsistent shapes')
+        if logits.data_ptr() % 16:
+            logits = logits.clone()
+        lib = _lib.load()
+        dev = logits.device
+        with torch.cuda.device(dev):
+            ws = torch.empty(lib.dhd_occ_loss_workspace_bytes(), dtype=torch.uint8, device=dev)
+            losses = torch.empty(3, dtype=torch.float32, device=dev)
+            _lib.check(lib.dhd_occ_loss_forward(_lib.ptr(logits), _lib.ptr(labels), _lib.ptr(mask), _lib.ptr(cw), m, k, ignore_index,
+                                                non_empty_idx, _lib.ptr(losses), _lib.ptr(ws), _lib.stream_ptr(dev)),
+                       'dhd_occ_loss_forward')
+        ctx.save_for_backward(logits, labels, mask, cw, ws)
+        ctx.args = (m, k, ignore_index, non_empty_idx)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, mask, cw, ws = ctx.saved_tensors
+        m, k, ignore_index, non_empty_idx = ctx.args
+        lib = _lib.load()
+        dev = logits.device
+        g = g.float().contiguous()
+        with torch.cuda.device(dev):
+            grad = torch.empty_like(logits)
+            _lib.check(lib.dhd_occ_loss_backward(_lib.ptr(logits), _lib.ptr(labels), _lib.ptr(mask), _lib.ptr(cw), m, k, ignore_index,
+                                                 non_empty_idx, _lib.ptr(g), _lib.ptr(ws), _lib.ptr(grad), _lib.stream_ptr(dev)),
+                       'dhd_occ_loss_backward')
+        return grad, None, None, None, None, None
+
+
+def supported(logits):
+    return logits.is_cuda and logits.dim() == 2 and logits.shape[1] == NUM_CLASSES
+
+
+def occ_losses(logits, labels, mask_camera, class_weight, ignore_index=255, non_empty_idx=17):
+    """(loss_occ, loss_voxel_sem_scal, loss_voxel_geo_scal) before the head's weight_* factors.
+    labels / mask_camera may be any integer or bool dtype (converted to uint8 once)."""
+    labels = labels.reshape(-1).to(torch.uint8)
+    mask = mask_camera.reshape(-1).to(torch.uint8)
+    out = _OccLosses.apply(logits.float(), labels, mask, class_weight.to(device=logits.device, dtype=torch.float32),
+                           int(ignore_index), int(non_empty_idx))
+    return out[0], out[1], out[2]

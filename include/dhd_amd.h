@@ -281,6 +281,27 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
                            const float* gout, float* gx, const dhd_sfa_grads* grads, void* scratch,
                            int b, int c, int hw, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * 5. Occupancy-head losses (models/dense_heads/occ_head.py:102-139, predictor.loss): the
+ *    class-balanced camera-masked cross entropy (models/losses/cross_entropy_loss.py:12-63,
+ *    weight = mask_camera, avg_factor = sum_i #valid(i) * w_i), sem_scal_loss_with_mask
+ *    (models/losses/semkitti_loss.py:171-226) and geo_scal_loss_with_mask (:136-169) in two
+ *    streaming passes over the (n_voxels, 18) logits -- the caller row after the hot path.
+ *    labels: uint8, ignore_index (255) = unknown; mask: uint8 camera visibility; class_weight (18).
+ *    losses / grad_losses: [dev] float[3] = {cross entropy, sem scal, geo scal}, before the
+ *    head's weight_ce / weight_sem / weight_geo factors.  n_classes must be 18.
+ * ------------------------------------------------------------------------------------ */
+size_t dhd_occ_loss_workspace_bytes(void);
+/* workspace carries the global sums from forward to backward. */
+int dhd_occ_loss_forward(const float* logits, const uint8_t* labels, const uint8_t* mask,
+                         const float* class_weight, int64_t n_voxels, int n_classes, int ignore_index,
+                         int non_empty_idx, float* losses, void* workspace, void* stream);
+/* grad_logits (n_voxels, 18) = d(sum_k grad_losses[k] * losses[k]) / d logits, overwritten. */
+int dhd_occ_loss_backward(const float* logits, const uint8_t* labels, const uint8_t* mask,
+                          const float* class_weight, int64_t n_voxels, int n_classes, int ignore_index,
+                          int non_empty_idx, const float* grad_losses, const void* workspace,
+                          float* grad_logits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -473,3 +473,62 @@ def sfa_stage(x, fc1_w, fc1_b, fc2_w, fc2_b, conv1_w, conv1_b, bn1, conv2_w, con
     t = np.einsum('oc,bchw->bohw', conv2_w.reshape(c, c).astype(f64), t) + conv2_b[None, :, None, None]
     a2 = 1 / (1 + np.exp(-bn(t, bn2)))
     return (a2 * xb1 + (1 - a2) * xv1).astype(f32)
+
+
+# ---------------------------------------------------------------------------------------------
+# Occupancy-head losses (the caller row after the hot path)
+# ---------------------------------------------------------------------------------------------
+
+def _nll_clamped(x):
+    """binary_cross_entropy_with_logits(inverse_sigmoid(x), 1): inverse_sigmoid's loops
+    (semkitti_loss.py:8-16) move x into [1e-5, 1-1e-5) in steps of 1e-5; the result is -log(x')."""
+    x = float(np.float32(x))
+    while x >= 1 - 1e-5:
+        x -= 1e-5
+    while x < 1e-5:
+        x += 1e-5
+    return -np.log(x)
+
+
+def occ_losses(logits, labels, mask_camera, class_weights, ignore_index=255, non_empty_idx=17):
+    """predictor.loss (dense_heads/occ_head.py:102-139) in float64, written like the reference: the
+    class-balanced, camera-masked cross entropy (losses/cross_entropy_loss.py:12-63 with weight = mask,
+    avg_factor = sum_i #(valid voxels of class i) * w_i), sem_scal_loss_with_mask (semkitti_loss.py:171-226)
+    and geo_scal_loss_with_mask (:136-169).  Returns (loss_occ, loss_sem_scal, loss_geo_scal) before the
+    head's weight_ce / weight_sem / weight_geo factors (all 1 in DHD-S)."""
+    z = logits.astype(np.float64)
+    z = z - z.max(1, keepdims=True)
+    p = np.exp(z)
+    p /= p.sum(1, keepdims=True)
+    n_cls = p.shape[1]
+    cam = mask_camera.astype(bool)
+    # cross entropy
+    valid_labels = labels[cam]
+    avg = sum(float((valid_labels == i).sum()) * float(class_weights[i]) for i in range(n_cls))
+    keep = labels != ignore_index
+    nll = np.zeros(len(labels))
+    nll[keep] = -np.log(p[keep, labels[keep]]) * class_weights.astype(np.float64)[labels[keep]]
+    loss_occ = float((nll * cam).sum() / avg)
+    # semantic scal
+    m = keep & cam
+    loss, count = 0.0, 0
+    tgt = labels[m]
+    for i in range(n_cls - 1):
+        pi = p[m, i]
+        ct = (tgt == i).astype(np.float64)
+        if ct.sum() > 0:
+            count += 1
+            nom = (pi * ct).sum()
+            if pi.sum() > 0:
+                loss += _nll_clamped(nom / (pi.sum() + 1e-5))
+            loss += _nll_clamped(nom / (ct.sum() + 1e-5))
+            if (1 - ct).sum() > 0:
+                loss += _nll_clamped(((1 - pi) * (1 - ct)).sum() / ((1 - ct).sum() + 1e-5))
+    loss_sem = loss / count
+    # geometric scal
+    empty = p[m, non_empty_idx]
+    nonempty_t = (tgt != non_empty_idx).astype(np.float64)
+    inter = (nonempty_t * (1 - empty)).sum()
+    loss_geo = (_nll_clamped(inter / ((1 - empty).sum() + 1e-5)) + _nll_clamped(inter / (nonempty_t.sum() + 1e-5)) +
+                _nll_clamped(((1 - nonempty_t) * empty).sum() / ((1 - nonempty_t).sum() + 1e-5)))
+    return loss_occ, loss_sem, loss_geo

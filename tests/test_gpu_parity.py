@@ -584,3 +584,59 @@ def test_mghs_step_is_graph_capturable(gpu):
     for a, b in zip(cap[0], ref[0]):
         assert torch.allclose(a, 2 * b, atol=1e-4, rtol=1e-4)
     assert torch.allclose(cap[1], ref[1], atol=1e-4) and torch.allclose(cap[2], 2 * ref[2], atol=1e-3, rtol=1e-4)
+
+
+# --------------------------------------------------------------------------- occupancy-head losses (8f-2)
+
+def _class_weights():
+    from dhd_amd.detector import NUSC_CLASS_FREQUENCIES
+    return (1 / np.log(NUSC_CLASS_FREQUENCIES + 0.001)).astype(np.float32)
+
+
+def test_occ_losses_vs_reference_golden(gpu):
+    """dhd_occ_loss_forward/backward against golden G6 (the reference's own sem/geo scal code: values and
+    the gradient of sem + 2*geo) and the oracle's float64 cross entropy."""
+    from dhd_amd.occ_loss import occ_losses
+    from oracle import mghs_oracle as O
+    g = golden('g6_occ_losses')
+    cw = _class_weights()
+    logits = T(g['logits'], gpu).requires_grad_()
+    l_ce, l_sem, l_geo = occ_losses(logits, T(g['labels'], gpu), T(g['mask_camera'], gpu), T(cw, gpu))
+    assert abs(l_sem.item() - float(g['sem_scal'])) < 1e-5 and abs(l_geo.item() - float(g['geo_scal'])) < 1e-5
+    assert abs(l_ce.item() - O.occ_losses(g['logits'], g['labels'], g['mask_camera'], cw)[0]) < 1e-5
+    (l_sem + 2.0 * l_geo).backward()
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), g['grad'], atol=2e-7, rtol=1e-4)
+
+
+@pytest.mark.parametrize('m', [1, 255, 4097, 2 * 200 * 200 * 16])
+def test_occ_losses_vs_torch_autograd(gpu, m):
+    """All three losses and their joint gradient against the vectorised PyTorch formulation (itself pinned
+    to the reference by G6 on CPU), including ragged tile sizes, ignored labels and an absent class."""
+    from dhd_amd.detector import CrossEntropyLoss, geo_scal_loss_with_mask, sem_scal_loss_with_mask
+    from dhd_amd.occ_loss import occ_losses
+    gen = torch.Generator().manual_seed(m)
+    z = (3.0 * torch.randn(m, 18, generator=gen)).to(gpu)
+    t = torch.randint(0, 18, (m,), generator=gen)
+    t[t == 5] = 4
+    t[::97] = 255
+    t[0] = 3
+    if m > 1:
+        t[1] = 17
+    t = t.to(gpu)
+    cam = (torch.rand(m, generator=gen) < 0.4).to(gpu)
+    cam[:2] = True
+    cw = T(_class_weights(), gpu)
+    w = [0.7, 1.3, 2.0]
+    a = z.clone().requires_grad_()
+    la = occ_losses(a, t, cam, cw)
+    sum(wi * li for wi, li in zip(w, la)).backward()
+    b = z.clone().requires_grad_()
+    counts = torch.bincount(t[cam], minlength=256)[:18]
+    avg = (counts.double() * cw.double()).sum().float()
+    lb = (CrossEntropyLoss(class_weight=cw)(b, t, weight=cam.int(), avg_factor=avg),
+          sem_scal_loss_with_mask(b, t, cam.int()), geo_scal_loss_with_mask(b, t, cam.int(), non_empty_idx=17))
+    sum(wi * li for wi, li in zip(w, lb)).backward()
+    for x, y in zip(la, lb):
+        assert abs(x.item() - y.item()) <= 2e-5 * max(1.0, abs(y.item())), (x.item(), y.item())
+    scale = b.grad.abs().max().item()
+    assert (a.grad - b.grad).abs().max().item() <= 1e-4 * scale + 1e-9

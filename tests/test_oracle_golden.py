@@ -145,3 +145,19 @@ def test_sfa_stage_eval_mode():
                       sd[p + 'spacial_leanring.0.weight'], sd[p + 'spacial_leanring.0.bias'], bn(1),
                       sd[p + 'spacial_leanring.3.weight'], sd[p + 'spacial_leanring.3.bias'], bn(4))
     np.testing.assert_allclose(out, g['eval.stage'], atol=2e-6, rtol=1e-5)
+
+
+def test_occupancy_losses_oracle_vs_reference_code():
+    """oracle.occ_losses (predictor.loss restated in float64) against golden G6, recorded from the reference's
+    own semkitti_loss.py; the cross-entropy part against its textbook definition."""
+    from dhd_amd.detector import NUSC_CLASS_FREQUENCIES
+    g = golden('g6_occ_losses')
+    cw = (1 / np.log(NUSC_CLASS_FREQUENCIES + 0.001)).astype(np.float32)
+    l_ce, l_sem, l_geo = O.occ_losses(g['logits'], g['labels'], g['mask_camera'], cw)
+    assert abs(l_sem - float(g['sem_scal'])) < 1e-6 and abs(l_geo - float(g['geo_scal'])) < 1e-6
+    z = g['logits'].astype(np.float64)
+    lp = z - np.log(np.exp(z).sum(1, keepdims=True))
+    t, cam = g['labels'], g['mask_camera'].astype(bool)
+    keep = cam & (t != 255)
+    ce = -(lp[keep, t[keep]] * cw[t[keep]]).sum() / sum((t[cam] == i).sum() * float(cw[i]) for i in range(18))
+    assert abs(l_ce - ce) < 1e-9
