@@ -58,7 +58,7 @@ def parse():
     p.add_argument('--warmup', type=int, default=10)
     p.add_argument('--batch', type=int, default=4, help='samples per GPU (DHD-S.py:243 samples_per_gpu=4)')
     p.add_argument('--no-sfa', action='store_true', help='time the MGHS part only')
-    p.add_argument('--workload', choices=['hotpath', 'e2e'], default='hotpath',
+    p.add_argument('--workload', choices=['hotpath', 'e2e', 'occ_loss'], default='hotpath',
                    help="hotpath: MGHS + SFA stage (default). e2e: the whole DHD-S detector (dense parts on MIOpen/hipBLASLt), "
                         "forward_train + backward + AdamW step, DDP over RCCL when --gpus > 1")
     p.add_argument('--amp', choices=['off', 'bf16', 'fp16'], default='off', help='autocast dtype of the dense modules (e2e)')
@@ -239,6 +239,62 @@ def cpu_baseline(hp, n_samples):
                        (f' + SFA stage fwd+bwd in torch-CPU fp32 ({t_sfa:.2f} s, {os.cpu_count()} threads)' if hp.with_sfa else ''))
 
 
+def run_occ_loss(a, rank, world, dev):
+    """The caller row after the hot path: predictor.loss on B x 200x200x16 voxels x 18 classes,
+    forward + backward through dhd_occ_loss_forward/backward.  Roofline: the gradient pass (reads and writes the
+    (M,18) logits matrix once each), timed with HIP events on the launch stream."""
+    from dhd_amd import occ_loss
+    from dhd_amd.detector import NUSC_CLASS_FREQUENCIES
+    m = a.batch * 200 * 200 * 16
+    g = torch.Generator(device='cpu').manual_seed(2000 + rank)
+    logits = torch.randn(m, 18, generator=g).to(dev).requires_grad_()
+    labels = torch.randint(0, 18, (m,), generator=g).to(torch.uint8).to(dev)
+    cam = (torch.rand(m, generator=g) < 0.3).to(torch.uint8).to(dev)
+    cw = torch.from_numpy((1 / np.log(NUSC_CLASS_FREQUENCIES + 0.001)).astype(np.float32)).to(dev)
+    ones = torch.ones(3, device=dev)
+    ev = []
+
+    def step(record):
+        logits.grad = None
+        l = occ_loss._OccLosses.apply(logits, labels, cam, cw, 255, 17)
+        occ_loss._OccLosses.events = ev if record else None  # HIP events right around the gradient kernel's launch
+        l.backward(ones)
+        occ_loss._OccLosses.events = None
+
+    for _ in range(a.warmup):
+        step(False)
+    torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+        grad_bytes = m * (2 * 18 * 4 + 2)  # logits read + gradient written + label and mask bytes
+        achieved = grad_bytes / (kern_ms * 1e-3) / 1e9
+        line = dict(metric='samples/sec (fwd+bwd) DHD-S occupancy-head losses', value=a.batch * world * a.steps / elapsed, unit='samples/s',
+                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True,
+                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    config=dict(workload='DHD-S predictor.loss (class-balanced masked CE + sem_scal + geo_scal) on B x 200x200x16 voxels x 18 '
+                                         'classes, forward + backward', samples_per_gpu=a.batch, global_batch=a.batch * world,
+                                parallelism=f'sample-sharded x{world}, no data-path collective'),
+                    roofline=dict(bound='hbm', kernel='occ_loss_grad', achieved=achieved,
+                                  peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic('occ_loss_grad', a.batch),
+                                  launch_ms=kern_ms, algorithmic_bytes=grad_bytes))
+        if world == 1 and a.cpu_samples > 0:
+            from oracle import mghs_oracle as O  # checker / CPU baseline only
+            n1 = 200 * 200 * 16
+            z, t, c = logits[:n1].detach().cpu().numpy(), labels[:n1].cpu().numpy().astype(np.int64), cam[:n1].cpu().numpy()
+            t0 = time.perf_counter()
+            O.occ_losses(z, t, c, cw.cpu().numpy())
+            dt = time.perf_counter() - t0
+            line['cpu_baseline'] = dict(value=1.0 / dt, unit='samples/s', cores=1, kind='port',
+                                        sample='1 sample (640 000 voxels), oracle.occ_losses forward only (numpy float64, 1 thread)')
+        print(json.dumps(line), flush=True)
+    ddist.shutdown()
+
+
 def main():
     a = parse()
     rank, local, world = ddist.env_world()
@@ -252,6 +308,8 @@ def main():
     _lib.load()
     if a.workload == 'e2e':
         return run_e2e(a, rank, world, dev)
+    if a.workload == 'occ_loss':
+        return run_occ_loss(a, rank, world, dev)
     hp = HotPath(dev, a.batch, 1000 + rank, not a.no_sfa)
 
     for _ in range(a.warmup):

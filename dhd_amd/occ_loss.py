@@ -13,6 +13,8 @@ NUM_CLASSES = 18
 class _OccLosses(torch.autograd.Function):
     """logits (M,18) f32, labels (M) u8, mask (M) u8, class_weight (18) f32 -> losses (3,) f32."""
 
+    events = None  # bench.py: a list that receives (start, end) HIP events around the gradient kernel launch
+
     @staticmethod
     def forward(ctx, logits, labels, mask, class_weight, ignore_index, non_empty_idx):
         logits = _lib.require_gpu_tensor(logits.contiguous(), torch.float32, 'occupancy logits')
@@ -45,9 +47,16 @@ class _OccLosses(torch.autograd.Function):
         g = g.float().contiguous()
         with torch.cuda.device(dev):
             grad = torch.empty_like(logits)
+            ev = _OccLosses.events
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             _lib.check(lib.dhd_occ_loss_backward(_lib.ptr(logits), _lib.ptr(labels), _lib.ptr(mask), _lib.ptr(cw), m, k, ignore_index,
                                                  non_empty_idx, _lib.ptr(g), _lib.ptr(ws), _lib.ptr(grad), _lib.stream_ptr(dev)),
                        'dhd_occ_loss_backward')
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
         return grad, None, None, None, None, None
 
 
