@@ -287,8 +287,18 @@ class MGHS(nn.Module):
             loss = F.binary_cross_entropy(pred.float()[fg], labels[fg], reduction='none').sum()
             return loss / max(1.0, fg.sum())
 
+    def _hip_labels(self, gt_depth, gt_height):
+        from . import label_loss
+        return label_loss.bin_labels(gt_depth.float(), gt_height.float(), self.downsample, self.grid_config['depth'], self.D,
+                                     self.height_range[0], self.height_interval, self.H)
+
     def get_height_loss(self, gt_depth, gt_height, height):
-        """BCE over foreground pixels (those with a depth label), reference :595-622."""
+        """BCE over foreground pixels (those with a depth label), reference :595-622.  On the GPU (non-SID
+        binning) labels are bin indices and the loss is one HIP operator (csrc/label_loss.hip)."""
+        if height.is_cuda and not self.sid:
+            from . import label_loss
+            dbin, hbin = self._hip_labels(gt_depth, gt_height)
+            return label_loss.fg_bce(height, hbin, dbin, self.loss_height_weight)
         height_labels = self.get_downsampled_gt_height(gt_height)
         depth_labels = self.get_downsampled_gt_depth(gt_depth)
         fg = depth_labels.max(dim=1).values > 0.0
@@ -330,6 +340,11 @@ class MGHS_Depth(MGHS):
 
     def get_depth_and_height_loss(self, gt_depth, gt_height, depth, height):
         """reference :859-897 -> (loss_depth, loss_height)."""
+        if height.is_cuda and not self.sid:
+            from . import label_loss
+            dbin, hbin = self._hip_labels(gt_depth, gt_height)
+            return (label_loss.fg_bce(depth, dbin, dbin, self.loss_depth_weight),
+                    label_loss.fg_bce(height, hbin, dbin, self.loss_height_weight))
         height_labels = self.get_downsampled_gt_height(gt_height)
         depth_labels = self.get_downsampled_gt_depth(gt_depth)
         fg = depth_labels.max(dim=1).values > 0.0

@@ -302,6 +302,35 @@ int dhd_occ_loss_backward(const float* logits, const uint8_t* labels, const uint
                           int non_empty_idx, const float* grad_losses, const void* workspace,
                           float* grad_logits, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * 6. Height / depth supervision of the view transformer (row a16):
+ *    MGHS.get_height_loss (models/necks/lss_heightmap.py:595-622), its label builders
+ *    get_downsampled_gt_depth / _height (:625-667, :670-701; non-SID binning) and
+ *    MGHS_Depth.get_depth_and_height_loss (:859-897).
+ * ------------------------------------------------------------------------------------ */
+
+/* gt_depth, gt_height: (bn, fh*downsample, fw*downsample) sparse maps (0 = no LiDAR return).
+ * Per feature pixel: m = min over the window of the non-zero values (1e5 if none),
+ * g = (m - offset) / step in float32, bin = trunc(g) if 0 <= g < bins + 1 else 0.  Bin 0 means
+ * "no label"; bin k >= 1 is channel k-1 of the reference's one-hot matrix.  Outputs (bn*fh*fw) int16.
+ * offset/step: depth (d0 - dstep, dstep) of grid_config['depth'] (:649-651), height
+ * (height_range[0], height_interval) (:691). */
+int dhd_sparse_bin_labels(const float* gt_depth, const float* gt_height, int bn, int fh, int fw,
+                          int downsample, float depth_offset, float depth_step, int depth_bins,
+                          float height_offset, float height_step, int height_bins,
+                          int16_t* depth_bin, int16_t* height_bin, void* stream);
+
+size_t dhd_bin_bce_workspace_bytes(void);
+/* loss[0] = weight * sum_{pixels with fg_bin > 0} sum_c BCE(pred[b,c,pixel], [c == bin-1]) / max(1, n_fg)
+ * (F.binary_cross_entropy, logs clamped at -100; :612-622).  pred is (bn, c, hw), the softmax map in
+ * its native layout.  workspace carries n_fg to backward. */
+int dhd_bin_bce_forward(const float* pred, const int16_t* bin, const int16_t* fg_bin, int bn, int c,
+                        int hw, float weight, float* loss, void* workspace, void* stream);
+/* grad_pred (bn, c, hw) = grad_loss[0] * d loss / d pred, overwritten (zeros outside the foreground). */
+int dhd_bin_bce_backward(const float* pred, const int16_t* bin, const int16_t* fg_bin, int bn, int c,
+                         int hw, float weight, const float* grad_loss, const void* workspace,
+                         float* grad_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

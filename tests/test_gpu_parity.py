@@ -640,3 +640,59 @@ def test_occ_losses_vs_torch_autograd(gpu, m):
         assert abs(x.item() - y.item()) <= 2e-5 * max(1.0, abs(y.item())), (x.item(), y.item())
     scale = b.grad.abs().max().item()
     assert (a.grad - b.grad).abs().max().item() <= 1e-4 * scale + 1e-9
+
+
+# --------------------------------------------------------------------------- height / depth supervision (a16)
+
+def test_height_loss_labels_and_value_vs_reference_golden(gpu):
+    """dhd_sparse_bin_labels + dhd_bin_bce_* against golden G4 (the reference's get_downsampled_gt_* one-hots and
+    get_height_loss, in both grid_config states of the quirk) -- labels exact, loss 1e-6."""
+    import dhd_amd
+    from dhd_amd import label_loss
+    g = golden('g4_loss')
+    cfg = syn.dhd_s_config()
+    cfg['input_size'] = (64, 176)
+    m = dhd_amd.MGHS(**cfg).to(gpu)
+    gd, gh, hp = T(g['gt_depth'], gpu), T(g['gt_height'], gpu), T(g['height_prob'], gpu)
+
+    def onehot(bins, n):
+        b = bins.cpu().numpy().astype(np.int64)
+        return (b[:, None] == np.arange(1, n + 1)[None, :]).astype(np.float32)
+    for state, key_d, key_l in ((None, 'gt_depth_onehot_init', 'loss_height_init'),
+                                (m.mask_3_grid, 'gt_depth_onehot_after_forward', 'loss_height_after_forward')):
+        if state is not None:
+            m._set_grid(state)
+        dbin, hbin = m._hip_labels(gd, gh)
+        np.testing.assert_array_equal(onehot(dbin, m.D), g[key_d])
+        np.testing.assert_array_equal(onehot(hbin, m.H), g['gt_height_onehot'])
+        assert abs(float(m.get_height_loss(gd, gh, hp)) - float(g[key_l])) < 1e-6
+
+
+def test_height_and_depth_loss_vs_torch_mirror_full_size(gpu):
+    """Full DHD-S size (B=2, 6 cameras, 256x704): loss values and gradients of the HIP operators against the
+    PyTorch mirror of the reference code (pinned to G4 on CPU); covers MGHS_Depth's two losses as well."""
+    import dhd_amd
+    cfg = syn.dhd_s_config()
+    md = dhd_amd.build_neck(dict(cfg, type='MGHS_Depth', collapse_z=False, depthnet_cfg=dict(use_dcn=False),
+                                 heightnet_cfg=dict(use_dcn=False, use_aspp=False))).to(gpu)
+    gen = torch.Generator().manual_seed(3)
+    B, N = 2, 6
+    sel = torch.rand(B, N, 256, 704, generator=gen) < 0.02
+    gd = (torch.rand(B, N, 256, 704, generator=gen) * 50.0 * sel).to(gpu)       # some beyond the 45 m range
+    gh = ((torch.rand(B, N, 256, 704, generator=gen) * 7.4 - 1.5) * sel).to(gpu)  # some outside [-1, 5.4]
+    hp = torch.softmax(torch.randn(B * N, md.H, 16, 44, generator=gen), 1).to(gpu)
+    dp = torch.softmax(torch.randn(B * N, md.D, 16, 44, generator=gen), 1).to(gpu)
+    a_h, a_d = hp.clone().requires_grad_(), dp.clone().requires_grad_()
+    ld, lh = md.get_depth_and_height_loss(gd, gh, a_d, a_h)
+    (0.7 * ld + 1.3 * lh).backward()
+    b_h, b_d = hp.clone().requires_grad_(), dp.clone().requires_grad_()
+    hl, dl = md.get_downsampled_gt_height(gh), md.get_downsampled_gt_depth(gd)
+    fg = dl.max(dim=1).values > 0.0
+    rd = md.loss_depth_weight * md._fg_bce(b_d.permute(0, 2, 3, 1).reshape(-1, md.D), dl, fg)
+    rh = md.loss_height_weight * md._fg_bce(b_h.permute(0, 2, 3, 1).reshape(-1, md.H), hl, fg)
+    (0.7 * rd + 1.3 * rh).backward()
+    assert fg.sum().item() > 1000
+    assert abs(ld.item() - rd.item()) < 1e-5 * max(1.0, abs(rd.item())) and abs(lh.item() - rh.item()) < 1e-5 * max(1.0, abs(rh.item()))
+    for a, b in ((a_h, b_h), (a_d, b_d)):
+        scale = b.grad.abs().max().item()
+        assert (a.grad - b.grad).abs().max().item() <= 1e-5 * scale
