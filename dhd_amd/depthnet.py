@@ -36,8 +36,45 @@ class BasicBlock(nn.Module):
         return self.relu(out + identity)
 
 
+class _DeformIm2col(torch.autograd.Function):
+    """x (B,C,H,W), offset (B,2kk,H,W) -> col (B, C*kk, H*W) through libdhd_amd.so (csrc/deform.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, offset, k, pad, dil):
+        from . import _lib
+        x = _lib.require_gpu_tensor(x.contiguous(), torch.float32, 'DCN input')
+        offset = _lib.require_gpu_tensor(offset.contiguous(), torch.float32, 'DCN offsets')
+        b, c, h, w = x.shape
+        dev = x.device
+        with torch.cuda.device(dev):
+            col = torch.empty((b, c * k * k, h * w), dtype=torch.float32, device=dev)
+            _lib.check(_lib.load().dhd_deform_im2col(_lib.ptr(x), _lib.ptr(offset), _lib.ptr(col), b, c, h, w, k, pad, dil,
+                                                     _lib.stream_ptr(dev)), 'dhd_deform_im2col')
+        ctx.save_for_backward(x, offset)
+        ctx.args = (k, pad, dil)
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        from . import _lib
+        x, offset = ctx.saved_tensors
+        k, pad, dil = ctx.args
+        b, c, h, w = x.shape
+        dev = x.device
+        dcol = dcol.float().contiguous()
+        with torch.cuda.device(dev):
+            dx, doff = torch.empty_like(x), torch.empty_like(offset)
+            _lib.check(_lib.load().dhd_deform_col2im(_lib.ptr(dcol), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(dx), _lib.ptr(doff), b, c, h, w,
+                                                     k, pad, dil, _lib.stream_ptr(dev)), 'dhd_deform_col2im')
+        return dx, doff, None, None, None
+
+
 class DCN(nn.Module):
-    """Deformable convolution v1 with its own offset branch (mmcv DeformConv2dPack)."""
+    """Deformable convolution v1 with its own offset branch (mmcv DeformConv2dPack).  On the GPU the sampling
+    (deformable im2col and its two backward passes) runs in libdhd_amd.so; the grid_sample formulation
+    below is the same math for CPU tensors and serves as the cross-check in the tests."""
+
+    use_hip = True
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, groups=1,
                  deform_groups=1, im2col_step=128, bias=False):
@@ -57,6 +94,14 @@ class DCN(nn.Module):
     def forward(self, x):
         b, c, h, w = x.shape
         k = self.k
+        g = self.groups
+        wgt = self.weight.view(g, self.out_channels // g, (c // g) * k * k)
+        if self.use_hip and x.is_cuda and h * w * 4 <= 48 * 1024:
+            # sampling in HIP (float32); the GEMM with the layer's weight follows the ambient autocast dtype
+            col = _DeformIm2col.apply(x.float(), self.conv_offset(x).float(), k, self.padding, self.dilation)
+            col = col.view(b, g, (c // g) * k * k, h * w)
+            out = torch.einsum('gok,bgkp->bgop', wgt, col)
+            return out.reshape(b, self.out_channels, h, w)
         offset = self.conv_offset(x).view(b, k * k, 2, h, w)
         ys, xs = torch.meshgrid(torch.arange(h, device=x.device, dtype=x.dtype),
                                 torch.arange(w, device=x.device, dtype=x.dtype), indexing='ij')
@@ -68,9 +113,7 @@ class DCN(nn.Module):
             grid = torch.stack((2 * px / max(w - 1, 1) - 1, 2 * py / max(h - 1, 1) - 1), -1)
             cols.append(F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=True))
         col = torch.stack(cols, 2)  # (B, C, k*k, H, W)
-        g = self.groups
         col = col.view(b, g, (c // g) * k * k, h * w)
-        wgt = self.weight.view(g, self.out_channels // g, (c // g) * k * k)
         out = torch.einsum('gok,bgkp->bgop', wgt, col)
         return out.reshape(b, self.out_channels, h, w)
 

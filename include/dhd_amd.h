@@ -331,6 +331,20 @@ int dhd_bin_bce_backward(const float* pred, const int16_t* bin, const int16_t* f
                          int hw, float weight, const float* grad_loss, const void* workspace,
                          float* grad_pred, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * 7. Deformable-convolution sampling for HeightNet / DepthNet's DCN layer
+ *    (models/necks/depthnet.py:225-236, :466-477 -> mmcv-full 1.5.3 DeformConv2dPack, v1,
+ *    stride 1, one deformable group).  x (B,C,H,W), offset (B, 2*k*k, H, W) with channel 2t =
+ *    dy and 2t+1 = dx of tap t = ky*k + kx;  col (B, C*k*k, H*W), row c*k*k + t: the im2col
+ *    matrix of the sampled values, to be multiplied by the layer's weight.
+ * ------------------------------------------------------------------------------------ */
+int dhd_deform_im2col(const float* x, const float* offset, float* col, int b, int c, int h, int w,
+                      int k, int pad, int dil, void* stream);
+/* dcol -> dx (B,C,H,W) and doffset (B, 2*k*k, H, W), both overwritten.  H*W*4 must be <= 48 KiB. */
+int dhd_deform_col2im(const float* dcol, const float* x, const float* offset, float* dx,
+                      float* doffset, int b, int c, int h, int w, int k, int pad, int dil,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

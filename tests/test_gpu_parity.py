@@ -696,3 +696,30 @@ def test_height_and_depth_loss_vs_torch_mirror_full_size(gpu):
     for a, b in ((a_h, b_h), (a_d, b_d)):
         scale = b.grad.abs().max().item()
         assert (a.grad - b.grad).abs().max().item() <= 1e-5 * scale
+
+
+# --------------------------------------------------------------------------- DCN sampling (HeightNet / DepthNet, a12)
+
+@pytest.mark.parametrize('c,groups,h,w,dil,scale', [(16, 4, 16, 44, 1, 0.5), (8, 1, 7, 9, 2, 3.0), (64, 4, 32, 88, 1, 8.0)])
+def test_dcn_hip_sampling_vs_grid_sample_formulation(gpu, c, groups, h, w, dil, scale):
+    """dhd_deform_im2col / dhd_deform_col2im against the grid_sample formulation of the same layer: output,
+    input gradient, offset-branch gradients and weight gradient; large offsets put samples outside the image."""
+    import copy
+    from dhd_amd.depthnet import DCN
+    torch.manual_seed(c + h)
+    a = DCN(c, 2 * c, kernel_size=3, padding=dil, dilation=dil, groups=groups).to(gpu)
+    with torch.no_grad():
+        a.conv_offset.weight.normal_(0, 0.05 * scale)
+        a.conv_offset.bias.normal_(0, scale)
+    b = copy.deepcopy(a)
+    b.use_hip = False
+    x = torch.randn(3, c, h, w, device=gpu)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = a(xa), b(xb)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    assert (ya - yb).abs().max().item() < 1e-4 * max(1.0, yb.abs().max().item())
+    assert (xa.grad - xb.grad).abs().max().item() < 2e-4 * max(1.0, xb.grad.abs().max().item())
+    for (k, p), q in zip(a.named_parameters(), b.parameters()):
+        assert (p.grad - q.grad).abs().max().item() < 5e-4 * max(1.0, q.grad.abs().max().item()), k
