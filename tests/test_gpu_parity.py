@@ -212,6 +212,36 @@ def test_view_transform_channel_counts_vs_oracle(gpu, channels):
     np.testing.assert_allclose(grads[1], fg, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('name,input_size', [('DHD-M', (256, 704)), ('DHD-L', (512, 1408))])
+def test_dhd_m_and_l_geometry_vs_oracle(gpu, name, input_size):
+    """BASELINE configs 4/5 geometry (DHD-M.py / DHD-L.py: depth bins 0.5 m -> D = 88; L: 512x1408 images ->
+    32x88 feature maps, 1.49 M frustum points per sample): voxel indices bit-exact, outputs and gradients
+    against the oracle."""
+    from dhd_amd import mghs_op
+    from oracle import mghs_oracle as O
+    cfg = syn.dhd_s_config()
+    cfg['input_size'] = input_size
+    cfg['grid_config'] = dict(cfg['grid_config'], depth=[1.0, 45.0, 0.5])
+    fh, fw = input_size[0] // 16, input_size[1] // 16
+    calib_np = syn.make_calibration(41, 1, 6, input_size)
+    depth, feat, hidx = syn.lift_inputs(42, 1, 6, 88, fh, fw, 64, 65)
+    plan, axes = make_plan(cfg, 1, 6)
+    assert plan.n_depth == 88 if hasattr(plan, 'n_depth') else True
+    calib, keep = device_calib(calib_np, axes, gpu)
+    coor = O.ego_coor(axes, calib_np[0], calib_np[2], calib_np[3], calib_np[4], calib_np[5])
+    for k, gcfg in enumerate(grid_cfgs(cfg)):
+        rank, _ = mghs_op.voxel_index(plan, calib, k)
+        assert np.array_equal(rank.cpu().numpy(), O.voxel_rank(coor, {a: gcfg[a] for a in 'xyz'})), k
+    outs, grads, _ = run_fused(gpu, cfg, calib_np, depth, feat, hidx, weights_seed=600)
+    ref = O.view_transform(cfg, calib_np, depth, feat, hidx)
+    for o, r in zip(outs, ref):
+        np.testing.assert_allclose(o, r, atol=5e-5, rtol=1e-5)
+    ws = [syn.hash_signed(600 + k, r.shape) for k, r in enumerate(ref)]
+    dg, fg = O.view_transform_backward(cfg, calib_np, depth, feat, hidx, ws)
+    np.testing.assert_allclose(grads[0], dg, atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(grads[1], fg, atol=5e-4, rtol=1e-5)
+
+
 @pytest.mark.parametrize('batch', [1, 2])
 def test_full_dhds_size_vs_reference(gpu, batch):
     """DHD-S, 6 cameras, 200x200x{1,4,4,8}: index hashes, sampled voxels, sums and gradients of the
