@@ -58,6 +58,8 @@ def parse():
     p.add_argument('--warmup', type=int, default=10)
     p.add_argument('--batch', type=int, default=4, help='samples per GPU (DHD-S.py:243 samples_per_gpu=4)')
     p.add_argument('--no-sfa', action='store_true', help='time the MGHS part only')
+    p.add_argument('--geometry', choices=['dhd-s', 'dhd-m', 'dhd-l'], default='dhd-s',
+                   help='view-transform geometry of the hot path: DHD-S (D=44, 16x44), DHD-M (D=88), DHD-L (D=88, 32x88 from 512x1408)')
     p.add_argument('--workload', choices=['hotpath', 'e2e', 'occ_loss'], default='hotpath',
                    help="hotpath: MGHS + SFA stage (default). e2e: the whole DHD-S detector (dense parts on MIOpen/hipBLASLt), "
                         "forward_train + backward + AdamW step, DDP over RCCL when --gpus > 1")
@@ -69,17 +71,23 @@ def parse():
 class HotPath:
     """Device-resident inputs + the exact C-ABI call sequence of MGHS.view_transform fwd/bwd."""
 
-    def __init__(self, dev, batch, seed, with_sfa):
+    GEOMETRY = {'dhd-s': ((256, 704), 1.0), 'dhd-m': ((256, 704), 0.5), 'dhd-l': ((512, 1408), 0.5)}  # input size, depth step
+
+    def __init__(self, dev, batch, seed, with_sfa, geometry='dhd-s'):
         self.dev, self.B = dev, batch
         cfg = self.cfg = syn.dhd_s_config()
-        N, D, fh, fw, C = 6, 44, 16, 44, 64
+        (ih, iw), dstep = self.GEOMETRY[geometry]
+        cfg['input_size'] = (ih, iw)
+        cfg['grid_config'] = dict(cfg['grid_config'], depth=[1.0, 45.0, dstep])
+        N, D, fh, fw, C = 6, int(round(44 / dstep)), ih // 16, iw // 16, 64
+        self.dims = (N, D, fh, fw, C)
         self.calib_np = syn.make_calibration(seed, batch, N, cfg['input_size'])
         depth, feat, hidx = syn.lift_inputs(seed + 1, batch, N, D, fh, fw, C, 65)
         self.inputs_np = (depth, feat, hidx)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        u = torch.linspace(0, 703, fw, dtype=torch.float)
-        v = torch.linspace(0, 255, fh, dtype=torch.float)
-        d = torch.arange(1.0, 45.0, 1.0, dtype=torch.float)
+        u = torch.linspace(0, iw - 1, fw, dtype=torch.float)
+        v = torch.linspace(0, ih - 1, fh, dtype=torch.float)
+        d = torch.arange(1.0, 45.0, dstep, dtype=torch.float)
         s2e, _, intrin, post_rot, post_tran, bda = [t(a) for a in self.calib_np]
         self.calib, self._keep = mghs_op.make_calib(s2e, intrin, post_rot, post_tran, bda,
                                                     (u.to(dev), v.to(dev), d.to(dev)))
@@ -310,7 +318,7 @@ def main():
         return run_e2e(a, rank, world, dev)
     if a.workload == 'occ_loss':
         return run_occ_loss(a, rank, world, dev)
-    hp = HotPath(dev, a.batch, 1000 + rank, not a.no_sfa)
+    hp = HotPath(dev, a.batch, 1000 + rank, not a.no_sfa, a.geometry)
 
     for _ in range(a.warmup):
         hp.step(False)
@@ -331,12 +339,12 @@ def main():
         kern_ms = float(np.mean([s.elapsed_time(e) for s, e in hp.ev]))
         achieved = hp.pool_fwd_bytes / (kern_ms * 1e-3) / 1e9
         line = dict(
-            metric='samples/sec (6-cam fwd+bwd) DHD-S view-transform hot path', value=a.batch * world * a.steps / elapsed,
+            metric=f'samples/sec (6-cam fwd+bwd) {a.geometry.upper()} view-transform hot path', value=a.batch * world * a.steps / elapsed,
             unit='samples/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps,
             higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-            config=dict(workload='DHD-S (configs[1]) hot path: MGHS 4-grid lift-splat fwd+bwd incl. geometry/grouping'
+            config=dict(workload=('DHD-S (configs[1])' if a.geometry == 'dhd-s' else a.geometry.upper() + ' geometry (configs[3-4])') + ' hot path: MGHS 4-grid lift-splat fwd+bwd incl. geometry/grouping'
                                  + ('' if a.no_sfa else ' + SFA attention stage fwd+bwd') +
-                                 '; 6 cams 256x704 -> 16x44, D=44, C=64, grids 200x200x{1,4,4,8}; dense backbone/encoder convs not in the step',
+                                 f'; geometry {a.geometry}: 6 cams -> {hp.dims[2]}x{hp.dims[3]}, D={hp.dims[1]}, C=64, grids 200x200x{{1,4,4,8}}; dense backbone/encoder convs not in the step',
                         samples_per_gpu=a.batch, global_batch=a.batch * world, parallelism=f'sample-sharded x{world}, no data-path collective'),
             roofline=dict(bound='hbm', kernel='mghs_stream_fwd', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s',
                           frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic('mghs_stream_fwd', a.batch), launch_ms=kern_ms,
