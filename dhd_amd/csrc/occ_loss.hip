@@ -366,3 +366,61 @@ int dhd_occ_loss_backward(const float* logits, const uint8_t* labels, const uint
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Evaluation side of the same logits: predictor.get_occ (occ_head.py:141-153: softmax -> argmax) and
+// Metric_mIoU.hist_info (core/evaluation/occ_metrics.py:79-104: 18x18 confusion counts over the
+// camera-visible voxels with a label in [0, 18)), in one pass over the (M,18) logits.
+// argmax of the logits = argmax of their softmax (first maximum wins); the two can differ only where
+// the two largest probabilities round to the same float.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(kBlock) void occ_argmax_hist(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
+                                                          const uint8_t* __restrict__ mask, long m, uint8_t* __restrict__ pred,
+                                                          unsigned long long* __restrict__ hist) {
+  __shared__ float tile[kBlock * K];
+  __shared__ unsigned cnt[K * K];
+  for (int i = threadIdx.x; i < K * K; i += kBlock) cnt[i] = 0;
+  const long n_tiles = (m + kBlock - 1) / kBlock;
+  for (long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    const long v0 = tl * kBlock;
+    const int n_in = (int)min((long)kBlock, m - v0);
+    __syncthreads();
+    load_tile(logits, v0, n_in, tile);
+    __syncthreads();
+    if ((int)threadIdx.x < n_in) {
+      const float* row = tile + threadIdx.x * K;
+      float best = row[0];
+      int arg = 0;
+#pragma unroll
+      for (int k = 1; k < K; ++k) {
+        const float z = row[k];
+        if (z > best) { best = z; arg = k; }
+      }
+      const long v = v0 + threadIdx.x;
+      if (pred) pred[v] = (uint8_t)arg;
+      if (hist) {
+        const int t = labels[v];
+        if (t < K && (mask == nullptr || mask[v] != 0)) atomicAdd(&cnt[t * K + arg], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (hist)
+    for (int i = threadIdx.x; i < K * K; i += kBlock)
+      if (cnt[i]) atomicAdd(&hist[i], (unsigned long long)cnt[i]);
+}
+
+}  // namespace
+
+extern "C" int dhd_occ_argmax_hist(const float* logits, const uint8_t* labels, const uint8_t* mask, int64_t n_voxels, int n_classes,
+                                   uint8_t* pred, int64_t* hist, void* stream) {
+  if (!logits || n_voxels <= 0 || (!pred && !hist) || (hist && !labels)) return DHD_EINVAL;
+  if (n_classes != K) return DHD_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(logits) & 15) != 0) return DHD_EINVAL;
+  hipLaunchKernelGGL(occ_argmax_hist, dim3(n_blocks_for(n_voxels)), dim3(kBlock), 0, dhd_stream(stream), logits, labels, mask,
+                     (long)n_voxels, pred, reinterpret_cast<unsigned long long*>(hist));
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}

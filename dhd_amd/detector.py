@@ -393,6 +393,10 @@ class predictor(nn.Module):
             loss_voxel_geo_scal=self.weight_geo * geo_scal_loss_with_mask(preds, sem, mask, non_empty_idx=17))
 
     def get_occ(self, occ_pred, img_metas=None):
+        from . import occ_loss
+        if occ_pred.is_cuda and occ_pred.shape[-1] == occ_loss.NUM_CLASSES:
+            pred, _ = occ_loss.occ_argmax_hist(occ_pred.float())  # argmax of the logits = argmax of their softmax
+            return list(pred.view(occ_pred.shape[:-1]).cpu().numpy())
         return list(occ_pred.softmax(-1).argmax(-1).cpu().numpy().astype(np.uint8))
 
 

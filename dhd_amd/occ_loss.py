@@ -72,3 +72,32 @@ def occ_losses(logits, labels, mask_camera, class_weight, ignore_index=255, non_
     out = _OccLosses.apply(logits.float(), labels, mask, class_weight.to(device=logits.device, dtype=torch.float32),
                            int(ignore_index), int(non_empty_idx))
     return out[0], out[1], out[2]
+
+
+def occ_argmax_hist(logits, labels=None, mask_camera=None, hist=None):
+    """predictor.get_occ + Metric_mIoU.hist_info in one pass: returns (pred (M,) uint8, hist (18,18) int64).
+    `hist` (device int64) is accumulated into when given; rows = ground truth, columns = prediction."""
+    logits = _lib.require_gpu_tensor(logits.reshape(-1, NUM_CLASSES).contiguous(), torch.float32, 'occupancy logits')
+    if logits.data_ptr() % 16:
+        logits = logits.clone()
+    m = logits.shape[0]
+    dev = logits.device
+    with torch.cuda.device(dev):
+        pred = torch.empty(m, dtype=torch.uint8, device=dev)
+        lab = msk = None
+        if labels is not None:
+            lab = labels.reshape(-1).to(torch.uint8).contiguous()
+            msk = None if mask_camera is None else mask_camera.reshape(-1).to(torch.uint8).contiguous()
+            if hist is None:
+                hist = torch.zeros(NUM_CLASSES, NUM_CLASSES, dtype=torch.int64, device=dev)
+        _lib.check(_lib.load().dhd_occ_argmax_hist(_lib.ptr(logits), _lib.ptr(lab), _lib.ptr(msk), m, NUM_CLASSES, _lib.ptr(pred),
+                                                   _lib.ptr(hist) if labels is not None else None, _lib.stream_ptr(dev)),
+                   'dhd_occ_argmax_hist')
+    return pred, hist
+
+
+def miou_from_hist(hist):
+    """Metric_mIoU.per_class_iu / count_miou (occ_metrics.py:106-108,159-167): mean IoU of the 17 semantic classes, in %."""
+    h = hist.double()
+    iu = torch.diag(h) / (h.sum(1) + h.sum(0) - torch.diag(h))
+    return float(torch.nanmean(iu[:NUM_CLASSES - 1]) * 100), iu

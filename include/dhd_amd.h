@@ -302,6 +302,13 @@ int dhd_occ_loss_backward(const float* logits, const uint8_t* labels, const uint
                           int non_empty_idx, const float* grad_losses, const void* workspace,
                           float* grad_logits, void* stream);
 
+/* Evaluation side: pred[v] = argmax_k logits[v,k] (predictor.get_occ, occ_head.py:141-153) and
+ * hist[t*18 + pred] += 1 for voxels with mask != 0 (mask may be NULL) and label t < 18
+ * (Metric_mIoU.hist_info, core/evaluation/occ_metrics.py:79-104).  hist is [dev] int64[324],
+ * ACCUMULATED into (zero it once per evaluation); pred or hist may be NULL. */
+int dhd_occ_argmax_hist(const float* logits, const uint8_t* labels, const uint8_t* mask,
+                        int64_t n_voxels, int n_classes, uint8_t* pred, int64_t* hist, void* stream);
+
 /* ------------------------------------------------------------------------------------ *
  * 6. Height / depth supervision of the view transformer (row a16):
  *    MGHS.get_height_loss (models/necks/lss_heightmap.py:595-622), its label builders

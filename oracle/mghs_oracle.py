@@ -532,3 +532,18 @@ def occ_losses(logits, labels, mask_camera, class_weights, ignore_index=255, non
     loss_geo = (_nll_clamped(inter / ((1 - empty).sum() + 1e-5)) + _nll_clamped(inter / (nonempty_t.sum() + 1e-5)) +
                 _nll_clamped(((1 - nonempty_t) * empty).sum() / ((1 - nonempty_t).sum() + 1e-5)))
     return loss_occ, loss_sem, loss_geo
+
+
+def occ_confusion(logits, labels, mask_camera, n_cls=18):
+    """predictor.get_occ (occ_head.py:141-153) + Metric_mIoU.hist_info (occ_metrics.py:79-104):
+    pred = argmax softmax(logits); hist[gt, pred] over camera-visible voxels with 0 <= gt < n_cls."""
+    z = logits.astype(np.float64)
+    p = np.exp(z - z.max(1, keepdims=True))
+    pred = (p / p.sum(1, keepdims=True)).argmax(1)
+    cam = mask_camera.astype(bool)
+    gt, pr = labels[cam], pred[cam]
+    k = (gt >= 0) & (gt < n_cls)
+    hist = np.bincount(n_cls * gt[k].astype(int) + pr[k].astype(int), minlength=n_cls ** 2).reshape(n_cls, n_cls)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        iu = np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
+    return pred.astype(np.uint8), hist, iu

@@ -672,6 +672,26 @@ def test_occ_losses_vs_torch_autograd(gpu, m):
     assert (a.grad - b.grad).abs().max().item() <= 1e-4 * scale + 1e-9
 
 
+def test_occ_argmax_and_confusion_histogram_vs_oracle(gpu):
+    """dhd_occ_argmax_hist: predictions and the 18x18 confusion counts exactly equal to the oracle's
+    (get_occ + Metric_mIoU.hist_info); accumulation over two calls; mIoU from the histogram."""
+    from dhd_amd.occ_loss import miou_from_hist, occ_argmax_hist
+    from oracle import mghs_oracle as O
+    m = 200 * 200 * 16 + 37
+    z = syn.hash_signed(71, (m, 18)) * 3.0
+    t = (syn.hash_u32(72, m) % 18).astype(np.int64)
+    t[::101] = 255
+    cam = (syn.hash_uniform(73, (m,)) < 0.35)
+    pred, hist = occ_argmax_hist(T(z, gpu), T(t, gpu), T(cam, gpu))
+    p_ref, h_ref, iu_ref = O.occ_confusion(z, t, cam)
+    assert np.array_equal(pred.cpu().numpy(), p_ref)
+    assert np.array_equal(hist.cpu().numpy(), h_ref)
+    _, hist = occ_argmax_hist(T(z, gpu), T(t, gpu), T(cam, gpu), hist=hist)
+    assert np.array_equal(hist.cpu().numpy(), 2 * h_ref)
+    miou, iu = miou_from_hist(hist)
+    assert abs(miou - float(np.nanmean(iu_ref[:17]) * 100)) < 1e-9
+
+
 # --------------------------------------------------------------------------- height / depth supervision (a16)
 
 def test_height_loss_labels_and_value_vs_reference_golden(gpu):
