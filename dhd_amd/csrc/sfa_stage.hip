@@ -1276,6 +1276,24 @@ inline int pw_cot(int c) { return (DHD_PW_COT_SEL == 8 && c % 256 == 0) ? 8 : 4;
 
 inline bool stage_supported(int c, int hw) { return (c == 128 || (c > 0 && c % 256 == 0)) && hw > 0 && (hw & 3) == 0; }
 
+// hipFuncSetAttribute is not a stream operation: doing it on every launch breaks stream capture (HIP graphs),
+// so each kernel instantiation raises its dynamic-LDS limit once per device, on first use.
+inline int device_index() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d < 0 || d >= 64 ? 0 : d;
+}
+#define DHD_LDS_ATTR_ONCE(kern, bytes)                                                                              \
+  do {                                                                                                              \
+    static bool done__[64] = {};                                                                                    \
+    const int dev__ = device_index();                                                                               \
+    if (!done__[dev__]) {                                                                                           \
+      DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                  (int)(bytes)));                                                                   \
+      done__[dev__] = true;                                                                                         \
+    }                                                                                                               \
+  } while (0)
+
 int g_gemm_mode = 1;  // 1: bf16x6 split on the bf16 MFMA (default), 0: f32 MFMA
 
 int launch_pack(const float* w, int transpose, float* packed, int c, hipStream_t st) {
@@ -1304,14 +1322,12 @@ int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in
   do {                                                                                                                 \
     if (g_gemm_mode == 1) {                                                                                            \
       auto kern = pw_gemm6_kernel<COT, TWO, RELU, EPI>;                                                                \
-      DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                  (int)shmem));                                                                        \
+      DHD_LDS_ATTR_ONCE(kern, shmem);                    \
       hipLaunchKernelGGL(kern, grid, dim3(kPwBlock), shmem, st, in0, in1, in_bstride, in_bytes, coef,                  \
                          reinterpret_cast<const u32x4*>(wp), bias, relu_mask, stat_part, y, c, hw);                           \
     } else {                                                                                                           \
       auto kern = pw_gemm_kernel<COT, TWO, RELU, EPI>;                                                                 \
-      DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                  (int)shmem));                                                                        \
+      DHD_LDS_ATTR_ONCE(kern, shmem);                    \
       hipLaunchKernelGGL(kern, grid, dim3(kPwBlock), shmem, st, in0, in1, in_bstride, coef, wp, bias, aux, aux_scsh, y, \
                          c, hw);                                                                                       \
     }                                                                                                                  \
@@ -1343,8 +1359,7 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
 #define DHD_WG(OT, ATWO, BTWO, BRELU)                                                                              \
   do {                                                                                                             \
     auto kern = pw_wgrad_kernel<OT, ATWO, BTWO, BRELU>;                                                            \
-    DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                (int)shmem));                                                                      \
+    DHD_LDS_ATTR_ONCE(kern, shmem);                    \
     hipLaunchKernelGGL(kern, grid, dim3(kWgBlock), shmem, st, a0, a1, acoef, a_bs, b0, b1, bcoef, b_bs, partial, c, \
                        hw, b, workers);                                                                            \
   } while (0)
@@ -1355,8 +1370,7 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
 #define DHD_WG6(OT, ATWO, BTWO, BRELU)                                                                             \
   do {                                                                                                             \
     auto kern = pw_wgrad6_kernel<OT, ATWO, BTWO, BRELU>;                                                           \
-    DHD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                (int)shmem6));                                                                     \
+    DHD_LDS_ATTR_ONCE(kern, shmem6);                    \
     hipLaunchKernelGGL(kern, grid, dim3(kWgBlock), shmem6, st, a0, a1, acoef, a_bs, b0, b1, bcoef, b_bs, partial,  \
                        c, hw, b, workers);                                                                         \
   } while (0)

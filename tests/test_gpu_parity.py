@@ -616,6 +616,53 @@ def test_mghs_step_is_graph_capturable(gpu):
     assert torch.allclose(cap[1], ref[1], atol=1e-4) and torch.allclose(cap[2], 2 * ref[2], atol=1e-3, rtol=1e-4)
 
 
+def test_sfa_stage_and_losses_are_graph_capturable(gpu):
+    """The stage operator (forward + backward) and the occupancy losses inside a HIP graph: every launch is
+    asynchronous on the capture stream (kernels + hipMemsetAsync only), replay with new input values."""
+    from dhd_amd.mix import channel_spatial_stage
+    from dhd_amd.occ_loss import occ_losses
+    torch.manual_seed(11)
+    st = channel_spatial_stage(256).to(gpu).train()
+    x = torch.randn(2, 256, 20, 24, device=gpu, requires_grad=True)
+    gy = torch.randn(2, 128, 20, 24, device=gpu)
+    z = torch.randn(3000, 18, device=gpu, requires_grad=True)
+    t = torch.randint(0, 18, (3000,), device=gpu).to(torch.uint8)
+    cam = (torch.rand(3000, device=gpu) < 0.5).to(torch.uint8)
+    cw = T(_class_weights(), gpu)
+
+    def step():
+        for p in list(st.parameters()) + [x, z]:
+            p.grad = None
+        y = st(x)
+        y.backward(gy)
+        sum(occ_losses(z, t, cam, cw)).backward()
+        return y, x.grad, z.grad, st.spacial_leanring[0].weight.grad
+
+    sd = {k: v.clone() for k, v in st.state_dict().items()}
+    # detached copies: holding a grad-tracking output of an earlier eager step while capturing forward+backward
+    # segfaults in PyTorch-ROCm 2.10 even with plain conv layers (experiments/dbg_graph2.py)
+    ref = [a.detach().clone() for a in step()]
+    st.load_state_dict(sd)  # running statistics back to their initial values
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cap = step()
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(cap, ref):
+        assert torch.allclose(a, b, atol=1e-5, rtol=1e-4)
+    with torch.no_grad():
+        x.mul_(0.5)
+    g.replay()
+    torch.cuda.synchronize()
+    assert not torch.allclose(cap[0], ref[0], atol=1e-3)
+
+
 # --------------------------------------------------------------------------- occupancy-head losses (8f-2)
 
 def _class_weights():
