@@ -167,3 +167,67 @@ int dhd_bin_bce_backward(const float* pred, const int16_t* bin, const int16_t* f
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// LiDAR points -> sparse per-camera depth / height maps (the dataloader-side label step,
+// datasets/pipelines/loading_new.py:35-99: PointToMultiViewDepthandHeight.points2depthmap /
+// points2heightmap).  The reference sorts all points by the float32 key  pixel_rank + d/100  and keeps the
+// first point of every pixel; here that is a z-buffer: one 64-bit atomicMin per point on
+// (key bits << 32 | point index), then one thread per pixel writes the winner's depth and height.  Equal keys
+// (depths closer than the float32 spacing at that rank) resolve to the lowest point index = a stable sort;
+// the reference's unstable argsort may keep any of the tied points there.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(kBlock) void raster_min_kernel(const float* __restrict__ pts, int n_pts, int h, int w, float inv_ds_div,
+                                                            float d_lo, float d_hi, unsigned long long* __restrict__ zbuf) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int cam = blockIdx.y;
+  if (i >= n_pts) return;
+  const float* p = pts + ((size_t)cam * n_pts + i) * 4;
+  const float cu = rintf(__fdiv_rn(p[0], inv_ds_div)), cv = rintf(__fdiv_rn(p[1], inv_ds_div));  // torch.round: half to even
+  const float d = p[2];
+  if (!(cu >= 0.f && cu < (float)w && cv >= 0.f && cv < (float)h && d < d_hi && d >= d_lo)) return;
+  const float rank = __fadd_rn(cu, __fmul_rn(cv, (float)w));
+  const float key = __fadd_rn(rank, __fdiv_rn(d, 100.0f));  // positive: the bit pattern orders like the value
+  const unsigned long long packed = ((unsigned long long)__float_as_uint(key) << 32) | (unsigned)i;
+  atomicMin(zbuf + (size_t)cam * h * w + (size_t)((int)cv * w + (int)cu), packed);
+}
+
+__global__ __launch_bounds__(kBlock) void raster_write_kernel(const float* __restrict__ pts, int n_pts, int hw,
+                                                              const unsigned long long* __restrict__ zbuf,
+                                                              float* __restrict__ depth_map, float* __restrict__ height_map) {
+  const int px = blockIdx.x * kBlock + threadIdx.x;
+  const int cam = blockIdx.y;
+  if (px >= hw) return;
+  const unsigned long long z = zbuf[(size_t)cam * hw + px];
+  float d = 0.f, hv = 0.f;
+  if (z != ~0ull) {
+    const float* p = pts + ((size_t)cam * n_pts + (unsigned)(z & 0xffffffffull)) * 4;
+    d = p[2];
+    hv = p[3];
+  }
+  depth_map[(size_t)cam * hw + px] = d;
+  height_map[(size_t)cam * hw + px] = hv;
+}
+
+}  // namespace
+
+extern "C" int dhd_points_to_maps(const float* points, int n_cams, int n_points, int height, int width, int downsample, float depth_lo,
+                                  float depth_hi, float* depth_map, float* height_map, void* zbuffer, void* stream) {
+  if ((!points && n_points > 0) || !depth_map || !height_map || !zbuffer || n_cams <= 0 || n_points < 0 || height <= 0 || width <= 0 ||
+      downsample <= 0)
+    return DHD_EINVAL;
+  const int h = height / downsample, w = width / downsample;
+  if (h <= 0 || w <= 0 || (long)h * w >= (1L << 24)) return DHD_EUNSUPPORTED;  // pixel ranks must be exact in float32
+  hipStream_t st = dhd_stream(stream);
+  unsigned long long* zb = static_cast<unsigned long long*>(zbuffer);
+  DHD_HIP(hipMemsetAsync(zb, 0xff, (size_t)n_cams * h * w * sizeof(unsigned long long), st));
+  if (n_points > 0)
+    hipLaunchKernelGGL(raster_min_kernel, dim3(dhd_cdiv(n_points, kBlock), n_cams), dim3(kBlock), 0, st, points, n_points, h, w,
+                       (float)downsample, depth_lo, depth_hi, zb);
+  hipLaunchKernelGGL(raster_write_kernel, dim3(dhd_cdiv((long)h * w, kBlock), n_cams), dim3(kBlock), 0, st, points, n_points, h * w, zb,
+                     depth_map, height_map);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}

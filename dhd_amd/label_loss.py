@@ -60,3 +60,22 @@ class _BinBCE(torch.autograd.Function):
 
 def fg_bce(pred, bin_idx, fg_bin, weight):
     return _BinBCE.apply(pred.float(), bin_idx, fg_bin, float(weight))
+
+
+def points_to_maps(points, height, width, downsample=1, depth_range=(1.0, 45.0)):
+    """PointToMultiViewDepthandHeight.points2depthmap / points2heightmap (loading_new.py:35-99) for all cameras at once:
+    points (n_cams, n_points, 4) = (u, v, d, h) -> (gt_depth, gt_height), each (n_cams, H/ds, W/ds)."""
+    points = _lib.require_gpu_tensor(points.contiguous(), torch.float32, 'projected points')
+    if points.dim() != 3 or points.shape[2] != 4:
+        raise _lib.DhdError('points must be (n_cams, n_points, 4)')
+    n_cams, n_pts = points.shape[:2]
+    h, w = height // downsample, width // downsample
+    dev = points.device
+    with torch.cuda.device(dev):
+        dm = torch.empty((n_cams, h, w), dtype=torch.float32, device=dev)
+        hm = torch.empty_like(dm)
+        zbuf = torch.empty(n_cams * h * w, dtype=torch.int64, device=dev)
+        _lib.check(_lib.load().dhd_points_to_maps(_lib.ptr(points), n_cams, n_pts, height, width, downsample, float(depth_range[0]),
+                                                  float(depth_range[1]), _lib.ptr(dm), _lib.ptr(hm), _lib.ptr(zbuf), _lib.stream_ptr(dev)),
+                   'dhd_points_to_maps')
+    return dm, hm

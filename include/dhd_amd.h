@@ -352,6 +352,16 @@ int dhd_deform_col2im(const float* dcol, const float* x, const float* offset, fl
                       float* doffset, int b, int c, int h, int w, int k, int pad, int dil,
                       void* stream);
 
+/* LiDAR points -> sparse depth / height maps, all cameras of a sample at once
+ * (datasets/pipelines/loading_new.py:35-99, PointToMultiViewDepthandHeight.points2depthmap /
+ * points2heightmap).  points: (n_cams, n_points, 4) = (u, v, d, h) in augmented image coordinates;
+ * maps: (n_cams, height/downsample, width/downsample), 0 where no point lands.  A pixel keeps the
+ * point with the smallest float32 key  pixel_rank + d/100  (ties: lowest index).  zbuffer: scratch of
+ * n_cams * h * w * 8 bytes.  Points outside the image or outside [depth_lo, depth_hi) are ignored. */
+int dhd_points_to_maps(const float* points, int n_cams, int n_points, int height, int width,
+                       int downsample, float depth_lo, float depth_hi, float* depth_map,
+                       float* height_map, void* zbuffer, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -547,3 +547,46 @@ def occ_confusion(logits, labels, mask_camera, n_cls=18):
     with np.errstate(divide='ignore', invalid='ignore'):
         iu = np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
     return pred.astype(np.uint8), hist, iu
+
+
+# ---------------------------------------------------------------------------------------------
+# LiDAR -> per-camera sparse depth / height maps (the label side before the hot path)
+# ---------------------------------------------------------------------------------------------
+
+def points_to_maps(points, height, width, downsample=1, depth_range=(1.0, 45.0), return_ties=False):
+    """PointToMultiViewDepthandHeight.points2depthmap / points2heightmap
+    (datasets/pipelines/loading_new.py:35-99): points (N,4) = (u, v, d, h) in augmented image coordinates.
+    Pixel = round-half-even(uv / downsample); among the points of a pixel the one with the smallest float32 key
+    pixel_rank + d/100 wins (the reference sorts by that key and keeps the first of each pixel; equal keys --
+    depths closer than the float32 spacing at the rank, up to ~1.5 m at the bottom of a 256x704 image -- keep
+    their input order here, i.e. a stable sort; the reference's torch.argsort is NOT stable, so at such pixels it
+    may keep any of the tied points: `return_ties` adds the mask of pixels whose winning key is shared).
+    Returns (depth_map, height_map, height_mask[, tie_mask])."""
+    h, w = height // downsample, width // downsample
+    pts = points.astype(f32)
+    cu = np.rint(pts[:, 0] / f32(downsample)).astype(f32)
+    cv = np.rint(pts[:, 1] / f32(downsample)).astype(f32)
+    d = pts[:, 2]
+    kept = (cu >= 0) & (cu < w) & (cv >= 0) & (cv < h) & (d < f32(depth_range[1])) & (d >= f32(depth_range[0]))
+    cu, cv, d, hv = cu[kept], cv[kept], d[kept], pts[kept, 3]
+    ranks = (cu + cv * f32(w)).astype(f32)
+    key = (ranks + d / f32(100.0)).astype(f32)
+    order = np.argsort(key, kind='stable')
+    cu, cv, d, hv, ranks = cu[order], cv[order], d[order], hv[order], ranks[order]
+    first = np.ones(len(ranks), bool)
+    first[1:] = ranks[1:] != ranks[:-1]
+    x, y = cu[first].astype(np.int64), cv[first].astype(np.int64)
+    depth_map = np.zeros((h, w), f32)
+    height_map = np.zeros((h, w), f32)
+    mask = np.zeros((h, w), bool)
+    depth_map[y, x] = d[first]
+    height_map[y, x] = hv[first]
+    mask[y, x] = True
+    if return_ties:
+        key = key[order]
+        tied = np.zeros(len(ranks), bool)
+        tied[:-1] = first[:-1] & (key[1:] == key[:-1]) & (ranks[1:] == ranks[:-1])
+        ties = np.zeros((h, w), bool)
+        ties[cv[tied].astype(np.int64), cu[tied].astype(np.int64)] = True
+        return depth_map, height_map, mask, ties
+    return depth_map, height_map, mask

@@ -795,6 +795,30 @@ def test_height_and_depth_loss_vs_torch_mirror_full_size(gpu):
         assert (a.grad - b.grad).abs().max().item() <= 1e-5 * scale
 
 
+def test_rasterise_points_vs_oracle_and_reference_golden(gpu):
+    """dhd_points_to_maps: bit-identical to the oracle (stable-sort semantics) on the golden G7 points and on a
+    6-camera, 34 k-point, 256x704 case; against the reference's own maps everywhere except the tie pixels."""
+    from dhd_amd.label_loss import points_to_maps
+    from oracle import mghs_oracle as O
+    g = golden('g7_rasterise')
+    h, w = (int(v) for v in g['size'])
+    dm, hm = points_to_maps(T(g['points'][None], gpu), h, w, 1, tuple(g['depth_range']))
+    odm, ohm, omk, ties = O.points_to_maps(g['points'], h, w, 1, tuple(g['depth_range']), return_ties=True)
+    assert np.array_equal(dm[0].cpu().numpy(), odm) and np.array_equal(hm[0].cpu().numpy(), ohm)
+    ok = ~ties
+    assert np.array_equal(dm[0].cpu().numpy()[ok], g['depth_map'][ok]) and np.array_equal(hm[0].cpu().numpy()[ok], g['height_map'][ok])
+    n = 34000
+    pts = np.stack([syn.hash_uniform(81, (6, n)) * 720 - 8, syn.hash_uniform(82, (6, n)) * 270 - 7,
+                    syn.hash_uniform(83, (6, n)) * 60.0, syn.hash_signed(84, (6, n)) * 5.0], -1).astype(np.float32)
+    for ds in (1, 2):
+        dm, hm = points_to_maps(T(pts, gpu), 256, 704, ds)
+        for c in range(6):
+            odm, ohm, _ = O.points_to_maps(pts[c], 256, 704, ds)
+            assert np.array_equal(dm[c].cpu().numpy(), odm) and np.array_equal(hm[c].cpu().numpy(), ohm), (ds, c)
+    dm, hm = points_to_maps(T(pts[:, :0], gpu), 256, 704, 1)   # no points: all-zero maps
+    assert float(dm.abs().sum()) == 0.0 and float(hm.abs().sum()) == 0.0
+
+
 # --------------------------------------------------------------------------- DCN sampling (HeightNet / DepthNet, a12)
 
 @pytest.mark.parametrize('c,groups,h,w,dil,scale', [(16, 4, 16, 44, 1, 0.5), (8, 1, 7, 9, 2, 3.0), (64, 4, 32, 88, 1, 8.0)])

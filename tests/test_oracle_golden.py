@@ -161,3 +161,20 @@ def test_occupancy_losses_oracle_vs_reference_code():
     keep = cam & (t != 255)
     ce = -(lp[keep, t[keep]] * cw[t[keep]]).sum() / sum((t[cam] == i).sum() * float(cw[i]) for i in range(18))
     assert abs(l_ce - ce) < 1e-9
+
+
+def test_rasterise_oracle_vs_reference_code():
+    """oracle.points_to_maps against golden G7 (recorded from the reference's PointToMultiViewDepthandHeight):
+    identical everywhere except where the winning sort key is shared by several points (the reference's unstable
+    argsort keeps an arbitrary one of them), and there the reference's value is one of the tied points."""
+    g = golden('g7_rasterise')
+    h, w = (int(v) for v in g['size'])
+    dm, hm, mk, ties = O.points_to_maps(g['points'], h, w, 1, tuple(g['depth_range']), return_ties=True)
+    assert np.array_equal(mk, g['height_mask']) and mk.sum() > 3000
+    ok = ~ties
+    assert np.array_equal(dm[ok], g['depth_map'][ok]) and np.array_equal(hm[ok], g['height_map'][ok])
+    assert 0 < ties.sum() < 10
+    p = g['points']
+    for y, x in np.argwhere(ties):
+        cand = p[(np.rint(p[:, 0]) == x) & (np.rint(p[:, 1]) == y)]
+        assert any(c[2] == g['depth_map'][y, x] and c[3] == g['height_map'][y, x] for c in cand)
