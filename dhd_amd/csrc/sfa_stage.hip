@@ -758,7 +758,11 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
   const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((TWO_IN ? in1 : in0) + (size_t)b * in_bstride), 0, in_bytes, 0x00020000);
   const int voff = (pc + 8 * h * hw) * 4;
   const int row_bytes = hw * 4;
-  float raw0[3][8], raw1[3][8];
+  // Two register sets; the loads of step k+2 are issued into a set right after the prologue of step k has
+  // consumed it.  Everything in the loop is unconditional (addresses clamped, kcn even, unrolled by two): a
+  // conditional load or step makes the compiler copy loaded registers at the control-flow merge, and a copy
+  // waits for its load -- that silently shortened the lookahead of an earlier three-set version to one step.
+  float raw0[2][8], raw1[2][8];
   auto issue = [&](auto set, int kc) {
     constexpr int S = decltype(set)::value;
     const int so = 16 * kc * row_bytes;
@@ -770,9 +774,8 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
   issue(I0{}, 0);
-  if (kcn > 1) issue(I1{}, 1);
+  issue(I1{}, 1);
   __syncthreads();
 
   f32x16 acc[COT];
@@ -781,7 +784,7 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-  auto step = [&](auto cset, auto lset, int kc) {
+  auto step = [&](auto cset, int kc) {
     constexpr int CS = decltype(cset)::value;
     u32x4 ah, am, al;
     {
@@ -822,12 +825,12 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
         ah[jp] = hh; am[jp] = mm; al[jp] = ll;
       }
     }
-    const bool more = (kc + 1 < kcn) && !(PWABL & 1);
-    if (more) {
+    // next weight image (after the last step: a harmless reload that nobody reads)
+    if (!(PWABL & 1)) {
 #pragma unroll
-      for (int j = 0; j < kWst; ++j) wst[j] = wsrc[(size_t)(kc + 1) * kImg + j * kPwBlock + tid];
+      for (int j = 0; j < kWst; ++j) wst[j] = wsrc[(size_t)min(kc + 1, kcn - 1) * kImg + j * kPwBlock + tid];
     }
-    if (kc + 2 < kcn && !(PWABL & 4)) issue(lset, kc + 2);
+    if (!(PWABL & 4)) issue(cset, min(kc + 2, kcn - 1));  // past the end: a harmless reload of the last step
     const u32x4* img = lds6 + (kc & 1) * kImg + lane;
 #pragma unroll
     for (int t = 0; t < COT; t += 2) {
@@ -847,17 +850,16 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
       acc[t] = mfma_bf16(ah, bh0, acc[t]);
       acc[t + 1] = mfma_bf16(ah, bh1, acc[t + 1]);
     }
-    if (more) {
+    if (!(PWABL & 1)) {
       u32x4* dst = lds6 + ((kc + 1) & 1) * kImg;
 #pragma unroll
       for (int j = 0; j < kWst; ++j) dst[j * kPwBlock + tid] = wst[j];
     }
     if (!(PWABL & 1)) __syncthreads();
   };
-  for (int kc = 0; kc < kcn; kc += 3) {
-    step(I0{}, I2{}, kc);
-    if (kc + 1 < kcn) step(I1{}, I0{}, kc + 1);
-    if (kc + 2 < kcn) step(I2{}, I1{}, kc + 2);
+  for (int kc = 0; kc < kcn; kc += 2) {
+    step(I0{}, kc);
+    step(I1{}, kc + 1);
   }
 
   // acc[t][4q + e] = pixel p0 + 8q + 4h + e, channel rb*32*COT + 32t + r
@@ -1155,13 +1157,15 @@ __global__ __launch_bounds__(kWgBlock, 2) void pw_wgrad6_kernel(const float* __r
   if (s0 < s1) {
     fetch(s0);
     stage(s0, 0);
-    if (s0 + 1 < s1) fetch(s0 + 1);
+    fetch(min(s0 + 1, s1 - 1));
   }
   __syncthreads();
   for (int s = s0; s < s1; ++s) {
     const int buf = (s - s0) & 1;
-    if (s + 1 < s1) stage(s + 1, buf ^ 1);
-    if (s + 2 < s1) fetch(s + 2);
+    // unconditional (indices clamped to the last step, whose re-staged copy nobody reads): a conditional fetch
+    // would make the compiler copy the loaded registers at the merge point, and such a copy waits for the load
+    stage(min(s + 1, s1 - 1), buf ^ 1);
+    fetch(min(s + 2, s1 - 1));
     const u32x4* ta = ldsw + (buf * 2) * kOp + lane;
     const u32x4* tb = ta + kOp;
     u32x4 fb[TB][3];
@@ -1298,7 +1302,7 @@ int g_gemm_mode = 1;  // 1: bf16x6 split on the bf16 MFMA (default), 0: f32 MFMA
 
 int launch_pack(const float* w, int transpose, float* packed, int c, hipStream_t st) {
   const int cot = pw_cot(c);
-  if (g_gemm_mode == 1)
+  if (g_gemm_mode >= 1)
     hipLaunchKernelGGL(pack_weight6_kernel, dim3(dhd_cdiv((c / 32) * (c / 16) * 64, kEwBlock)), dim3(kEwBlock), 0, st, w, transpose,
                        reinterpret_cast<u32x4*>(packed), c, cot);
   else
@@ -1316,11 +1320,11 @@ int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in
   const dim3 grid(tiles8 * (c / (32 * cot)), b);
   const bool two = in1 != nullptr;
   const unsigned in_bytes = (unsigned)((size_t)in_channels * hw * sizeof(float));  // one sample of in0 (and of in1, which follows it for x)
-  const size_t shmem = g_gemm_mode == 1 ? (size_t)2 * cot * 3 * 64 * 16 + (size_t)3 * c * sizeof(float)
+  const size_t shmem = g_gemm_mode >= 1 ? (size_t)2 * cot * 3 * 64 * 16 + (size_t)3 * c * sizeof(float)
                                         : (size_t)(2 * cot * 512 + 3 * c) * sizeof(float);
 #define DHD_PW(COT, TWO, RELU, EPI)                                                                                    \
   do {                                                                                                                 \
-    if (g_gemm_mode == 1) {                                                                                            \
+    if (g_gemm_mode >= 1) {                                                                                            \
       auto kern = pw_gemm6_kernel<COT, TWO, RELU, EPI>;                                                                \
       DHD_LDS_ATTR_ONCE(kern, shmem);                    \
       hipLaunchKernelGGL(kern, grid, dim3(kPwBlock), shmem, st, in0, in1, in_bstride, in_bytes, coef,                  \
@@ -1365,7 +1369,7 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
   } while (0)
   const bool btwo = b1 != nullptr;
   if (a1 == nullptr) return DHD_EUNSUPPORTED;
-  if (g_gemm_mode == 1) {
+  if (g_gemm_mode >= 1) {
     const size_t shmem6 = (size_t)2 * 2 * (ot / 32) * 3 * 64 * 16;
 #define DHD_WG6(OT, ATWO, BTWO, BRELU)                                                                             \
   do {                                                                                                             \
@@ -1439,7 +1443,7 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
   float* sc = static_cast<float*>(scratch);
   const dim3 planes2(kPlaneChunks, b * 2 * c), planes(kPlaneChunks, b * c);
   const dim3 per_ch(dhd_cdiv(c, kEwBlock));
-  const bool fused_stats = w->training && g_gemm_mode == 1;  // BatchNorm sums come out of the GEMM epilogue
+  const bool fused_stats = w->training && g_gemm_mode >= 1;  // BatchNorm sums come out of the GEMM epilogue
   const int nwt = (hw + 31) / 32;
 
   hipLaunchKernelGGL(plane_mean_kernel, planes2, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw);
