@@ -64,6 +64,7 @@ def parse():
                    help="hotpath: MGHS + SFA stage (default). e2e: the whole DHD-S detector (dense parts on MIOpen/hipBLASLt), "
                         "forward_train + backward + AdamW step, DDP over RCCL when --gpus > 1")
     p.add_argument('--amp', choices=['off', 'bf16', 'fp16'], default='off', help='autocast dtype of the dense modules (e2e)')
+    p.add_argument('--model', choices=['dhd-s', 'dhd-m'], default='dhd-s', help='e2e: DHD-S (single frame) or DHD-M (temporal stereo)')
     p.add_argument('--cpu-samples', type=int, default=2, help='samples for the CPU baseline leg (0 = skip)')
     return p.parse_args()
 
@@ -140,11 +141,13 @@ class EndToEnd:
     """DHD-S exactly as projects/configs/DHD/DHD-S.py:42-155 (random init, synthetic 6-camera batch,
     SURVEY.md 8d config 2): forward_train -> sum of the four losses -> backward -> grad clip 5 -> AdamW."""
 
-    def __init__(self, dev, batch, seed, world, amp):
+    def __init__(self, dev, batch, seed, world, amp, model='dhd-s'):
         import dhd_amd
-        from dhd_amd.detector import dhd_s_model_cfg
+        from dhd_amd.detector import dhd_m_model_cfg, dhd_s_model_cfg
         torch.manual_seed(seed)
-        self.model = dhd_amd.build_detector(dhd_s_model_cfg()).to(dev).train()
+        # dhd-m: DHD-M.py (DHD_stereo: key frame + 1 adjacent + 1 stereo reference frame, D = 88, SFA with C = 512)
+        frames = 3 if model == 'dhd-m' else 1
+        self.model = dhd_amd.build_detector(dhd_m_model_cfg() if model == 'dhd-m' else dhd_s_model_cfg()).to(dev).train()
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         self.n_params = sum(p.numel() for p in self.params)
         self.net = self.model
@@ -154,9 +157,12 @@ class EndToEnd:
         self.opt = torch.optim.AdamW(self.params, lr=2e-4, weight_decay=1e-2, fused=True)  # DHD-S.py:262
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         N, H, W = 6, 256, 704
-        calib = [t(a) for a in syn.make_calibration(seed, batch, N, (H, W))]
+        per = [syn.make_calibration(seed + 7 * f, batch, N, (H, W)) for f in range(frames)]
+        calib = [t(np.concatenate([p[k] for p in per], 1)) for k in range(5)] + [t(per[0][5])]
+        for f in range(1, frames):  # the ego vehicle moves 0.8 m per frame
+            calib[1][:, f * N:(f + 1) * N, 0, 3] += 0.8 * f
         g = torch.Generator(device='cpu').manual_seed(seed)
-        imgs = torch.randn(batch, N, 3, H, W, generator=g).to(dev)
+        imgs = torch.randn(batch, N * frames, 3, H, W, generator=g).to(dev)
         sel = torch.rand(batch, N, H, W, generator=g) < 0.02
         self.kw = dict(
             img_inputs=[imgs] + calib,
@@ -187,7 +193,7 @@ class EndToEnd:
 
 
 def run_e2e(a, rank, world, dev):
-    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp)
+    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp, a.model)
     for _ in range(a.warmup):
         job.step(False)
 
@@ -204,11 +210,13 @@ def run_e2e(a, rank, world, dev):
     elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         print(json.dumps(dict(
-            metric='samples/sec (6-cam fwd+bwd) DHD-S end-to-end', value=a.batch * world * a.steps / elapsed, unit='samples/s',
+            metric=f'samples/sec (6-cam fwd+bwd) {a.model.upper()} end-to-end', value=a.batch * world * a.steps / elapsed, unit='samples/s',
             n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True,
             scaling='weak', vs_baseline=None, dtype={'off': 'f32', 'bf16': 'bf16', 'fp16': 'f16'}[a.amp], data='synthetic',
-            config=dict(workload='DHD-S (configs[1]/[2]) whole detector: ResNet-50 + FPN, MGHS (HIP), BEV encoder, 3 UNets, SFA '
-                                 '(HIP stage), predictor + losses; forward_train + backward + grad-clip + AdamW; random init',
+            config=dict(workload=('DHD-M (DHD_stereo: key + adjacent + stereo reference frame, D=88) whole detector' if a.model == 'dhd-m'
+                                  else 'DHD-S (configs[1]/[2]) whole detector') +
+                                 ': ResNet-50 + FPN, MGHS (HIP), BEV encoder, 3 UNets, SFA (HIP stage), predictor + losses (HIP); '
+                                 'forward_train + backward + grad-clip + AdamW; random init',
                         samples_per_gpu=a.batch, global_batch=a.batch * world, params=job.n_params,
                         parallelism=f'DDP x{world} (RCCL bucketed all-reduce overlapped with backward)' if world > 1 else 'single GPU',
                         final_loss=float(loss)))), flush=True)

@@ -93,6 +93,11 @@ class ResNet(nn.Module):
                 outs.append(x)
         return tuple(outs)
 
+    def forward_first_stage(self, x):
+        """Stem + first residual stage only: the stereo reference feature of BEVStereo4D (bevstereo4d.py:29-40)."""
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        return getattr(self, self.res_layers[0])(x)
+
 
 class ConvModule(nn.Module):
     """conv (+ BN) (+ ReLU); the convolution lives under `.conv`, the norm under `.bn` (mmcv layout)."""
@@ -502,6 +507,160 @@ class DHD(nn.Module):
         return self.forward_train(**kwargs) if return_loss else self.simple_test(**kwargs)
 
 
+@DETECTORS.register_module()
+class DHD_stereo(DHD):
+    """The temporal-stereo detector of DHD-M / DHD-L (models/detectors/DHD_model.py:245-666 on top of
+    bevstereo4d.py:11-140 and bevdet4d.py:21-300): the key frame and `num_adj` adjacent frames go through the view
+    transformer (adjacent ones without gradient), one extra reference frame only provides the stereo feature of the
+    oldest adjacent frame; per-frame BEV features are concatenated on the channel axis.  img_inputs carry all
+    frames: imgs (B, N_views*N_frames, 3, H, W), view index major."""
+
+    def __init__(self, pre_process=None, pre_process_net_3d=None, align_after_view_transfromation=False, num_adj=1,
+                 with_prev=True, **kwargs):
+        super().__init__(**kwargs)
+        self.pre_process = pre_process is not None
+        if self.pre_process:
+            self.pre_process_net = build_backbone(pre_process)
+            self.pre_process_net_3d = build_backbone(pre_process_net_3d)
+        self.align_after_view_transfromation = align_after_view_transfromation
+        self.with_prev = with_prev
+        self.extra_ref_frames = 1
+        self.temporal_frame = num_adj + 1
+        self.num_frame = self.temporal_frame + self.extra_ref_frames
+        self.grid = None
+
+    # ---- inputs (bevdet4d.py:208-300)
+    def prepare_inputs(self, img_inputs, stereo=False):
+        imgs = img_inputs[0]
+        B, NT, C, H, W = imgs.shape
+        F_, N = self.num_frame, NT // self.num_frame
+        imgs = [t.squeeze(2) for t in torch.split(imgs.view(B, N, F_, C, H, W), 1, 2)]
+        s2e, e2g, intrins, post_rots, post_trans, bda = img_inputs[1:7]
+        s2e, e2g = s2e.view(B, F_, N, 4, 4), e2g.view(B, F_, N, 4, 4)
+        key_inv = torch.inverse(e2g[:, 0, 0].double())[:, None, None]
+        s2k = (key_inv @ e2g.double() @ s2e.double()).float()
+        curr2adj = None
+        if stereo:
+            t = self.temporal_frame
+            cur = e2g[:, :t].double() @ s2e[:, :t].double()
+            adj = e2g[:, 1:t + 1].double() @ s2e[:, 1:t + 1].double()
+            c2a = (torch.inverse(adj) @ cur).float()
+            curr2adj = [p.squeeze(1) for p in torch.split(c2a, 1, 1)] + [None] * self.extra_ref_frames
+            assert len(curr2adj) == F_
+        per_frame = [[p.squeeze(1) for p in torch.split(v, 1, 1)] for v in
+                     (s2k, e2g, intrins.view(B, F_, N, 3, 3), post_rots.view(B, F_, N, 3, 3), post_trans.view(B, F_, N, 3))]
+        return [imgs] + per_frame + [bda, curr2adj]
+
+    # ---- BEV alignment of a previous frame (bevdet4d.py:43-138); unused by the shipped configs
+    def gen_grid(self, inp, sensor2keyegos, bda, bda_adj=None):
+        B, C, H, W = inp.shape
+        if self.grid is None or self.grid.shape[:2] != (H, W) or self.grid.device != inp.device:
+            xs = torch.linspace(0, W - 1, W, dtype=inp.dtype, device=inp.device).view(1, W).expand(H, W)
+            ys = torch.linspace(0, H - 1, H, dtype=inp.dtype, device=inp.device).view(H, 1).expand(H, W)
+            self.grid = torch.stack((xs, ys, torch.ones_like(xs)), -1)
+        grid = self.grid.view(1, H, W, 3).expand(B, H, W, 3).view(B, H, W, 3, 1)
+        c02l0, c12l0 = sensor2keyegos[0][:, 0:1], sensor2keyegos[1][:, 0:1]
+        bda_ = torch.zeros((B, 1, 4, 4), dtype=grid.dtype, device=grid.device)
+        bda_[:, :, :3, :3] = bda.unsqueeze(1)
+        bda_[:, :, 3, 3] = 1
+        c02l0 = bda_.matmul(c02l0)
+        c12l0 = (bda_ if bda_adj is None else bda_adj).matmul(c12l0)
+        l02l1 = c02l0.matmul(torch.inverse(c12l0))[:, 0].view(B, 1, 1, 4, 4)
+        l02l1 = l02l1[:, :, :, [True, True, False, True], :][:, :, :, :, [True, True, False, True]]
+        vt = self.img_view_transformer
+        feat2bev = torch.zeros((3, 3), dtype=grid.dtype, device=grid.device)
+        feat2bev[0, 0], feat2bev[1, 1] = vt.grid_interval[0], vt.grid_interval[1]
+        feat2bev[0, 2], feat2bev[1, 2] = vt.grid_lower_bound[0], vt.grid_lower_bound[1]
+        feat2bev[2, 2] = 1
+        feat2bev = feat2bev.view(1, 3, 3)
+        tf = torch.inverse(feat2bev).matmul(l02l1).matmul(feat2bev)
+        grid = tf.matmul(grid)
+        norm = torch.tensor([W - 1.0, H - 1.0], dtype=inp.dtype, device=inp.device)
+        return grid[:, :, :, :2, 0] / norm.view(1, 1, 1, 2) * 2.0 - 1.0
+
+    def shift_feature(self, inp, sensor2keyegos, bda, bda_adj=None):
+        grid = self.gen_grid(inp, sensor2keyegos, bda, bda_adj=bda_adj)
+        return F.grid_sample(inp, grid.to(inp.dtype), align_corners=True)
+
+    # ---- stereo reference feature = first residual stage of the backbone (bevstereo4d.py:18-50)
+    def extract_stereo_ref_feat(self, x):
+        B, N, C, H, W = x.shape
+        return self.img_backbone.forward_first_stage(x.view(B * N, C, H, W))
+
+    def prepare_bev_feat(self, img, sensor2keyego, ego2global, intrin, post_rot, post_tran, bda, mlp_input, feat_prev_iv,
+                         k2s_sensor, extra_ref_frame):
+        if extra_ref_frame:
+            return None, None, None, None, self.extract_stereo_ref_feat(img)
+        x, stereo_feat = self.image_encoder(img, stereo=True)
+        vt = self.img_view_transformer
+        metas = dict(k2s_sensor=k2s_sensor, intrins=intrin, post_rots=post_rot, post_trans=post_tran,
+                     frustum=vt.cv_frustum.to(x), cv_downsample=4, downsample=vt.downsample, grid_config=vt.grid_config,
+                     cv_feat_list=[feat_prev_iv, stereo_feat])
+        bev_2d, bev_3d, depth, height = vt([x, sensor2keyego, ego2global, intrin, post_rot, post_tran, bda, mlp_input], metas)
+        if self.pre_process and bev_3d.dim() == 5:
+            b2 = self.pre_process_net(torch.cat(bev_2d.unbind(dim=2), 1))[0]
+            b3 = self.pre_process_net_3d(torch.cat(bev_3d.unbind(dim=2), 1))[0]
+            bev_2d = torch.stack(torch.chunk(b2, 1, dim=1), dim=2)
+            bev_3d = torch.stack(torch.chunk(b3, 16, dim=1), dim=2)
+        return bev_2d, bev_3d, depth, height, stereo_feat
+
+    def extract_img_feat(self, img_inputs, img_metas=None, pred_prev=False, sequential=False, **kwargs):
+        if sequential or pred_prev:
+            raise NotImplementedError('sequential / pred_prev inference (DHD_model.py:401-402,459-484) is not mirrored')
+        imgs, s2ks, e2gs, intrins, post_rots, post_trans, bda, curr2adj = self.prepare_inputs(img_inputs, stereo=True)
+        vt = self.img_view_transformer
+        list_2d, list_3d = [], []
+        depth_key = height_key = feat_prev_iv = None
+        for fid in range(self.num_frame - 1, -1, -1):
+            key_frame = fid == 0
+            extra_ref = fid == self.num_frame - self.extra_ref_frames
+            if not (key_frame or self.with_prev):
+                continue
+            s2k, e2g = (s2ks[0], e2gs[0]) if self.align_after_view_transfromation else (s2ks[fid], e2gs[fid])
+            mlp_input = vt.get_mlp_input(s2ks[0], e2gs[0], intrins[fid], post_rots[fid], post_trans[fid], bda)
+            args = (imgs[fid], s2k, e2g, intrins[fid], post_rots[fid], post_trans[fid], bda, mlp_input, feat_prev_iv,
+                    curr2adj[fid], extra_ref)
+            if key_frame:
+                b2, b3, depth_key, height_key, feat_curr = self.prepare_bev_feat(*args)
+            else:
+                with torch.no_grad():
+                    b2, b3, _, _, feat_curr = self.prepare_bev_feat(*args)
+            if not extra_ref:
+                list_2d.append(b2)
+                list_3d.append(b3)
+            if not key_frame:
+                feat_prev_iv = feat_curr
+        if not self.with_prev:
+            n_prev = self.num_frame - self.extra_ref_frames - 1
+            k2, k3 = list_2d[0], list_3d[0]
+            z2 = k2.new_zeros((k2.shape[0], k2.shape[1] * n_prev) + tuple(k2.shape[2:]))
+            z3 = k3.new_zeros((k3.shape[0], k3.shape[1] * n_prev) + tuple(k3.shape[2:]))
+            list_2d, list_3d = [z2, k2], [z3, k3]
+        if self.align_after_view_transfromation:
+            if list_2d[0].dim() != 4:
+                raise NotImplementedError('aligning (B,C,Dz,Dy,Dx) features: the reference passes them to a 4-D grid_sample')
+            for adj_id in range(self.num_frame - 2):
+                pair = [s2ks[0], s2ks[self.num_frame - 2 - adj_id]]
+                list_2d[adj_id] = self.shift_feature(list_2d[adj_id], pair, bda)
+                list_3d[adj_id] = self.shift_feature(list_3d[adj_id], pair, bda)
+        bev_2d = torch.cat(list_2d, dim=1)
+        bev_3d = torch.cat(list_3d, dim=1)                    # (B, C*frames, 16, Dy, Dx)
+        bev_2d = torch.cat(bev_2d.unbind(dim=2), 1)
+        colz = lambda t: torch.cat(t.unbind(dim=2), 1)
+        x_2d = self.bev_encoder(bev_2d)
+        x_3d = torch.cat((self.voxel_encoder0(colz(bev_3d[:, :, :4])), self.voxel_encoder1(colz(bev_3d[:, :, 4:8])),
+                          self.voxel_encoder2(colz(bev_3d[:, :, 8:]))), dim=1)
+        return x_2d, x_3d, depth_key, height_key
+
+    def forward_train(self, points=None, img_metas=None, img_inputs=None, **kwargs):
+        x_2d, x_3d, _, depth, height = self.extract_feat(points, img_inputs=img_inputs, img_metas=img_metas, **kwargs)
+        loss_depth, loss_height = self.img_view_transformer.get_depth_and_height_loss(kwargs['gt_depth'], kwargs['gt_height'],
+                                                                                      depth, height)
+        losses = dict(loss_depth=loss_depth, loss_height=loss_height)
+        losses.update(self.forward_occ_train([x_2d, x_3d], kwargs['voxel_semantics'], kwargs['mask_camera']))
+        return losses
+
+
 def dhd_s_model_cfg(**overrides):
     """The `model = dict(...)` block of projects/configs/DHD/DHD-S.py:42-155, verbatim values."""
     from .synthetic import dhd_s_config
@@ -527,3 +686,33 @@ def dhd_s_model_cfg(**overrides):
                       loss_occ=dict(type='CrossEntropyLoss', use_sigmoid=False, ignore_index=255, loss_weight=1.0)))
     cfg.update(overrides)
     return cfg
+
+
+def dhd_m_model_cfg(input_size=(256, 704)):
+    """The model block of projects/configs/DHD/DHD-M.py:41-170 (values verbatim), with a reduced image size."""
+    n = 64
+    band = lambda z: {'x': [-40, 40, 0.4], 'y': [-40, 40, 0.4], 'z': z, 'depth': [1.0, 45.0, 0.5]}
+    return dict(
+        type='DHD_stereo', align_after_view_transfromation=False, num_adj=1,
+        img_backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 2, 3), frozen_stages=-1,
+                          norm_cfg=dict(type='BN', requires_grad=True), norm_eval=False, with_cp=True, style='pytorch'),
+        img_neck=dict(type='CustomFPN', in_channels=[1024, 2048], out_channels=256, num_outs=1, start_level=0, out_ids=[0]),
+        img_view_transformer=dict(
+            type='MGHS_Stereo', grid_config={'x': [-40, 40, 0.4], 'y': [-40, 40, 0.4], 'z': [-1, 5.4, 6.4], 'depth': [1.0, 45.0, 0.5]},
+            input_size=input_size, height_range=[round(-1.0 + 0.1 * i, 1) for i in range(65)], height_interval=0.1,
+            mask_range=[-1.0, 0.6, 2.2, 5.4], mask_1_grid=band([-1, 0.6, 0.4]), mask_2_grid=band([0.6, 2.2, 0.4]),
+            mask_3_grid=band([2.2, 5.4, 0.4]), in_channels=256, out_channels=n, sid=False, collapse_z=False,
+            loss_height_weight=0.1, loss_depth_weight=0.05,
+            depthnet_cfg=dict(use_dcn=False, aspp_mid_channels=96, stereo=True, bias=5.), downsample=16),
+        img_bev_encoder_backbone=dict(type='UNet', n_channels=n * 2, n_classes=512),
+        img_bev_encoder_neck=dict(type='Identity'),
+        pre_process=dict(type='CustomResNet', numC_input=n, num_layer=[1], num_channels=[n], stride=[1], backbone_output_ids=[0]),
+        pre_process_net_3d=dict(type='CustomResNet', numC_input=n * 16, num_layer=[1], num_channels=[n * 16], stride=[1],
+                                backbone_output_ids=[0]),
+        img_voxel_encoder0_backbone=dict(type='UNet', n_channels=n * 4 * 2, n_classes=128), img_voxel_encoder0_neck=dict(type='Identity'),
+        img_voxel_encoder1_backbone=dict(type='UNet', n_channels=n * 4 * 2, n_classes=256), img_voxel_encoder1_neck=dict(type='Identity'),
+        img_voxel_encoder2_backbone=dict(type='UNet', n_channels=n * 8 * 2, n_classes=128), img_voxel_encoder2_neck=dict(type='Identity'),
+        mix=dict(type='SFA', in_channels=1024, out_channels=512),
+        occ_head=dict(type='predictor', in_dim=512, out_dim=256, Dz=16, use_mask=True, num_classes=18, use_predicter=True,
+                      class_balance=True, weight_ce=10.0, weight_geo=0.2, weight_sem=0.2,
+                      loss_occ=dict(type='CrossEntropyLoss', use_sigmoid=False, ignore_index=255, loss_weight=1.0)))

@@ -64,3 +64,30 @@ def test_dhd_s_config_builds_the_detector_and_matches_the_packaged_copy():
     assert type(model).__name__ == 'DHD' and type(model.img_view_transformer).__name__ == 'MGHS'
     m = dhd_amd.build_neck(Config.fromfile(os.path.join(REF_CFG, 'DHD-M.py')).model.img_view_transformer)
     assert type(m).__name__ == 'MGHS_Stereo' and m.D == 88 and m.collapse_z is False
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason='reference tree not present on this box')
+def test_dhd_m_config_builds_the_temporal_stereo_detector():
+    """projects/configs/DHD/DHD-M.py (DHD_stereo + MGHS_Stereo, ResNet-50, one adjacent frame + one stereo
+    reference frame) builds unchanged; parameter names follow the reference's attribute names."""
+    import dhd_amd
+    from dhd_amd.config import Config
+    cfg = Config.fromfile(os.path.join(REF_CFG, 'DHD-M.py'))
+    m = dhd_amd.build_detector(cfg.model)
+    assert type(m).__name__ == 'DHD_stereo' and m.num_frame == 3 and m.temporal_frame == 2 and m.extra_ref_frames == 1
+    assert m.pre_process and not m.align_after_view_transfromation
+    keys = set(m.state_dict())
+    for k in ('pre_process_net.layers.0.0.conv1.weight', 'pre_process_net_3d.layers.0.0.conv1.weight',
+              'img_view_transformer.depth_net.cost_volumn_net.0.weight', 'img_view_transformer.height_net.depth_conv.4.conv_offset.weight',
+              'img_bev_encoder_backbone.inc.double_conv.0.weight', 'mix.mysk_7.spacial_leanring.0.weight', 'occ_head.predicter.2.bias'):
+        assert k in keys, k
+    assert m.mix.mysk_7.channels == 512 and m.img_view_transformer.D == 88
+    from dhd_amd.detector import dhd_m_model_cfg
+    ours, ref = dhd_m_model_cfg(), cfg.model
+    norm = lambda v: list(v) if isinstance(v, tuple) else v
+    assert set(ours) == set(ref)
+    for k, b in ours.items():
+        if isinstance(b, dict):
+            assert {kk: norm(vv) for kk, vv in b.items()} == {kk: norm(ref[k][kk]) for kk in b if kk in ref[k]}, k
+        else:
+            assert b == ref[k], k

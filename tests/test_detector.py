@@ -113,6 +113,42 @@ def test_dhd_forward_train_and_simple_test_on_gpu(gpu):
 
 
 @pytest.mark.gpu
+def test_dhd_stereo_forward_train_and_simple_test_on_gpu(gpu):
+    """DHD-M wiring (temporal stereo: key frame + one adjacent frame + one stereo reference frame, D = 88,
+    uncollapsed band tensors, SFA with C = 512) through forward_train + backward and simple_test on reduced images."""
+    import dhd_amd
+    torch.manual_seed(0)
+    from dhd_amd.detector import dhd_m_model_cfg
+    m = dhd_amd.build_detector(dhd_m_model_cfg(input_size=(64, 176))).to(gpu).train()
+    B, N, Fr = 1, 2, 3
+    imgs = torch.randn(B, N * Fr, 3, 64, 176, device=gpu)
+    per = [syn.make_calibration(5 + f, B, N, (64, 176)) for f in range(Fr)]
+    # (B, N_frames*N_views, ...) -> the detector views it as (B, N_frames, N_views, ...)
+    cat = lambda k: T(np.concatenate([p[k] for p in per], 1), gpu)
+    e2g = cat(1).clone()
+    e2g[:, N:2 * N, 0, 3] += 0.8   # the ego vehicle moved between the frames
+    e2g[:, 2 * N:, 0, 3] += 1.6
+    calib = [cat(0), e2g, cat(2), cat(3), cat(4), T(per[0][5], gpu)]
+    gt_d = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, 1 + 40 * syn.hash_uniform(2, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    gt_h = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, -1 + 6 * syn.hash_uniform(3, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    sem = torch.randint(0, 18, (B, 200, 200, 16), device=gpu)
+    cam = torch.rand(B, 200, 200, 16, device=gpu) < 0.3
+    losses = m(return_loss=True, img_inputs=[imgs] + calib, gt_depth=gt_d, gt_height=gt_h, voxel_semantics=sem, mask_camera=cam)
+    assert set(losses) == {'loss_depth', 'loss_height', 'loss_occ', 'loss_voxel_sem_scal', 'loss_voxel_geo_scal'}
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    for name in ('img_backbone.conv1.weight', 'img_view_transformer.depth_net.cost_volumn_net.0.weight', 'pre_process_net_3d.layers.0.0.conv1.weight',
+                 'img_voxel_encoder1.inc.double_conv.0.weight', 'mix.mysk_7.spacial_leanring.3.weight', 'occ_head.predicter.0.weight'):
+        g = dict(m.named_parameters())[name].grad
+        assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0, name
+    m.eval()
+    with torch.no_grad():
+        occ = m(return_loss=False, points=None, img_metas=None, img=[imgs] + calib)
+    assert len(occ) == B and occ[0].shape == (200, 200, 16) and occ[0].dtype == np.uint8
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_hip_nodes_under_autocast(gpu, dtype):
     """Under autocast the dense producers hand bf16/fp16 tensors to the HIP nodes: they must cast
