@@ -227,24 +227,31 @@ class _LiftNetBase(nn.Module):
         self.depth_channels = depth_channels
 
     # ---- stereo cost volume (depthnet.py:249-361 / :492-603) ------------------------------------
+    @staticmethod
+    def _mat_vec(m, comps):
+        """(B,N,r,c) matrices applied to per-point vectors given as c component tensors (B,N,D,H,W) -> r tensors.
+        Written with broadcast multiply-adds: the reference's `matmul` over (B,N,D,H,W,3,3)@(…,3,1) becomes a batched
+        GEMM with B*N*D*H*W = 17.8 M batches at B = 3, which faults in the ROCm BLAS path (fine at B <= 2)."""
+        mb = m[:, :, None, None, None]
+        return [sum(mb[..., i, j] * comps[j] for j in range(m.shape[-1])) for i in range(m.shape[-2])]
+
     def gen_grid(self, metas, B, N, D, H, W, hi, wi):
-        frustum = metas['frustum']
-        pts = frustum - metas['post_trans'].view(B, N, 1, 1, 1, 3)
-        pts = torch.inverse(metas['post_rots']).view(B, N, 1, 1, 1, 3, 3).matmul(pts.unsqueeze(-1))
-        pts = torch.cat((pts[..., :2, :] * pts[..., 2:3, :], pts[..., 2:3, :]), 5)
+        """Current-frame stereo frustum -> sampling grid in the adjacent frame's image (reference depthnet.py:249-305)."""
+        pts = metas['frustum'] - metas['post_trans'].view(B, N, 1, 1, 1, 3)
+        x, y, z = self._mat_vec(torch.inverse(metas['post_rots']), list(pts.unbind(-1)))
+        x, y = x * z, y * z
         rots = metas['k2s_sensor'][:, :, :3, :3].contiguous()
         trans = metas['k2s_sensor'][:, :, :3, 3].contiguous()
         combine = rots.matmul(torch.inverse(metas['intrins']))
-        pts = combine.view(B, N, 1, 1, 1, 3, 3).matmul(pts) + trans.view(B, N, 1, 1, 1, 3, 1)
-        neg = pts[..., 2, 0] < 1e-3
-        pts = metas['intrins'].view(B, N, 1, 1, 1, 3, 3).matmul(pts)
-        pts = pts[..., :2, :] / pts[..., 2:3, :]
-        pts = metas['post_rots'][..., :2, :2].view(B, N, 1, 1, 1, 2, 2).matmul(pts).squeeze(-1)
-        pts = pts + metas['post_trans'][..., :2].view(B, N, 1, 1, 1, 2)
-        px = pts[..., 0] / (wi - 1.0) * 2.0 - 1.0
-        py = pts[..., 1] / (hi - 1.0) * 2.0 - 1.0
-        px = px.masked_fill(neg, -2)
-        py = py.masked_fill(neg, -2)
+        x, y, z = [v + trans[:, :, i, None, None, None] for i, v in enumerate(self._mat_vec(combine, [x, y, z]))]
+        neg = z < 1e-3
+        x, y, z = self._mat_vec(metas['intrins'], [x, y, z])
+        x, y = x / z, y / z
+        x, y = self._mat_vec(metas['post_rots'][..., :2, :2], [x, y])
+        x = x + metas['post_trans'][:, :, 0, None, None, None]
+        y = y + metas['post_trans'][:, :, 1, None, None, None]
+        px = (x / (wi - 1.0) * 2.0 - 1.0).masked_fill(neg, -2)
+        py = (y / (hi - 1.0) * 2.0 - 1.0).masked_fill(neg, -2)
         return torch.stack([px, py], dim=-1).view(B * N, D * H, W, 2)
 
     def calculate_cost_volumn(self, metas):
