@@ -163,3 +163,112 @@ int dhd_deform_col2im(const float* dcol, const float* x, const float* offset, fl
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Temporal-stereo cost volume of DepthNet (models/necks/depthnet.py:307-361 in the reference; the
+// BEVStereo matching cost): for every stereo-resolution pixel and depth hypothesis, the adjacent
+// frame's feature map is sampled bilinearly at the hypothesis' reprojection and compared with the
+// current frame's feature:
+//     cost[bn,d,y,x] = sum_c | curr[bn,c,y,x] - sample(prev[bn,c], grid[bn,d,y,x]) |   (+ bias where the sample of
+//                      the reference's last channel group came back exactly 0, i.e. outside the image)
+//     out = softmax_d(-cost)
+// The reference runs C/4 grid_sample calls over (BN, 4, D*H, W) tensors plus sub/abs/sum passes (29 % of a
+// DHD-M training step on this GPU).  Here: features in NHWC, one wave per pixel: the current feature lives in
+// registers (lane = 4 channels), each hypothesis costs four 1-KB tap loads, a DPP wave reduction, and the
+// softmax over the D hypotheses is done in the same wave.  No gradient (the reference wraps it in no_grad).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+constexpr int kCvMaxD = 256;
+
+__global__ __launch_bounds__(kBlock) void stereo_cost_volume_kernel(const float* __restrict__ prev, const float* __restrict__ curr,
+                                                                    const float* __restrict__ grid, int c, int h, int w, int nd,
+                                                                    float bias, int flag_channel, float* __restrict__ out, int n_pix) {
+  const int lane = threadIdx.x & 63;
+  const int pix = blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6);  // (bn, y, x)
+  if (pix >= n_pix) return;
+  const int hw = h * w;
+  const int bn = pix / hw, yx = pix % hw;
+  const int c4 = c >> 2;                       // float4 groups per pixel
+  const float* pb = prev + (size_t)bn * hw * c;
+  // this lane's channels: groups lane, lane + 64, ...
+  f32x4_t cur[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int g = lane + 64 * q;
+    cur[q] = g < c4 ? reinterpret_cast<const f32x4_t*>(curr + (size_t)pix * c)[g] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const int flag_group = flag_channel >> 2, flag_comp = flag_channel & 3;
+  float mine[kCvMaxD / DHD_WAVE];  // cost of hypothesis d lives in lane d % 64, register d / 64
+#pragma unroll
+  for (int q = 0; q < kCvMaxD / DHD_WAVE; ++q) mine[q] = 3.0e38f;
+  const float* gp = grid + ((size_t)bn * nd * hw + yx) * 2;
+  for (int d0 = 0; d0 < nd; d0 += DHD_WAVE) {
+    // lane l fetches the sampling position of hypothesis d0 + l
+    float gx = 0.f, gy = 0.f;
+    if (d0 + lane < nd) {
+      const float2 g2 = *reinterpret_cast<const float2*>(gp + (size_t)(d0 + lane) * hw * 2);
+      gx = g2.x; gy = g2.y;
+    }
+    const int nb = min(DHD_WAVE, nd - d0);
+    for (int i = 0; i < nb; ++i) {
+      const float px = (__shfl(gx, i, DHD_WAVE) + 1.0f) * 0.5f * (float)(w - 1);   // align_corners=True
+      const float py = (__shfl(gy, i, DHD_WAVE) + 1.0f) * 0.5f * (float)(h - 1);
+      const Tap tp = make_tap(py, px, h, w);
+      float acc = 0.f, flag = 1.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int g = lane + 64 * q;
+        if (g >= c4) break;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+        if (tp.v00) s += tp.w00 * reinterpret_cast<const f32x4_t*>(pb + (size_t)tp.i00 * c)[g];
+        if (tp.v01) s += tp.w01 * reinterpret_cast<const f32x4_t*>(pb + (size_t)tp.i01 * c)[g];
+        if (tp.v10) s += tp.w10 * reinterpret_cast<const f32x4_t*>(pb + (size_t)tp.i10 * c)[g];
+        if (tp.v11) s += tp.w11 * reinterpret_cast<const f32x4_t*>(pb + (size_t)tp.i11 * c)[g];
+        const f32x4_t df = cur[q] - s;
+        acc += (fabsf(df.x) + fabsf(df.y)) + (fabsf(df.z) + fabsf(df.w));
+        if (g == flag_group) flag = s[flag_comp];
+      }
+      float tot = wave_sum_bcast(acc);
+      if (bias != 0.f) {
+        const float fv = __shfl(flag, flag_group & 63, DHD_WAVE);
+        if (fv == 0.f) tot += bias;
+      }
+      if (lane == i) mine[d0 >> 6] = tot;
+    }
+  }
+  // softmax over the hypotheses of -cost: lanes/registers without a hypothesis hold +3e38 -> exp(-inf) = 0
+  float mn = mine[0];
+#pragma unroll
+  for (int q = 1; q < kCvMaxD / DHD_WAVE; ++q) mn = fminf(mn, mine[q]);
+  for (int m = 32; m > 0; m >>= 1) mn = fminf(mn, __shfl_xor(mn, m, DHD_WAVE));
+  float e[kCvMaxD / DHD_WAVE], sum = 0.f;
+#pragma unroll
+  for (int q = 0; q < kCvMaxD / DHD_WAVE; ++q) {
+    e[q] = mine[q] > 1.0e38f ? 0.f : __expf(mn - mine[q]);
+    sum += e[q];
+  }
+  sum = wave_sum_bcast(sum);
+  const float inv = 1.0f / sum;
+  float* ob = out + (size_t)bn * nd * hw + yx;
+#pragma unroll
+  for (int q = 0; q < kCvMaxD / DHD_WAVE; ++q) {
+    const int d = lane + 64 * q;
+    if (d < nd) ob[(size_t)d * hw] = e[q] * inv;
+  }
+}
+
+}  // namespace
+
+extern "C" int dhd_stereo_cost_volume(const float* prev_nhwc, const float* curr_nhwc, const float* grid, int bn, int c, int h, int w,
+                                      int n_depth, float bias, int flag_channel, float* out, void* stream) {
+  if (!prev_nhwc || !curr_nhwc || !grid || !out || bn <= 0 || c <= 0 || h <= 0 || w <= 0 || n_depth <= 0) return DHD_EINVAL;
+  if ((c & 3) != 0 || c > 1024 || n_depth > kCvMaxD || flag_channel < 0 || flag_channel >= c) return DHD_EUNSUPPORTED;
+  const long n_pix = (long)bn * h * w;
+  if (n_pix >= (1L << 31) / n_depth) return DHD_EUNSUPPORTED;
+  hipLaunchKernelGGL(stereo_cost_volume_kernel, dim3(dhd_cdiv(n_pix, kBlock / DHD_WAVE)), dim3(kBlock), 0, dhd_stream(stream), prev_nhwc,
+                     curr_nhwc, grid, c, h, w, n_depth, bias, flag_channel, out, (int)n_pix);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}

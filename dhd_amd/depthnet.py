@@ -264,6 +264,8 @@ class _LiftNetBase(nn.Module):
         grid = self.gen_grid(metas, B, N, D, H, W, hi, wi).to(curr.dtype)
         prev = prev.view(B * N, -1, H, W)
         curr = curr.view(B * N, -1, H, W)
+        if self.use_hip_cost_volume and curr.is_cuda and c % group == 0 and c <= 1024 and D <= 256:
+            return self._hip_cost_volume(prev, curr, grid, D, (c // group - 1) * group)
         cost = 0
         warped = None
         for f in range(curr.shape[1] // group):
@@ -274,6 +276,23 @@ class _LiftNetBase(nn.Module):
             invalid = warped[:, 0].view(B * N, D, H, W) == 0
             cost = torch.where(invalid, cost + self.bias, cost)
         return (-cost).softmax(dim=1)
+
+    use_hip_cost_volume = True
+
+    def _hip_cost_volume(self, prev, curr, grid, n_depth, flag_channel):
+        """The same cost volume in one HIP kernel (csrc/deform.hip: stereo_cost_volume_kernel); float32."""
+        from . import _lib, mghs_op
+        bn, c, h, w = curr.shape
+        dev = curr.device
+        prev_l = mghs_op._nchw_to_nhwc(prev.float().contiguous())
+        curr_l = mghs_op._nchw_to_nhwc(curr.float().contiguous())
+        grid = grid.float().contiguous()
+        with torch.cuda.device(dev):
+            out = torch.empty((bn, n_depth, h, w), dtype=torch.float32, device=dev)
+            _lib.check(_lib.load().dhd_stereo_cost_volume(_lib.ptr(prev_l), _lib.ptr(curr_l), _lib.ptr(grid), bn, c, h, w, n_depth,
+                                                          float(self.bias), flag_channel, _lib.ptr(out), _lib.stream_ptr(dev)),
+                       'dhd_stereo_cost_volume')
+        return out.to(curr.dtype)
 
     def _gated(self, x, mlp_input, mlp, se):
         return se(x, mlp(mlp_input)[..., None, None])

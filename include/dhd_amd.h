@@ -362,6 +362,16 @@ int dhd_points_to_maps(const float* points, int n_cams, int n_points, int height
                        int downsample, float depth_lo, float depth_hi, float* depth_map,
                        float* height_map, void* zbuffer, void* stream);
 
+/* Temporal-stereo cost volume of DepthNet (models/necks/depthnet.py:307-361): prev / curr are the
+ * stereo features of the adjacent and the current frame in NHWC (bn, h, w, c); grid (bn, n_depth*h, w, 2)
+ * holds the normalised sampling positions of F.grid_sample(align_corners=True, padding zeros), as the
+ * reference's gen_grid produces them.  cost = sum_c |curr - sample(prev)|, + bias where the sample of
+ * channel flag_channel (the reference's last group, C-4) is exactly 0; out (bn, n_depth, h, w) =
+ * softmax over the depth hypotheses of -cost.  c % 4 == 0, c <= 1024, n_depth <= 256.  No gradient. */
+int dhd_stereo_cost_volume(const float* prev_nhwc, const float* curr_nhwc, const float* grid, int bn,
+                           int c, int h, int w, int n_depth, float bias, int flag_channel, float* out,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif
