@@ -108,6 +108,7 @@ class HotPath:
             self.x = torch.randn(batch, 512, 200, 200, generator=g).to(dev).requires_grad_()
             self.gy = torch.randn(batch, 256, 200, 200, generator=g).to(dev)
         self.ev = []  # (start, end) HIP events around the dominant kernel, one pair per timed step
+        self.ev_sfa = []  # (start, after forward, after backward) events around the SFA stage operator
         # algorithmic bytes of the forward pooling per launch (fused form): dense outputs
         # written once + depth read once + context read once.  The streaming kernel is charged with ALL
         # of them although depth/context are read by the gather kernel before it (conservative by 1%).
@@ -132,8 +133,18 @@ class HotPath:
             self.x.grad = None
             for prm in self.stage_params:  # optimizer.zero_grad(set_to_none=True), the PyTorch default
                 prm.grad = None
-            y = self.stage(self.x)
-            y.backward(self.gy)
+            if record:
+                # HIP events on the launch stream around the stage's forward and backward calls
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e[0].record()
+                y = self.stage(self.x)
+                e[1].record()
+                y.backward(self.gy)
+                e[2].record()
+                self.ev_sfa.append(e)
+            else:
+                y = self.stage(self.x)
+                y.backward(self.gy)
         return outs, dg, fg_nchw
 
 
@@ -357,6 +368,20 @@ def main():
             roofline=dict(bound='hbm', kernel='mghs_stream_fwd', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s',
                           frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic('mghs_stream_fwd', a.batch), launch_ms=kern_ms,
                           algorithmic_bytes=hp.pool_fwd_bytes))
+        if hp.ev_sfa:
+            # second roofline, for the SFA stage operator as a whole (a dozen kernels per call): SURVEY 8(d) gives its forward
+            # algorithmic traffic as x read twice + u/out written + the two 1x1 convs reading and writing (B,C,H,W) once each
+            fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in hp.ev_sfa]))
+            bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in hp.ev_sfa]))
+            c, hw = 256, 200 * 200
+            fwd_bytes = a.batch * 4 * hw * (2 * 2 * c + 2 * c + 4 * c)
+            gemm_flop = 2.0 * c * c * hw * a.batch
+            line['roofline_sfa_stage'] = dict(
+                bound='hbm', kernel='dhd_sfa_stage_forward (plane_mean, fc, 2 x pw_gemm6, stat reductions, blend2_bn)',
+                achieved=fwd_bytes / (fwd_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit='GB/s',
+                frac=fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, traffic=None, launch_ms=fwd_ms, algorithmic_bytes=fwd_bytes,
+                backward_ms=bwd_ms, gemm_tflops_fp32_equivalent=6 * gemm_flop / ((fwd_ms + bwd_ms) * 1e-3) / 1e12,
+                note='float32 GEMMs computed as 6 bf16 MFMA products each (exact three-way split); f32-MFMA peak is 157 TFLOP/s')
         if world == 1 and a.cpu_samples > 0:
             line['cpu_baseline'] = cpu_baseline(hp, a.cpu_samples)
         print(json.dumps(line), flush=True)
