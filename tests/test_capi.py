@@ -102,6 +102,18 @@ def test_no_silent_fallback_without_gpu_or_library():
         SFA(32, 16)(torch.rand(1, 32, 5, 5))
     with pytest.raises(_lib.DhdError):
         mghs_op.height_band(torch.rand(2, 65, 4, 11), [0.1 * i for i in range(65)], [0, 1, 2, 3])
+    from dhd_amd import label_loss, occ_loss
+    from dhd_amd.depthnet import _DeformIm2col
+    with pytest.raises(_lib.DhdError):
+        occ_loss.occ_losses(torch.rand(10, 18), torch.zeros(10, dtype=torch.uint8), torch.ones(10, dtype=torch.uint8), torch.ones(18))
+    with pytest.raises(_lib.DhdError):
+        occ_loss.occ_argmax_hist(torch.rand(10, 18))
+    with pytest.raises(_lib.DhdError):
+        label_loss.bin_labels(torch.rand(1, 2, 32, 32), torch.rand(1, 2, 32, 32), 16, [1.0, 45.0, 1.0], 44, -1.0, 0.1, 65)
+    with pytest.raises(_lib.DhdError):
+        label_loss.points_to_maps(torch.rand(2, 100, 4), 64, 176)
+    with pytest.raises(_lib.DhdError):
+        _DeformIm2col.apply(torch.rand(1, 4, 5, 5), torch.zeros(1, 18, 5, 5), 3, 1, 1)
     code = ("import os, sys; sys.path.insert(0, %r); os.environ['DHD_AMD_LIB'] = '/nonexistent/libdhd_amd.so'\n"
             "from dhd_amd import _lib\n"
             "try:\n    _lib.load()\nexcept _lib.DhdError as e:\n    print('LOUD', e)\n" % ROOT)
