@@ -6,20 +6,25 @@
 //   y1  = conv1(u)   z1 = relu(bn1(y1))   y2 = conv2(z1)   s2 = bn2(y2)              (mix.py:51)
 //   out = sigmoid(s2)*(a*x_bev) + (1-sigmoid(s2))*((1-a)*x_voxel)                    (mix.py:52-58)
 //
-// The two 1x1 convolutions are (C x C) x (C x B*HW) float32 GEMMs on NCHW data.  Here they run on
-// the f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate) with everything
-// element-wise FUSED into the operand path, so no intermediate but y1 and y2 is ever stored:
-//   * pw_gemm: a wave owns 32 pixels x 256 output channels (128 accumulator registers).  The
-//     activation operand is loaded straight from NCHW global memory into the MFMA B layout (lane =
-//     (k parity, pixel): two 128-byte row segments per load) and passes through a per-(sample,channel)
+// The two 1x1 convolutions are (C x C) x (C x B*HW) float32 GEMMs on NCHW data (six of them per forward +
+// backward).  They run on the matrix cores with everything element-wise FUSED into the operand path, so no
+// intermediate but y1 and y2 is ever stored.  Two GEMM modes (dhd_sfa_set_gemm_mode):
+//   1 (default) bf16 MFMA on an exact three-way split of every float32 operand, six products per a*b:
+//               float32-level accuracy at 6/16 of the f32-MFMA cost (pw_gemm6 / pw_wgrad6, see below);
+//   0           f32 MFMA (v_mfma_f32_32x32x2_f32), a plain float32 fma chain (pw_gemm / pw_wgrad).
+// Common structure:
+//   * forward / dgrad GEMM: a wave owns 32 pixels x 256 output channels (128 accumulator registers).  The
+//     activation operand is loaded straight from NCHW global memory into the MFMA operand layout (lane =
+//     (k group, pixel): two 128-byte row segments per load) and passes through a per-(sample,channel)
 //     affine prologue  act(c0*in0 + c1*in1 + c2)  -- which is blend1 (in0,in1 = x_bev,x_voxel),
-//     BatchNorm+ReLU (in0 = y1) or BatchNorm-backward (in0,in1 = g,y).  The weight operand comes
-//     from LDS images pre-packed so that one ds_read_b128 feeds four MFMAs.
-//   * pw_wgrad: weight gradients, pixels are the reduction dimension: tiles of both operands are
-//     staged through LDS (with the same prologues), 8 waves x (128 x 64) outputs, per-worker
-//     partial matrices reduced by a second small kernel (deterministic, no float atomics).
-//   * BatchNorm statistics / gradient sums are per-plane streaming reductions with double-precision
-//     finalisation; the blends are fused with the BatchNorm affine and the sigmoid.
+//     BatchNorm+ReLU (in0 = y1) or BatchNorm-backward (in0,in1 = g,y).  The weight operand comes from LDS
+//     images pre-packed in fragment order.  Epilogue: bias + BatchNorm batch statistics (forward), the
+//     ReLU mask from the pass bits the forward recorded (dgrad 2), 16-byte stores along the pixel axis.
+//   * weight gradient: pixels are the reduction dimension: tiles of both operands are staged through LDS
+//     (with the same prologues), 8 waves x (128 x 64) outputs, per-worker partial matrices reduced by a
+//     second small kernel (deterministic, no float atomics).
+//   * BatchNorm gradient sums are per-plane streaming reductions with double-precision finalisation; the
+//     blends are fused with the BatchNorm affine and the sigmoid.
 // Forward reads x three times and y1/y2 twice; nothing is transposed, there is no NHWC detour.
 #include <type_traits>
 
