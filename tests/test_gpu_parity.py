@@ -479,6 +479,22 @@ def test_sfa_stage_vs_torch(gpu, c, b, h, w, train):
     _check_stage_against_torch(st, x)
 
 
+@pytest.mark.parametrize('c,b,h,w', [(128, 2, 20, 28), (256, 2, 36, 40), (512, 1, 24, 40)])
+def test_sfa_stage_f32_mfma_mode_vs_torch(gpu, c, b, h, w):
+    """GEMM mode 0 (dhd_sfa_set_gemm_mode: plain float32 MFMA kernels) through the same comparison."""
+    from dhd_amd import _lib
+    from dhd_amd.mix import channel_spatial_stage
+    torch.manual_seed(c + w)
+    st = channel_spatial_stage(2 * c).to(gpu).train()
+    x = (torch.randn(b, 2 * c, h, w, device=gpu) * 0.7 + 0.1).requires_grad_()
+    lib = _lib.load()
+    _lib.check(lib.dhd_sfa_set_gemm_mode(0), 'mode')
+    try:
+        _check_stage_against_torch(st, x)
+    finally:
+        _lib.check(lib.dhd_sfa_set_gemm_mode(1), 'mode')
+
+
 def test_fused_sfa_stage_matches_generic_path(gpu):
     """Same module, fused operator vs the blend kernels around library convolutions."""
     from dhd_amd.mix import channel_spatial_stage
