@@ -19,6 +19,13 @@ reference's own inverse/"combine" matrices so that the per-point arithmetic is
 pinned bit-for-bit given identical matrices, and the end-to-end difference from
 the inverse is measured (a handful of boundary points per 185 856).
 
+Also restated here, each pinned the same way: the SFA attention stage (`sfa_stage`, golden G5 from the
+reference's mix.py), the height loss and its label builders (G4), the occupancy-head losses (`occ_losses`,
+G6 from models/losses/semkitti_loss.py), the evaluation histogram (`occ_confusion`, definitional) and the
+LiDAR rasteriser (`points_to_maps`, G7 from datasets/pipelines/loading_new.py; equal keys of the reference's
+unstable argsort are identified as ties).  Unpinned (no reference fixture can be produced here): mmcv's DCN
+and the stereo cost volume, which the GPU tests check against their PyTorch formulations instead.
+
 All file:line citations are into /root/reference/projects/mmdet3d_plugin/.
 """
 import numpy as np
