@@ -23,8 +23,9 @@ Also restated here, each pinned the same way: the SFA attention stage (`sfa_stag
 reference's mix.py), the height loss and its label builders (G4), the occupancy-head losses (`occ_losses`,
 G6 from models/losses/semkitti_loss.py), the evaluation histogram (`occ_confusion`, definitional) and the
 LiDAR rasteriser (`points_to_maps`, G7 from datasets/pipelines/loading_new.py; equal keys of the reference's
-unstable argsort are identified as ties).  Unpinned (no reference fixture can be produced here): mmcv's DCN
-and the stereo cost volume, which the GPU tests check against their PyTorch formulations instead.
+unstable argsort are identified as ties).  The stereo sampling grid and cost volume are pinned directly against golden G8 (the reference's
+DepthNet.gen_grid / calculate_cost_volumn) without a numpy restatement.  Unpinned (no reference fixture can be
+produced here): mmcv's DCN, which the GPU tests check against its PyTorch (grid_sample) formulation instead.
 
 All file:line citations are into /root/reference/projects/mmdet3d_plugin/.
 """

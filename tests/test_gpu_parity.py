@@ -884,3 +884,18 @@ def test_stereo_cost_volume_vs_grid_sample_formulation(gpu, bn, c, h, w, d, bias
     ref = (-cost).softmax(dim=1)
     assert got.shape == ref.shape and abs(float(got.sum()) - bn * h * w) < 1e-2 * bn * h * w * 1e-2 + 1e-1
     assert (got - ref).abs().max().item() < 1e-4  # softmax of sums of up to 256 |diff| terms (cost ~ 300) in another order
+
+
+def test_stereo_cost_volume_vs_reference_golden(gpu):
+    """gen_grid on the GPU + dhd_stereo_cost_volume against golden G8 (the reference's DepthNet.gen_grid /
+    calculate_cost_volumn run on CPU): 70 % of the samples inside the adjacent image, the rest zero-padded and biased."""
+    from dhd_amd.depthnet import DepthNet
+    g = golden('g8_stereo')
+    d, h, w = g['frustum'].shape[:3]
+    bn = g['curr'].shape[0]
+    dn = DepthNet(32, 32, 16, d, use_dcn=False, aspp_mid_channels=16, stereo=True, bias=float(g['bias'])).to(gpu)
+    metas = dict(k2s_sensor=T(g['k2s_sensor'], gpu), intrins=T(g['intrins'], gpu), post_rots=T(g['post_rots'], gpu),
+                 post_trans=T(g['post_trans'], gpu), frustum=T(g['frustum'], gpu), cv_feat_list=[T(g['prev'], gpu), T(g['curr'], gpu)])
+    assert dn.use_hip_cost_volume
+    cv = dn.calculate_cost_volumn(metas)
+    np.testing.assert_allclose(cv.cpu().numpy(), g['cost_volume'], rtol=2e-4, atol=2e-6)

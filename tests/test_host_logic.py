@@ -153,3 +153,19 @@ def test_stereo_gen_grid_matches_the_matmul_formulation():
     ref = torch.stack([(pts[..., 0] / 175.0 * 2.0 - 1.0).masked_fill(neg, -2), (pts[..., 1] / 63.0 * 2.0 - 1.0).masked_fill(neg, -2)], -1)
     assert got.shape == (B * N, D * H, W, 2)
     assert torch.allclose(got, ref.view(B * N, D * H, W, 2), rtol=1e-5, atol=1e-4)
+
+
+def test_stereo_grid_and_cost_volume_match_reference_fixture():
+    """DepthNet.gen_grid and the PyTorch formulation of calculate_cost_volumn against golden G8, recorded from the
+    reference's own DepthNet methods (models/model_utils/depthnet.py:249-361)."""
+    from dhd_amd.depthnet import DepthNet
+    g = golden('g8_stereo')
+    d, h, w = g['frustum'].shape[:3]
+    bn, c = g['curr'].shape[:2]
+    dn = DepthNet(32, 32, 16, d, use_dcn=False, aspp_mid_channels=16, stereo=True, bias=float(g['bias']))
+    metas = dict(k2s_sensor=T(g['k2s_sensor']), intrins=T(g['intrins']), post_rots=T(g['post_rots']), post_trans=T(g['post_trans']),
+                 frustum=T(g['frustum']), cv_feat_list=[T(g['prev']), T(g['curr'])])
+    grid = dn.gen_grid(metas, 1, bn, d, h, w, h * 4, w * 4)
+    np.testing.assert_allclose(grid.numpy(), g['grid'], rtol=1e-5, atol=1e-5)
+    cv = dn.calculate_cost_volumn(metas)
+    np.testing.assert_allclose(cv.numpy(), g['cost_volume'], rtol=1e-4, atol=1e-6)
