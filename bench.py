@@ -51,6 +51,16 @@ def pmc_traffic(kernel, batch):
     return best
 
 
+def sfa_forward_traffic(batch):
+    """Sum of the committed PMC traffic of the kernels one dhd_sfa_stage_forward call launches, or None."""
+    calls = {'plane_mean_kernel': 1, 'fc_forward_kernel': 1, 'pack_weight6_kernel': 2, 'pw_gemm6_kernel<8,true,false,0>': 1,
+             'pw_gemm6_kernel<8,false,true,0>': 1, 'stat_reduce_kernel': 2, 'bn_train_finalize_kernel': 2, 'blend2_bn_kernel': 1}
+    parts = [pmc_traffic(k, batch) for k in calls]
+    if any(p is None for p in parts):
+        return None
+    return int(sum(p * n for p, n in zip(parts, calls.values())))
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
@@ -379,7 +389,8 @@ def main():
             line['roofline_sfa_stage'] = dict(
                 bound='hbm', kernel='dhd_sfa_stage_forward (plane_mean, fc, 2 x pw_gemm6, stat reductions, blend2_bn)',
                 achieved=fwd_bytes / (fwd_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit='GB/s',
-                frac=fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, traffic=None, launch_ms=fwd_ms, algorithmic_bytes=fwd_bytes,
+                frac=fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, traffic=sfa_forward_traffic(a.batch), launch_ms=fwd_ms,
+                algorithmic_bytes=fwd_bytes,
                 backward_ms=bwd_ms, gemm_tflops_fp32_equivalent=6 * gemm_flop / ((fwd_ms + bwd_ms) * 1e-3) / 1e12,
                 note='float32 GEMMs computed as 6 bf16 MFMA products each (exact three-way split); f32-MFMA peak is 157 TFLOP/s')
         if world == 1 and a.cpu_samples > 0:
