@@ -70,11 +70,12 @@ def parse():
     p.add_argument('--no-sfa', action='store_true', help='time the MGHS part only')
     p.add_argument('--geometry', choices=['dhd-s', 'dhd-m', 'dhd-l'], default='dhd-s',
                    help='view-transform geometry of the hot path: DHD-S (D=44, 16x44), DHD-M (D=88), DHD-L (D=88, 32x88 from 512x1408)')
-    p.add_argument('--workload', choices=['hotpath', 'e2e', 'occ_loss'], default='hotpath',
+    p.add_argument('--workload', choices=['hotpath', 'e2e', 'occ_loss', 'ema'], default='hotpath',
                    help="hotpath: MGHS + SFA stage (default). e2e: the whole DHD-S detector (dense parts on MIOpen/hipBLASLt), "
                         "forward_train + backward + AdamW step, DDP over RCCL when --gpus > 1")
     p.add_argument('--amp', choices=['off', 'bf16', 'fp16'], default='off', help='autocast dtype of the dense modules (e2e)')
     p.add_argument('--model', choices=['dhd-s', 'dhd-m'], default='dhd-s', help='e2e: DHD-S (single frame) or DHD-M (temporal stereo)')
+    p.add_argument('--no-ema', action='store_true', help='e2e: leave out the per-iteration weight EMA (MEGVIIEMAHook) of the configs')
     p.add_argument('--cpu-samples', type=int, default=2, help='samples for the CPU baseline leg (0 = skip)')
     return p.parse_args()
 
@@ -162,7 +163,7 @@ class EndToEnd:
     """DHD-S exactly as projects/configs/DHD/DHD-S.py:42-155 (random init, synthetic 6-camera batch,
     SURVEY.md 8d config 2): forward_train -> sum of the four losses -> backward -> grad clip 5 -> AdamW."""
 
-    def __init__(self, dev, batch, seed, world, amp, model='dhd-s'):
+    def __init__(self, dev, batch, seed, world, amp, model='dhd-s', ema=True):
         import dhd_amd
         from dhd_amd.detector import dhd_m_model_cfg, dhd_s_model_cfg
         torch.manual_seed(seed)
@@ -176,6 +177,8 @@ class EndToEnd:
             self.net = torch.nn.parallel.DistributedDataParallel(self.model, device_ids=[dev.index], bucket_cap_mb=64,
                                                                  gradient_as_bucket_view=True)
         self.opt = torch.optim.AdamW(self.params, lr=2e-4, weight_decay=1e-2, fused=True)  # DHD-S.py:262
+        # custom_hooks of all three configs (DHD-S.py:272-278): weight EMA after every iteration
+        self.ema = dhd_amd.ModelEMA(self.model, 0.9990, updates=10560) if ema else None
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         N, H, W = 6, 256, 704
         per = [syn.make_calibration(seed + 7 * f, batch, N, (H, W)) for f in range(frames)]
@@ -210,11 +213,13 @@ class EndToEnd:
             loss.backward()
             torch.nn.utils.clip_grad_norm_(self.params, 5.0)  # DHD-S.py:263
             self.opt.step()
+        if self.ema is not None:
+            self.ema.update(None, self.model)
         return loss
 
 
 def run_e2e(a, rank, world, dev):
-    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp, a.model)
+    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp, a.model, not a.no_ema)
     for _ in range(a.warmup):
         job.step(False)
 
@@ -237,7 +242,7 @@ def run_e2e(a, rank, world, dev):
             config=dict(workload=('DHD-M (DHD_stereo: key + adjacent + stereo reference frame, D=88) whole detector' if a.model == 'dhd-m'
                                   else 'DHD-S (configs[1]/[2]) whole detector') +
                                  ': ResNet-50 + FPN, MGHS (HIP), BEV encoder, 3 UNets, SFA (HIP stage), predictor + losses (HIP); '
-                                 'forward_train + backward + grad-clip + AdamW; random init',
+                                 'forward_train + backward + grad-clip + AdamW' + ('' if a.no_ema else ' + weight EMA (HIP)') + '; random init',
                         samples_per_gpu=a.batch, global_batch=a.batch * world, params=job.n_params,
                         parallelism=f'DDP x{world} (RCCL bucketed all-reduce overlapped with backward)' if world > 1 else 'single GPU',
                         final_loss=float(loss)))), flush=True)
@@ -332,6 +337,64 @@ def run_occ_loss(a, rank, world, dev):
     ddist.shutdown()
 
 
+def run_ema(a, rank, world, dev):
+    """The caller row after the optimizer step: MEGVIIEMAHook.after_train_iter on the DHD-S
+    detector's whole state dict.  A step = one EMA update; 12 algorithmic bytes per value (EMA read + write,
+    model read).  The reference's own formulation (two eager ops per state-dict entry) is timed beside it."""
+    import dhd_amd
+    from dhd_amd.detector import dhd_s_model_cfg
+    from dhd_amd.ema import ModelEMA
+    torch.manual_seed(3000 + rank)
+    model = dhd_amd.build_detector(dhd_s_model_cfg()).to(dev).train()
+    ema = ModelEMA(model, 0.9990, updates=10560)
+    n_val = sum(v.numel() for v in model.state_dict().values() if v.dtype.is_floating_point)
+    n_tensors = sum(1 for v in model.state_dict().values() if v.dtype.is_floating_point)
+    ev = []
+
+    def step(record):
+        ema.events = ev if record else None  # HIP events right around the kernel's launch
+        ema.update(None, model)
+        ema.events = None
+
+    for _ in range(a.warmup):
+        step(False)
+    torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+
+    def eager():  # ema.py:55-59 verbatim in behaviour
+        with torch.no_grad():
+            msd = model.state_dict()
+            for k, v in ema.ema.state_dict().items():
+                if v.dtype.is_floating_point:
+                    v *= 0.999
+                    v += (1.0 - 0.999) * msd[k].detach()
+    for _ in range(2):
+        eager()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        eager()
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t0) / 5 * 1e3
+    if rank == 0:
+        kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+        achieved = 12 * n_val / (kern_ms * 1e-3) / 1e9
+        print(json.dumps(dict(
+            metric='EMA updates/sec, DHD-S state dict', value=world * a.steps / elapsed, unit='updates/s', n_gpus=world, steps=a.steps,
+            warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
+            data='synthetic', config=dict(workload=f'MEGVIIEMAHook.after_train_iter on the DHD-S detector: {n_val} float32 values in '
+                                                    f'{n_tensors} tensors, one launch', parallelism=f'replicas x{world}'),
+            roofline=dict(bound='hbm', kernel='ema_update_kernel', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s',
+                          frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic('ema_update_kernel', a.batch), launch_ms=kern_ms,
+                          algorithmic_bytes=12 * n_val),
+            pytorch_eager_ms=eager_ms)), flush=True)
+    ddist.shutdown()
+
+
 def main():
     a = parse()
     rank, local, world = ddist.env_world()
@@ -345,6 +408,8 @@ def main():
     _lib.load()
     if a.workload == 'e2e':
         return run_e2e(a, rank, world, dev)
+    if a.workload == 'ema':
+        return run_ema(a, rank, world, dev)
     if a.workload == 'occ_loss':
         return run_occ_loss(a, rank, world, dev)
     hp = HotPath(dev, a.batch, 1000 + rank, not a.no_sfa, a.geometry)

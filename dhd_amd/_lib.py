@@ -102,6 +102,7 @@ _PROTOTYPES = {
     'dhd_deform_im2col': ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     'dhd_stereo_cost_volume': ([_P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P], _I),
     'dhd_deform_col2im': ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    'dhd_ema_update': ([_P, _P, _P, _I, C.c_float, C.c_float, _P], _I),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -44,6 +44,7 @@ BACKBONES = Registry('backbone')
 HEADS = Registry('head')
 DETECTORS = Registry('detector')
 LOSSES = Registry('loss')
+HOOKS = Registry('hook')
 
 
 def build_neck(cfg):
@@ -60,3 +61,8 @@ def build_head(cfg):
 
 def build_detector(cfg):
     return DETECTORS.build(cfg)
+
+
+def build_hook(cfg):
+    """One entry of a config's `custom_hooks` list (DHD-S.py:272-278)."""
+    return HOOKS.build(cfg)

@@ -372,6 +372,18 @@ int dhd_stereo_cost_volume(const float* prev_nhwc, const float* curr_nhwc, const
                            int c, int h, int w, int n_depth, float bias, int flag_channel, float* out,
                            void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * 8. Weight EMA of the training loop (projects/mmdet3d_plugin/core/hook/ema.py:48-59,
+ *    ModelEMA.update: for every floating-point entry of the state dict  v *= d; v += (1-d)*m).
+ *    One launch over a chunk table: chunk i updates len[i] float32 values at device address
+ *    ema_addr[i] from those at model_addr[i]  (ema = fl(fl(ema*decay) + fl(one_minus_decay*model)),
+ *    the reference's two roundings).  The three tables live in device memory; the caller splits its
+ *    tensors into chunks (any length > 0; 16-byte aligned starts take the vector path) and passes
+ *    one_minus_decay = (float)(1.0 - (double)decay) as the reference computes it.
+ * ------------------------------------------------------------------------------------ */
+int dhd_ema_update(const uint64_t* ema_addr, const uint64_t* model_addr, const int* len, int n_chunks,
+                   float decay, float one_minus_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

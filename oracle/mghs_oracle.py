@@ -23,7 +23,8 @@ Also restated here, each pinned the same way: the SFA attention stage (`sfa_stag
 reference's mix.py), the height loss and its label builders (G4), the occupancy-head losses (`occ_losses`,
 G6 from models/losses/semkitti_loss.py), the evaluation histogram (`occ_confusion`, definitional) and the
 LiDAR rasteriser (`points_to_maps`, G7 from datasets/pipelines/loading_new.py; equal keys of the reference's
-unstable argsort are identified as ties).  The stereo sampling grid and cost volume are pinned directly against golden G8 (the reference's
+unstable argsort are identified as ties) and the weight EMA (`ema_decay` / `ema_update`, G9 from
+core/hook/ema.py's ModelEMA, bit-exact).  The stereo sampling grid and cost volume are pinned directly against golden G8 (the reference's
 DepthNet.gen_grid / calculate_cost_volumn) without a numpy restatement.  Unpinned (no reference fixture can be
 produced here): mmcv's DCN, which the GPU tests check against its PyTorch (grid_sample) formulation instead.
 
@@ -598,3 +599,20 @@ def points_to_maps(points, height, width, downsample=1, depth_range=(1.0, 45.0),
         ties[cv[tied].astype(np.int64), cu[tied].astype(np.int64)] = True
         return depth_map, height_map, mask, ties
     return depth_map, height_map, mask
+
+
+# ---------------------------------------------------------------------------------------------
+# weight EMA of the training loop (core/hook/ema.py:31-59)
+# ---------------------------------------------------------------------------------------------
+
+def ema_decay(decay, updates):
+    """ema.py:44: exponential ramp of the decay, a Python double."""
+    import math
+    return decay * (1 - math.exp(-updates / 2000))
+
+
+def ema_update(ema, model, d):
+    """ema.py:55-59 for one float32 tensor: `v *= d; v += (1.0 - d) * m` -- torch rounds the two
+    Python doubles d and 1-d to float32 and each of the three operations to float32."""
+    v = ema.astype(f32) * f32(d)
+    return (v + (f32(1.0 - d) * model.astype(f32)).astype(f32)).astype(f32)

@@ -4,6 +4,7 @@
 #   1. kernel stats of the default bench (MGHS + SFA stage) and of --no-sfa
 #   2. PMC passes (counters only, FETCH_SIZE and WRITE_SIZE separately) of the default bench
 #   3. a plain bench line outside the profiler
+#   4. kernel stats + the two PMC passes of `bench.py --workload ema` (its kernel is merged into pmc_summary.json)
 set -u
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_new
@@ -15,6 +16,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mo -o mo -- $B --no
 P="python $R/bench.py --steps 5 --warmup 2 --cpu-samples 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o pf -- $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pw -o pw -- $P > /dev/null 2>&1
+E="python $R/bench.py --workload ema --steps 5 --warmup 2"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/es -o es -- $E 2>/dev/null | grep '^{' > $OUT/bench_ema_under_rocprof.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/ef -o ef -- $E > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/ew -o ew -- $E > /dev/null 2>&1
+cp $(find $OUT/es -name 'es_kernel_stats.csv') $OUT/ema_kernel_stats.csv
+head -1 $(find $OUT/ef -name 'ef_counter_collection.csv') > $OUT/pmc_ema.csv
+grep -h ema_update_kernel $(find $OUT/ef -name 'ef_counter_collection.csv') $(find $OUT/ew -name 'ew_counter_collection.csv') >> $OUT/pmc_ema.csv
+rm -rf $OUT/es $OUT/ef $OUT/ew
 cp $(find $OUT/hp -name 'hp_kernel_stats.csv') $OUT/hotpath_kernel_stats.csv
 cp $(find $OUT/mo -name 'mo_kernel_stats.csv') $OUT/mghs_only_kernel_stats.csv
 cp $(find $OUT/pf -name 'pf_counter_collection.csv') $OUT/pmc_fetch_size.csv
@@ -36,6 +45,7 @@ def means(path, counter):
             acc[key].append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 f, w = means(out + '/pmc_fetch_size.csv', 'FETCH_SIZE'), means(out + '/pmc_write_size.csv', 'WRITE_SIZE')
+f.update(means(out + '/pmc_ema.csv', 'FETCH_SIZE')); w.update(means(out + '/pmc_ema.csv', 'WRITE_SIZE'))  # bench.py --workload ema
 ks = {}
 for k in sorted(set(f) | set(w)):
     if k.startswith('Cijk') or 'at::native' in k or k.startswith('__amd'): continue

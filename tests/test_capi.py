@@ -88,6 +88,8 @@ def test_argument_validation_happens_on_the_host():
     assert lib.dhd_bev_pool_v2_forward(None, None, None, None, None, None, None, None, 64, 0, None) == 0  # nothing to do
     assert lib.dhd_sfa_channel_mean(None, None, 1, 512, 40000, None) == -1
     assert lib.dhd_height_band(None, 6, 65, 16, 44, None, None, None, None) == -1
+    assert lib.dhd_ema_update(None, None, None, 5, 0.5, 0.5, None) == -1
+    assert lib.dhd_ema_update(None, None, None, 0, 0.5, 0.5, None) == 0  # empty state
     d.batch = 1 << 20
     assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == -3  # beyond the int32 index space
 

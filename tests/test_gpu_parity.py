@@ -899,3 +899,70 @@ def test_stereo_cost_volume_vs_reference_golden(gpu):
     assert dn.use_hip_cost_volume
     cv = dn.calculate_cost_volumn(metas)
     np.testing.assert_allclose(cv.cpu().numpy(), g['cost_volume'], rtol=2e-4, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# weight EMA (csrc/ema.hip) -- bit-exact against the reference fixture and the oracle
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_ema_hook_on_gpu_is_bit_identical_to_reference_golden(gpu):
+    import dhd_amd
+    from test_host_logic import _Runner, ema_fixture_net, ema_fixture_step
+    g = golden('g9_ema')
+    runner = _Runner(ema_fixture_net(g, gpu))
+    hook = dhd_amd.build_hook(dict(type='MEGVIIEMAHook', init_updates=10560, priority='NORMAL'))
+    hook.before_run(runner)
+    for it in range(3):
+        ema_fixture_step(runner.model.module, it)
+        hook.after_train_iter(runner)
+        for k, v in runner.ema_model.ema.state_dict().items():
+            assert np.array_equal(v.cpu().numpy(), g[f'ema{it}.{k}']), (it, k)
+
+
+@pytest.mark.gpu
+def test_ema_update_ragged_state_vs_oracle(gpu):
+    """Tensors of 1 ... 200 001 values (several chunks, ragged tails), an integer buffer and an empty
+    parameter; a second update after load_state_dict; then an unaligned chunk through the C ABI."""
+    from oracle import mghs_oracle as O
+    from dhd_amd import _lib
+    from dhd_amd.ema import CHUNK, ModelEMA
+    sizes = [1, 3, 64, 1023, CHUNK, CHUNK + 1, 200001, 0]
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.ParameterList([torch.nn.Parameter(torch.from_numpy(syn.hash_signed(300 + i, (n,)))) for i, n in enumerate(sizes)])
+            self.register_buffer('steps', torch.zeros((), dtype=torch.long))
+            self.register_buffer('running', torch.from_numpy(syn.hash_signed(299, (5, 7))))
+    net = Net().to(gpu)
+    ema = ModelEMA(net, decay=0.999, updates=100)
+    want = {k: v.cpu().numpy().copy() for k, v in ema.ema.state_dict().items()}
+    for it in range(2):
+        with torch.no_grad():
+            for i, p in enumerate(net.p):
+                p.add_(torch.from_numpy(syn.hash_signed(400 + 10 * it + i, (sizes[i],))).to(gpu))
+            net.steps += 1
+        if it == 1:
+            ema.ema.load_state_dict(ema.ema.state_dict())   # in-place copy: the chunk table stays valid
+        ema.update(None, net)
+        d = O.ema_decay(0.999, 100 + it + 1)
+        msd = net.state_dict()
+        for k, v in ema.ema.state_dict().items():
+            if v.dtype.is_floating_point:
+                want[k] = O.ema_update(want[k], msd[k].cpu().numpy(), d)
+            assert np.array_equal(v.cpu().numpy(), want[k]), (it, k)
+    assert int(ema.ema.steps) == 0
+    # chunk starts 4 bytes past a 16-byte boundary take the scalar path: same values
+    e = torch.from_numpy(syn.hash_signed(500, (1001,))).to(gpu)
+    m = torch.from_numpy(syn.hash_signed(501, (1001,))).to(gpu)
+    ref = O.ema_update(e.cpu().numpy()[1:], m.cpu().numpy()[1:], 0.75)
+    first = float(e[0])
+    ea = torch.tensor([e.data_ptr() + 4], dtype=torch.int64, device=gpu)
+    ma = torch.tensor([m.data_ptr() + 4], dtype=torch.int64, device=gpu)
+    ln = torch.tensor([1000], dtype=torch.int32, device=gpu)
+    _lib.check(_lib.load().dhd_ema_update(_lib.ptr(ea), _lib.ptr(ma), _lib.ptr(ln), 1, 0.75, 0.25, _lib.stream_ptr(gpu)), 'ema')
+    assert np.array_equal(e.cpu().numpy()[1:], ref) and float(e[0]) == first
+    with pytest.raises(_lib.DhdError):
+        half = Net().to(gpu).half()
+        ModelEMA(half).update(None, half)

@@ -169,3 +169,82 @@ def test_stereo_grid_and_cost_volume_match_reference_fixture():
     np.testing.assert_allclose(grid.numpy(), g['grid'], rtol=1e-5, atol=1e-5)
     cv = dn.calculate_cost_volumn(metas)
     np.testing.assert_allclose(cv.numpy(), g['cost_volume'], rtol=1e-4, atol=1e-6)
+
+
+class _Wrapped(torch.nn.Module):
+    """Stand-in for the runner's MMDataParallel: `.module` is the detector."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+
+class _Runner:
+    def __init__(self, model, work_dir=None):
+        import logging
+        self.model, self.epoch, self.work_dir, self.rank = _Wrapped(model), 0, work_dir, 0
+        self.logger = logging.getLogger('test')
+
+
+def ema_fixture_net(g, device='cpu'):
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.BatchNorm2d(5), torch.nn.Linear(7, 3))
+    net.load_state_dict({k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('init.')})
+    return net.to(device)
+
+
+def ema_fixture_step(net, it):
+    """The model drift golden G9 was recorded with (tests/golden/make_golden.py)."""
+    with torch.no_grad():
+        j = 0
+        for v in net.state_dict().values():
+            if v.dtype.is_floating_point:
+                v.add_(torch.from_numpy(np.float32(0.05) * syn.hash_signed(950 + 10 * it + j, tuple(v.shape))).to(v.device))
+                j += 1
+            else:
+                v.add_(1)
+
+
+def test_ema_hook_on_cpu_matches_reference_fixture(tmp_path):
+    import dhd_amd
+    g = golden('g9_ema')
+    runner = _Runner(ema_fixture_net(g), str(tmp_path))
+    hook = dhd_amd.build_hook(dict(type='MEGVIIEMAHook', init_updates=10560, priority='NORMAL'))   # DHD-S.py:272-278
+    hook.before_run(runner)
+    assert runner.ema_model.updates == 10560 and not runner.ema_model.ema.training
+    assert all(not p.requires_grad for p in runner.ema_model.ema.parameters())
+    for it in range(3):
+        ema_fixture_step(runner.model.module, it)
+        hook.after_train_iter(runner)
+        for k, v in runner.ema_model.ema.state_dict().items():
+            assert np.array_equal(v.numpy(), g[f'ema{it}.{k}']), (it, k)
+    assert runner.ema_model.updates == int(g['updates'])
+    hook.after_train_epoch(runner)
+    cpt = torch.load(tmp_path / 'epoch_1_ema.pth')
+    assert cpt['updates'] == 10563 and cpt['epoch'] == 0
+    resumed = dhd_amd.MEGVIIEMAHook(resume=str(tmp_path / 'epoch_1_ema.pth'))
+    resumed.before_run(runner)
+    assert runner.ema_model.updates == 10563
+    for k, v in runner.ema_model.ema.state_dict().items():
+        assert np.array_equal(v.numpy(), g[f'ema2.{k}'])
+
+
+def test_control_hooks_follow_reference_schedule():
+    import dhd_amd
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4))
+    runner = _Runner(net)
+    seq = dhd_amd.build_hook(dict(type='SequentialControlHook', temporal_start_epoch=1))
+    seq.before_run(runner)
+    assert runner.model.module.with_prev is False
+    for epoch, flag in ((0, False), (1, False), (2, True)):            # strictly after the start epoch
+        runner.epoch = epoch
+        seq.before_train_epoch(runner)
+        assert runner.model.module.with_prev is flag
+    sync = dhd_amd.build_hook(dict(type='SyncbnControlHook', syncbn_start_epoch=1))
+    runner.epoch = 0
+    sync.before_train_epoch(runner)
+    assert isinstance(runner.model.module[1], torch.nn.BatchNorm2d) and not sync.is_syncbn
+    runner.epoch = 1
+    sync.before_train_epoch(runner)
+    assert isinstance(runner.model.module[1], torch.nn.SyncBatchNorm) and sync.is_syncbn
+    with pytest.raises(KeyError):
+        dhd_amd.build_hook(dict(type='NoSuchHook'))

@@ -178,3 +178,26 @@ def test_rasterise_oracle_vs_reference_code():
     for y, x in np.argwhere(ties):
         cand = p[(np.rint(p[:, 0]) == x) & (np.rint(p[:, 1]) == y)]
         assert any(c[2] == g['depth_map'][y, x] and c[3] == g['height_map'][y, x] for c in cand)
+
+
+def test_ema_update_matches_reference_fixture():
+    """Golden G9: the reference's ModelEMA (core/hook/ema.py) driven for three iterations from updates = 10560."""
+    g = golden('g9_ema')
+    keys = [k[5:] for k in g.files if k.startswith('init.')]
+    ema = {k: g['init.' + k] for k in keys}
+    model = {k: g['init.' + k].copy() for k in keys}
+    updates = int(g['updates']) - 3
+    for it in range(3):
+        j = 0
+        for k in keys:
+            if model[k].dtype.kind == 'f':
+                model[k] = (model[k] + np.float32(0.05) * syn.hash_signed(950 + 10 * it + j, model[k].shape)).astype(np.float32)
+                j += 1
+        updates += 1
+        d = O.ema_decay(float(g['decay']), updates)
+        for k in keys:
+            if ema[k].dtype.kind == 'f':
+                ema[k] = O.ema_update(ema[k], model[k], d)
+                assert np.array_equal(ema[k], g[f'ema{it}.{k}']), (it, k)
+            else:
+                assert np.array_equal(g[f'ema{it}.{k}'], g['init.' + k])   # integer buffers are left alone
