@@ -5,31 +5,43 @@
 #   2. PMC passes (counters only, FETCH_SIZE and WRITE_SIZE separately) of the default bench
 #   3. a plain bench line outside the profiler
 #   4. kernel stats + the two PMC passes of `bench.py --workload ema` (its kernel is merged into pmc_summary.json)
+# Usage: collect.sh [hotpath] [ema]   (default: both)
 set -u
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_new
+WHAT="${*:-hotpath ema}"
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+if [[ " $WHAT " == *" hotpath "* ]]; then
 B="python $R/bench.py --steps 20 --warmup 3 --cpu-samples 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hp -o hp -- $B 2>/dev/null | grep '^{' > $OUT/bench_hotpath_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mo -o mo -- $B --no-sfa 2>/dev/null | grep '^{' > $OUT/bench_mghs_only_under_rocprof.json
 P="python $R/bench.py --steps 5 --warmup 2 --cpu-samples 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o pf -- $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pw -o pw -- $P > /dev/null 2>&1
-E="python $R/bench.py --workload ema --steps 5 --warmup 2"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/es -o es -- $E 2>/dev/null | grep '^{' > $OUT/bench_ema_under_rocprof.json
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/ef -o ef -- $E > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/ew -o ew -- $E > /dev/null 2>&1
-cp $(find $OUT/es -name 'es_kernel_stats.csv') $OUT/ema_kernel_stats.csv
-head -1 $(find $OUT/ef -name 'ef_counter_collection.csv') > $OUT/pmc_ema.csv
-grep -h ema_update_kernel $(find $OUT/ef -name 'ef_counter_collection.csv') $(find $OUT/ew -name 'ew_counter_collection.csv') >> $OUT/pmc_ema.csv
-rm -rf $OUT/es $OUT/ef $OUT/ew
 cp $(find $OUT/hp -name 'hp_kernel_stats.csv') $OUT/hotpath_kernel_stats.csv
 cp $(find $OUT/mo -name 'mo_kernel_stats.csv') $OUT/mghs_only_kernel_stats.csv
 cp $(find $OUT/pf -name 'pf_counter_collection.csv') $OUT/pmc_fetch_size.csv
 cp $(find $OUT/pw -name 'pw_counter_collection.csv') $OUT/pmc_write_size.csv
 rm -rf $OUT/hp $OUT/mo $OUT/pf $OUT/pw
 cd $R && python bench.py > $OUT/bench_default.json 2>/dev/null
+fi
+cd /tmp
+if [[ " $WHAT " == *" ema "* ]]; then
+# counters only for the EMA kernel: the detector's construction launches ~30 k kernels, each of which
+# would otherwise be serialised for counter collection (35 min)
+E="python $R/bench.py --workload ema --steps 5 --warmup 2"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/es -o es -- $E 2>/dev/null | grep '^{' > $OUT/bench_ema_under_rocprof.json
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex ema_update_kernel --output-format csv -d $OUT/ef -o ef -- $E > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex ema_update_kernel --output-format csv -d $OUT/ew -o ew -- $E > /dev/null 2>&1
+cp $(find $OUT/es -name 'es_kernel_stats.csv') $OUT/ema_kernel_stats.csv
+head -1 $(find $OUT/ef -name 'ef_counter_collection.csv') > $OUT/pmc_ema.csv
+grep -h ema_update_kernel $(find $OUT/ef -name 'ef_counter_collection.csv') $(find $OUT/ew -name 'ew_counter_collection.csv') >> $OUT/pmc_ema.csv
+rm -rf $OUT/es $OUT/ef $OUT/ew
+fi
+[ -f $OUT/pmc_fetch_size.csv ] || cp $R/profiles/r1/pmc_fetch_size.csv $R/profiles/r1/pmc_write_size.csv $OUT/
+[ -f $OUT/pmc_ema.csv ] || cp $R/profiles/r1/pmc_ema.csv $OUT/ 2>/dev/null || head -1 $OUT/pmc_fetch_size.csv > $OUT/pmc_ema.csv
+cd $R
 python - <<'PY'
 import collections, csv, json, os, re
 out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/profiles_new'
