@@ -729,7 +729,8 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
                                                                size_t in_bstride, unsigned in_bytes, const float* __restrict__ coef,
                                                                const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                                unsigned* __restrict__ relu_mask, float* __restrict__ stat_part,
-                                                               float* __restrict__ y, int c, int hw) {
+                                                               float* __restrict__ y, int c, int hw, int tile0, int tile_end,
+                                                               int borrowed) {
   constexpr int kImg = COT * 3 * 64;  // 16-byte units per weight image
   constexpr int kWst = kImg / kPwBlock;
   static_assert(kImg % kPwBlock == 0, "image must split evenly over the block");
@@ -737,10 +738,10 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
   float* cf = reinterpret_cast<float*>(lds6 + 2 * kImg);
   const int nrb = c / (32 * COT);
   const int b = blockIdx.y, rb = (blockIdx.x >> 3) % nrb;
-  const int tile = (blockIdx.x / (8 * nrb)) * 8 + (blockIdx.x & 7);
+  const int tile = tile0 + (blockIdx.x / (8 * nrb)) * 8 + (blockIdx.x & 7);  // this launch covers tiles [tile0, tile_end)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  if (tile * (kPwBlock / DHD_WAVE) * 32 >= hw) return;  // padding tile of the last group (block-uniform)
+  if (tile >= tile_end || tile * (kPwBlock / DHD_WAVE) * 32 >= hw) return;  // padding tile of the last group (block-uniform)
   const int wt = tile * (kPwBlock / DHD_WAVE) + wv;     // 32-pixel wave tile
   const int nwt = (hw + 31) >> 5;
   const int p0 = wt * 32;
@@ -749,7 +750,10 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
 
   for (int i = tid; i < 3 * c; i += kPwBlock) cf[i] = coef[(size_t)b * 3 * c + i];
 
-  const u32x4* wsrc = wp + (size_t)rb * kcn * kImg;
+  // `borrowed`: the weights were packed for row blocks of twice this kernel's COT (the tail launch reads the
+  // main launch's images): this block's half of image (rb / 2, kc) starts kImg units in, images are 2 kImg apart
+  const int wk = borrowed ? 2 * kImg : kImg;
+  const u32x4* wsrc = borrowed ? wp + ((size_t)(rb >> 1) * kcn * 2 + (rb & 1)) * kImg : wp + (size_t)rb * kcn * kImg;
   u32x4 wst[kWst];
 #pragma unroll
   for (int j = 0; j < kWst; ++j) wst[j] = wsrc[j * kPwBlock + tid];
@@ -833,7 +837,7 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
     // next weight image (after the last step: a harmless reload that nobody reads)
     if (!(PWABL & 1)) {
 #pragma unroll
-      for (int j = 0; j < kWst; ++j) wst[j] = wsrc[(size_t)min(kc + 1, kcn - 1) * kImg + j * kPwBlock + tid];
+      for (int j = 0; j < kWst; ++j) wst[j] = wsrc[(size_t)min(kc + 1, kcn - 1) * wk + j * kPwBlock + tid];
     }
     if (!(PWABL & 4)) issue(cset, min(kc + 2, kcn - 1));  // past the end: a harmless reload of the last step
     const u32x4* img = lds6 + (kc & 1) * kImg + lane;
@@ -1303,7 +1307,14 @@ inline int device_index() {
     }                                                                                                               \
   } while (0)
 
-int g_gemm_mode = 1;  // 1: bf16x6 split on the bf16 MFMA (default), 0: f32 MFMA
+int g_gemm_mode = 1;  // 1: bf16x6 split on the bf16 MFMA (default), 2: the same without the tail launch, 0: f32 MFMA
+
+int cu_count() {
+  static int n[64] = {};
+  const int dev = device_index();
+  if (n[dev] == 0 && hipDeviceGetAttribute(&n[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n[dev] = -1;
+  return n[dev];
+}
 
 int launch_pack(const float* w, int transpose, float* packed, int c, hipStream_t st) {
   const int cot = pw_cot(c);
@@ -1321,19 +1332,43 @@ int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in
                    const float* bias, const float* aux, const float* aux_scsh, unsigned* relu_mask, float* stat_part, float* y, int epi, int b,
                    int c, int hw, hipStream_t st) {
   const int cot = pw_cot(c);
-  const int tiles8 = dhd_cdiv(dhd_cdiv(hw, 32 * (kPwBlock / DHD_WAVE)), 8) * 8;  // whole groups of 8; surplus tiles exit at once
-  const dim3 grid(tiles8 * (c / (32 * cot)), b);
+  const int tps = dhd_cdiv(hw, 32 * (kPwBlock / DHD_WAVE));  // 128-pixel tiles per sample
   const bool two = in1 != nullptr;
   const unsigned in_bytes = (unsigned)((size_t)in_channels * hw * sizeof(float));  // one sample of in0 (and of in1, which follows it for x)
   const size_t shmem = g_gemm_mode >= 1 ? (size_t)2 * cot * 3 * 64 * 16 + (size_t)3 * c * sizeof(float)
                                         : (size_t)(2 * cot * 512 + 3 * c) * sizeof(float);
+  // Two 256-channel workgroups fit a CU (accumulators), so the tiles run in rounds of 2 x CUs, and a last
+  // round that is mostly empty costs as much as a full one (B = 4: 2.45 rounds of work in 3).  When the
+  // remainder is small, the tiles beyond the full rounds go to a second launch of the 128-channel kernel
+  // instead (twice the workgroups, three per CU, each about half as long), reading the same packed weights.
+  int t_main = tps;
+  if (g_gemm_mode == 1 && cot == 8) {
+    const int cus = cu_count();
+    const long nrb = c / 256, n = (long)b * tps * nrb, slots = 2L * cus;
+    if (cus > 0 && n % slots != 0) {
+      const int cand = (int)((n / slots) * slots / (b * nrb)) & ~7;
+      if ((long)b * (tps - cand) * nrb * 2 <= 3L * cus) t_main = cand;
+    }
+  }
+  const int t_tail8 = dhd_cdiv(tps - t_main, 8) * 8;  // whole groups of 8; surplus tiles exit at once
+  const dim3 grid((t_main == tps ? dhd_cdiv(tps, 8) * 8 : t_main) * (c / (32 * cot)), b);
+  const dim3 grid_tail(t_tail8 * (c / 128), b);
+  const size_t shmem_tail = (size_t)2 * 4 * 3 * 64 * 16 + (size_t)3 * c * sizeof(float);
 #define DHD_PW(COT, TWO, RELU, EPI)                                                                                    \
   do {                                                                                                                 \
     if (g_gemm_mode >= 1) {                                                                                            \
-      auto kern = pw_gemm6_kernel<COT, TWO, RELU, EPI>;                                                                \
-      DHD_LDS_ATTR_ONCE(kern, shmem);                    \
-      hipLaunchKernelGGL(kern, grid, dim3(kPwBlock), shmem, st, in0, in1, in_bstride, in_bytes, coef,                  \
-                         reinterpret_cast<const u32x4*>(wp), bias, relu_mask, stat_part, y, c, hw);                           \
+      if (grid.x > 0) {                                                                                                \
+        auto kern = pw_gemm6_kernel<COT, TWO, RELU, EPI>;                                                              \
+        DHD_LDS_ATTR_ONCE(kern, shmem);                                                                                \
+        hipLaunchKernelGGL(kern, grid, dim3(kPwBlock), shmem, st, in0, in1, in_bstride, in_bytes, coef,                \
+                           reinterpret_cast<const u32x4*>(wp), bias, relu_mask, stat_part, y, c, hw, 0, t_main, 0);    \
+      }                                                                                                                \
+      if (t_main < tps) {                                                                                              \
+        auto tail = pw_gemm6_kernel<4, TWO, RELU, EPI>;                                                                \
+        DHD_LDS_ATTR_ONCE(tail, shmem_tail);                                                                           \
+        hipLaunchKernelGGL(tail, grid_tail, dim3(kPwBlock), shmem_tail, st, in0, in1, in_bstride, in_bytes, coef,      \
+                           reinterpret_cast<const u32x4*>(wp), bias, relu_mask, stat_part, y, c, hw, t_main, tps, 1);  \
+      }                                                                                                                \
     } else {                                                                                                           \
       auto kern = pw_gemm_kernel<COT, TWO, RELU, EPI>;                                                                 \
       DHD_LDS_ATTR_ONCE(kern, shmem);                    \
@@ -1415,7 +1450,7 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
 extern "C" {
 
 int dhd_sfa_set_gemm_mode(int mode) {
-  if (mode != 0 && mode != 1) return DHD_EINVAL;
+  if (mode < 0 || mode > 2) return DHD_EINVAL;
   g_gemm_mode = mode;
   return DHD_OK;
 }

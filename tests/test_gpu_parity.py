@@ -495,6 +495,34 @@ def test_sfa_stage_f32_mfma_mode_vs_torch(gpu, c, b, h, w):
         _lib.check(lib.dhd_sfa_set_gemm_mode(1), 'mode')
 
 
+@pytest.mark.parametrize('c,b,h,w', [(256, 2, 200, 200), (512, 1, 200, 200), (256, 1, 64, 72)])
+def test_sfa_stage_tail_launch_is_bit_identical_to_one_launch(gpu, c, b, h, w):
+    """GEMM mode 1 sends the tiles beyond the full rounds of 2 x CUs workgroups to a second launch of
+    128-channel workgroups (full rounds + tail at (2,256) / (1,512), tail only at the small size); mode 2
+    is one launch.  Same accumulation order per output element: every result must be bit-identical."""
+    from dhd_amd import _lib
+    from dhd_amd.mix import channel_spatial_stage
+    torch.manual_seed(c + h)
+    st = channel_spatial_stage(2 * c).to(gpu).train()
+    x = (torch.randn(b, 2 * c, h, w, device=gpu) * 0.7 + 0.1).requires_grad_()
+    g = torch.randn(b, c, h, w, device=gpu)
+    lib = _lib.load()
+    res = []
+    try:
+        for mode in (1, 2):
+            _lib.check(lib.dhd_sfa_set_gemm_mode(mode), 'mode')
+            for p in st.parameters():
+                p.grad = None
+            x.grad = None
+            out = st(x)
+            out.backward(g)
+            res.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in st.parameters()])
+    finally:
+        _lib.check(lib.dhd_sfa_set_gemm_mode(1), 'mode')
+    for a, bb in zip(*res):
+        assert torch.equal(a, bb)
+
+
 def test_fused_sfa_stage_matches_generic_path(gpu):
     """Same module, fused operator vs the blend kernels around library convolutions."""
     from dhd_amd.mix import channel_spatial_stage
