@@ -1337,15 +1337,16 @@ int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in
   const unsigned in_bytes = (unsigned)((size_t)in_channels * hw * sizeof(float));  // one sample of in0 (and of in1, which follows it for x)
   const size_t shmem = g_gemm_mode >= 1 ? (size_t)2 * cot * 3 * 64 * 16 + (size_t)3 * c * sizeof(float)
                                         : (size_t)(2 * cot * 512 + 3 * c) * sizeof(float);
-  // Two 256-channel workgroups fit a CU (accumulators), so the tiles run in rounds of 2 x CUs, and a last
-  // round that is mostly empty costs as much as a full one (B = 4: 2.45 rounds of work in 3).  When the
-  // remainder is small, the tiles beyond the full rounds go to a second launch of the 128-channel kernel
-  // instead (twice the workgroups, three per CU, each about half as long), reading the same packed weights.
+  // Two 256-channel workgroups fit a CU (accumulators), so the tiles run in rounds of 2 x CUs.  With less
+  // than two rounds of work (small batches) a partly filled round is a large share of the time: the tiles
+  // beyond the full round go to a second launch of the 128-channel kernel instead (twice the workgroups,
+  // three per CU, each about half as long), reading the same packed weights.  Measured -7 % (B = 1) and
+  // -3 % (B = 2) on the stage; with more rounds the split gains nothing (B = 4: 1.715 vs 1.714 ms).
   int t_main = tps;
   if (g_gemm_mode == 1 && cot == 8) {
     const int cus = cu_count();
     const long nrb = c / 256, n = (long)b * tps * nrb, slots = 2L * cus;
-    if (cus > 0 && n % slots != 0) {
+    if (cus > 0 && n < 2 * slots && n % slots != 0) {
       const int cand = (int)((n / slots) * slots / (b * nrb)) & ~7;
       if ((long)b * (tps - cand) * nrb * 2 <= 3L * cus) t_main = cand;
     }

@@ -265,8 +265,9 @@ typedef struct dhd_sfa_grads { /* [dev] float32 outputs, shapes as in dhd_sfa_we
 int dhd_sfa_stage_supported(int c, int hw);
 /* How the stage's C x C GEMMs are computed (process-wide, not thread-safe against running calls):
  *   1 (default) bf16 MFMA on a three-way split of every float32 operand, six products per a*b --
- *     float32-level accuracy (dropped terms < 2^-25 |a*b|) at 6/16 of the f32-MFMA cost.  A last, mostly
- *     empty round of 256-channel tiles is launched as 128-channel workgroups instead;
+ *     float32-level accuracy (dropped terms < 2^-25 |a*b|) at 6/16 of the f32-MFMA cost.  With less than
+ *     two rounds of 256-channel tiles (small batches) the tiles past the full round are launched as
+ *     128-channel workgroups instead (bit-identical results);
  *   2 as 1 without that second launch (one kernel per GEMM);
  *   0 f32 MFMA (v_mfma_f32_32x32x2_f32), a plain float32 fma chain. */
 int dhd_sfa_set_gemm_mode(int mode);
