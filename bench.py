@@ -74,7 +74,8 @@ def parse():
                    help="hotpath: MGHS + SFA stage (default). e2e: the whole DHD-S detector (dense parts on MIOpen/hipBLASLt), "
                         "forward_train + backward + AdamW step, DDP over RCCL when --gpus > 1")
     p.add_argument('--amp', choices=['off', 'bf16', 'fp16'], default='off', help='autocast dtype of the dense modules (e2e)')
-    p.add_argument('--model', choices=['dhd-s', 'dhd-m'], default='dhd-s', help='e2e: DHD-S (single frame) or DHD-M (temporal stereo)')
+    p.add_argument('--model', choices=['dhd-s', 'dhd-m', 'dhd-l'], default='dhd-s',
+                   help='e2e: DHD-S (single frame), DHD-M (temporal stereo) or DHD-L (Swin-B, 512x1408 images, temporal stereo)')
     p.add_argument('--no-ema', action='store_true', help='e2e: leave out the per-iteration weight EMA (MEGVIIEMAHook) of the configs')
     p.add_argument('--cpu-samples', type=int, default=2, help='samples for the CPU baseline leg (0 = skip)')
     return p.parse_args()
@@ -165,11 +166,15 @@ class EndToEnd:
 
     def __init__(self, dev, batch, seed, world, amp, model='dhd-s', ema=True):
         import dhd_amd
-        from dhd_amd.detector import dhd_m_model_cfg, dhd_s_model_cfg
+        from dhd_amd.detector import dhd_l_model_cfg, dhd_m_model_cfg, dhd_s_model_cfg
         torch.manual_seed(seed)
         # dhd-m: DHD-M.py (DHD_stereo: key frame + 1 adjacent + 1 stereo reference frame, D = 88, SFA with C = 512)
-        frames = 3 if model == 'dhd-m' else 1
-        self.model = dhd_amd.build_detector(dhd_m_model_cfg() if model == 'dhd-m' else dhd_s_model_cfg()).to(dev).train()
+        # dhd-l: DHD-L.py (the same wiring on a Swin-B backbone, 512 x 1408 images, 32 x 88 feature maps with 512 channels)
+        frames = 1 if model == 'dhd-s' else 3
+        cfg = {'dhd-s': dhd_s_model_cfg, 'dhd-m': dhd_m_model_cfg, 'dhd-l': dhd_l_model_cfg}[model]()
+        self.model = dhd_amd.build_detector(cfg).to(dev).train()
+        if model == 'dhd-l':
+            self.model.img_backbone.init_weights()   # trunc-normal init of the Swin linears / bias tables (swin.py:876-890)
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         self.n_params = sum(p.numel() for p in self.params)
         self.net = self.model
@@ -180,7 +185,7 @@ class EndToEnd:
         # custom_hooks of all three configs (DHD-S.py:272-278): weight EMA after every iteration
         self.ema = dhd_amd.ModelEMA(self.model, 0.9990, updates=10560) if ema else None
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        N, H, W = 6, 256, 704
+        N, (H, W) = 6, ((512, 1408) if model == 'dhd-l' else (256, 704))
         per = [syn.make_calibration(seed + 7 * f, batch, N, (H, W)) for f in range(frames)]
         calib = [t(np.concatenate([p[k] for p in per], 1)) for k in range(5)] + [t(per[0][5])]
         for f in range(1, frames):  # the ego vehicle moves 0.8 m per frame
@@ -239,9 +244,11 @@ def run_e2e(a, rank, world, dev):
             metric=f'samples/sec (6-cam fwd+bwd) {a.model.upper()} end-to-end', value=a.batch * world * a.steps / elapsed, unit='samples/s',
             n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True,
             scaling='weak', vs_baseline=None, dtype={'off': 'f32', 'bf16': 'bf16', 'fp16': 'f16'}[a.amp], data='synthetic',
-            config=dict(workload=('DHD-M (DHD_stereo: key + adjacent + stereo reference frame, D=88) whole detector' if a.model == 'dhd-m'
-                                  else 'DHD-S (configs[1]/[2]) whole detector') +
-                                 ': ResNet-50 + FPN, MGHS (HIP), BEV encoder, 3 UNets, SFA (HIP stage), predictor + losses (HIP); '
+            config=dict(workload={'dhd-m': 'DHD-M (DHD_stereo: key + adjacent + stereo reference frame, D=88) whole detector: ResNet-50 + FPN',
+                                  'dhd-l': 'DHD-L (configs[3]: DHD_stereo on 512x1408 images, D=88, 32x88 feature maps) whole detector: '
+                                           'Swin-B + FPN_LSS',
+                                  'dhd-s': 'DHD-S (configs[1]/[2]) whole detector: ResNet-50 + FPN'}[a.model] +
+                                 ', MGHS (HIP), BEV encoder, 3 UNets, SFA (HIP stage), predictor + losses (HIP); '
                                  'forward_train + backward + grad-clip + AdamW' + ('' if a.no_ema else ' + weight EMA (HIP)') + '; random init',
                         samples_per_gpu=a.batch, global_batch=a.batch * world, params=job.n_params,
                         parallelism=f'DDP x{world} (RCCL bucketed all-reduce overlapped with backward)' if world > 1 else 'single GPU',

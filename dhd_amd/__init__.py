@@ -11,6 +11,7 @@ from .lss_heightmap import MGHS, MGHS_Depth, MGHS_Stereo  # noqa: F401
 from .mix import SFA, channel_spatial_stage  # noqa: F401
 from .depthnet import HeightNet, DepthNet  # noqa: F401
 from .detector import DHD  # noqa: F401  (also registers ResNet, CustomFPN, CustomResNet, FPN_LSS, UNet, Identity, predictor)
+from .swin import SwinTransformer  # noqa: F401
 from .ema import ModelEMA, MEGVIIEMAHook, SyncbnControlHook, SequentialControlHook  # noqa: F401
 from .config import Config  # noqa: F401
 

@@ -625,6 +625,11 @@ class DHD_stereo(DHD):
             else:
                 with torch.no_grad():
                     b2, b3, _, _, feat_curr = self.prepare_bev_feat(*args)
+                # Under autocast the half-precision copies of the weights made in this no_grad pass sit in
+                # autocast's cast cache without a grad_fn; the key frame (processed last) would reuse them and
+                # its weights would silently receive no gradient.  Drop them.
+                if torch.is_autocast_enabled():
+                    torch.clear_autocast_cache()
             if not extra_ref:
                 list_2d.append(b2)
                 list_3d.append(b3)
@@ -714,5 +719,41 @@ def dhd_m_model_cfg(input_size=(256, 704)):
         img_voxel_encoder2_backbone=dict(type='UNet', n_channels=n * 8 * 2, n_classes=128), img_voxel_encoder2_neck=dict(type='Identity'),
         mix=dict(type='SFA', in_channels=1024, out_channels=512),
         occ_head=dict(type='predictor', in_dim=512, out_dim=256, Dz=16, use_mask=True, num_classes=18, use_predicter=True,
+                      class_balance=True, weight_ce=10.0, weight_geo=0.2, weight_sem=0.2,
+                      loss_occ=dict(type='CrossEntropyLoss', use_sigmoid=False, ignore_index=255, loss_weight=1.0)))
+
+
+def dhd_l_model_cfg(input_size=(512, 1408)):
+    """The model block of projects/configs/DHD/DHD-L.py:41-185 (values verbatim): Swin-B image backbone, FPN_LSS
+    necks, 512-channel view-transformer input at 1/16 of 512 x 1408 (fH x fW = 32 x 88, D = 88)."""
+    n = 64
+    band = lambda z: {'x': [-40, 40, 0.4], 'y': [-40, 40, 0.4], 'z': z, 'depth': [1.0, 45.0, 0.5]}
+    return dict(
+        type='DHD_stereo', align_after_view_transfromation=False, num_adj=1,
+        img_backbone=dict(type='SwinTransformer', pretrain_img_size=224, patch_size=4, window_size=12, mlp_ratio=4, embed_dims=128,
+                          depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], strides=(4, 2, 2, 2), out_indices=(2, 3), qkv_bias=True,
+                          qk_scale=None, patch_norm=True, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1, use_abs_pos_embed=False,
+                          return_stereo_feat=True, act_cfg=dict(type='GELU'), norm_cfg=dict(type='LN', requires_grad=True),
+                          pretrain_style='official', output_missing_index_as_none=False),
+        img_neck=dict(type='FPN_LSS', in_channels=512 + 1024, out_channels=512, extra_upsample=None, input_feature_index=(0, 1),
+                      scale_factor=2),
+        img_view_transformer=dict(
+            type='MGHS_Stereo', grid_config={'x': [-40, 40, 0.4], 'y': [-40, 40, 0.4], 'z': [-1, 5.4, 6.4], 'depth': [1.0, 45.0, 0.5]},
+            input_size=input_size, height_range=[round(-1.0 + 0.1 * i, 1) for i in range(65)], height_interval=0.1,
+            mask_range=[-1.0, 0.6, 2.2, 5.4], mask_1_grid=band([-1, 0.6, 0.4]), mask_2_grid=band([0.6, 2.2, 0.4]),
+            mask_3_grid=band([2.2, 5.4, 0.4]), in_channels=512, out_channels=n, sid=False, collapse_z=False,
+            loss_height_weight=0.1, loss_depth_weight=0.05,
+            depthnet_cfg=dict(use_dcn=False, aspp_mid_channels=96, stereo=True, bias=5.),
+            heightnet_cfg=dict(use_dcn=False, aspp_mid_channels=96), downsample=16),
+        img_bev_encoder_backbone=dict(type='CustomResNet', with_cp=True, numC_input=n * 2, num_channels=[n * 2, n * 4, n * 8]),
+        img_bev_encoder_neck=dict(type='FPN_LSS', in_channels=n * 8 + n * 2, out_channels=256),
+        pre_process=dict(type='CustomResNet', numC_input=n, num_layer=[1], num_channels=[n], stride=[1], backbone_output_ids=[0]),
+        pre_process_net_3d=dict(type='CustomResNet', numC_input=n * 16, num_layer=[1], num_channels=[n * 16], stride=[1],
+                                backbone_output_ids=[0]),
+        img_voxel_encoder0_backbone=dict(type='UNet', n_channels=n * 4 * 2, n_classes=64), img_voxel_encoder0_neck=dict(type='Identity'),
+        img_voxel_encoder1_backbone=dict(type='UNet', n_channels=n * 4 * 2, n_classes=128), img_voxel_encoder1_neck=dict(type='Identity'),
+        img_voxel_encoder2_backbone=dict(type='UNet', n_channels=n * 8 * 2, n_classes=64), img_voxel_encoder2_neck=dict(type='Identity'),
+        mix=dict(type='SFA', in_channels=512, out_channels=256),
+        occ_head=dict(type='predictor', in_dim=256, out_dim=256, Dz=16, use_mask=True, num_classes=18, use_predicter=True,
                       class_balance=True, weight_ce=10.0, weight_geo=0.2, weight_sem=0.2,
                       loss_occ=dict(type='CrossEntropyLoss', use_sigmoid=False, ignore_index=255, loss_weight=1.0)))

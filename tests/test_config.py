@@ -91,3 +91,32 @@ def test_dhd_m_config_builds_the_temporal_stereo_detector():
             assert {kk: norm(vv) for kk, vv in b.items()} == {kk: norm(ref[k][kk]) for kk in b if kk in ref[k]}, k
         else:
             assert b == ref[k], k
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason='reference tree not present on this box')
+def test_dhd_l_config_builds_with_the_swin_backbone():
+    """projects/configs/DHD/DHD-L.py (Swin-B, 512 x 1408 images, FPN_LSS necks) builds unchanged."""
+    import dhd_amd
+    from dhd_amd.config import Config
+    from dhd_amd.detector import dhd_l_model_cfg
+    cfg = Config.fromfile(os.path.join(REF_CFG, 'DHD-L.py'))
+    m = dhd_amd.build_detector(cfg.model)
+    assert type(m).__name__ == 'DHD_stereo' and type(m.img_backbone).__name__ == 'SwinTransformer'
+    assert sum(p.numel() for p in m.img_backbone.parameters()) == 86_879_608   # Swin-B, 12 x 12 windows, norms of stages 2 and 3 only
+    keys = set(m.state_dict())
+    for k in ('img_backbone.patch_embed.projection.weight', 'img_backbone.stages.2.blocks.17.attn.w_msa.relative_position_bias_table',
+              'img_backbone.stages.2.blocks.17.ffn.layers.0.0.weight', 'img_backbone.stages.2.downsample.reduction.weight',
+              'img_backbone.norm2.weight', 'img_backbone.norm3.bias', 'img_neck.conv.0.weight',
+              'img_bev_encoder_backbone.layers.0.0.conv1.weight', 'img_bev_encoder_neck.up2.4.bias'):
+        assert k in keys, k
+    assert 'img_backbone.norm0.weight' not in keys and m.img_backbone.stages[2].blocks[17].attn.w_msa.relative_position_bias_table.shape == (529, 16)
+    vt = m.img_view_transformer
+    assert vt.D == 88 and tuple(vt.frustum.shape[:3]) == (88, 32, 88)
+    ours, ref = dhd_l_model_cfg(), cfg.model
+    norm = lambda v: list(v) if isinstance(v, tuple) else v
+    assert set(ours) == set(ref)
+    for k, b in ours.items():
+        if isinstance(b, dict):
+            assert {kk: norm(vv) for kk, vv in b.items()} == {kk: norm(vv) for kk, vv in ref[k].items()}, k
+        else:
+            assert b == ref[k], k

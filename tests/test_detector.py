@@ -149,6 +149,51 @@ def test_dhd_stereo_forward_train_and_simple_test_on_gpu(gpu):
 
 
 @pytest.mark.gpu
+def test_dhd_l_wiring_with_swin_backbone_on_gpu(gpu):
+    """DHD-L.py wiring (Swin-B -> FPN_LSS -> MGHS_Stereo with 512 input channels, CustomResNet + FPN_LSS BEV
+    encoder, SFA with C = 256) through forward_train + backward on reduced images; and the Swin mirror on the
+    GPU (fused attention path) against the reference fixture G10."""
+    import dhd_amd
+    from conftest import golden
+    from dhd_amd.detector import dhd_l_model_cfg
+    from test_host_logic import swin_from_fixture
+    g = golden('g10_swin')
+    net = swin_from_fixture(g).to(gpu)
+    x = torch.from_numpy(g['x']).to(gpu).requires_grad_()
+    outs = net(x)
+    ws = [T(syn.hash_signed(2000 + i, tuple(o.shape)), gpu) for i, o in enumerate(outs)]
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+    for i, o in enumerate(outs):
+        assert np.abs(o.detach().cpu().numpy() - g[f'out{i}']).max() <= 5e-5 * max(1.0, np.abs(g[f'out{i}']).max()), i
+    assert np.abs(x.grad.cpu().numpy() - g['x_grad']).max() <= 5e-5 * np.abs(g['x_grad']).max()
+
+    torch.manual_seed(0)
+    m = dhd_amd.build_detector(dhd_l_model_cfg(input_size=(128, 352))).to(gpu).train()
+    B, N, Fr, H, W = 1, 2, 3, 128, 352
+    imgs = torch.randn(B, N * Fr, 3, H, W, device=gpu)
+    per = [syn.make_calibration(5 + f, B, N, (H, W)) for f in range(Fr)]
+    cat = lambda k: T(np.concatenate([p[k] for p in per], 1), gpu)
+    e2g = cat(1).clone()
+    e2g[:, N:2 * N, 0, 3] += 0.8
+    e2g[:, 2 * N:, 0, 3] += 1.6
+    calib = [cat(0), e2g, cat(2), cat(3), cat(4), T(per[0][5], gpu)]
+    gt_d = T(np.where(syn.hash_uniform(1, (B, N, H, W)) < 0.05, 1 + 40 * syn.hash_uniform(2, (B, N, H, W)), 0).astype(np.float32), gpu)
+    gt_h = T(np.where(syn.hash_uniform(1, (B, N, H, W)) < 0.05, -1 + 6 * syn.hash_uniform(3, (B, N, H, W)), 0).astype(np.float32), gpu)
+    sem = torch.randint(0, 18, (B, 200, 200, 16), device=gpu)
+    cam = torch.rand(B, 200, 200, 16, device=gpu) < 0.3
+    losses = m(return_loss=True, img_inputs=[imgs] + calib, gt_depth=gt_d, gt_height=gt_h, voxel_semantics=sem, mask_camera=cam)
+    total = sum(losses.values())
+    assert set(losses) == {'loss_depth', 'loss_height', 'loss_occ', 'loss_voxel_sem_scal', 'loss_voxel_geo_scal'} and torch.isfinite(total)
+    total.backward()
+    for name in ('img_backbone.patch_embed.projection.weight', 'img_backbone.stages.2.blocks.17.attn.w_msa.relative_position_bias_table',
+                 'img_backbone.stages.3.blocks.1.ffn.layers.1.weight', 'img_neck.conv.0.weight',
+                 'img_view_transformer.depth_net.cost_volumn_net.0.weight', 'img_bev_encoder_backbone.layers.2.0.conv1.weight',
+                 'mix.mysk_7.spacial_leanring.3.weight', 'occ_head.predicter.0.weight'):
+        gr = dict(m.named_parameters())[name].grad
+        assert gr is not None and torch.isfinite(gr).all() and gr.abs().sum() > 0, name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_hip_nodes_under_autocast(gpu, dtype):
     """Under autocast the dense producers hand bf16/fp16 tensors to the HIP nodes: they must cast
@@ -175,3 +220,37 @@ def test_hip_nodes_under_autocast(gpu, dtype):
         loss = sum(o.float().mean() for o in (outs[0], outs[3], outs[4], outs[5]))
     loss.backward()
     assert feat.grad is not None and torch.isfinite(feat.grad).all() and m.depth_net.weight.grad.abs().sum() > 0
+
+
+@pytest.mark.gpu
+def test_stereo_detector_under_autocast_trains_the_shared_weights(gpu):
+    """DHD_stereo runs the adjacent / reference frames first and under no_grad; autocast would cache their
+    weight casts (no grad_fn) and hand them to the key frame.  Every module both passes share must still get
+    gradients, of the same size as without autocast."""
+    import dhd_amd
+    from dhd_amd.detector import dhd_m_model_cfg
+    torch.manual_seed(0)
+    m = dhd_amd.build_detector(dhd_m_model_cfg(input_size=(64, 176))).to(gpu).train()
+    B, N, Fr = 1, 2, 3
+    imgs = torch.randn(B, N * Fr, 3, 64, 176, device=gpu)
+    per = [syn.make_calibration(5 + f, B, N, (64, 176)) for f in range(Fr)]
+    cat = lambda k: T(np.concatenate([p[k] for p in per], 1), gpu)
+    calib = [cat(0), cat(1), cat(2), cat(3), cat(4), T(per[0][5], gpu)]
+    gt_d = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, 1 + 40 * syn.hash_uniform(2, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    gt_h = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, -1 + 6 * syn.hash_uniform(3, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    sem = torch.randint(0, 18, (B, 200, 200, 16), device=gpu)
+    cam = torch.rand(B, 200, 200, 16, device=gpu) < 0.3
+    prefixes = ('img_backbone.conv1', 'img_backbone.layer3', 'img_neck.', 'img_view_transformer.depth_net.reduce_conv',
+                'img_view_transformer.height_net.reduce_conv', 'pre_process_net.')
+    names = [next(n for n, p in m.named_parameters() if n.startswith(pre) and p.dim() > 1) for pre in prefixes]
+    norms = {}
+    for amp in (None, torch.bfloat16):
+        m.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=amp or torch.bfloat16, enabled=amp is not None):
+            losses = m(return_loss=True, img_inputs=[imgs] + calib, gt_depth=gt_d, gt_height=gt_h, voxel_semantics=sem, mask_camera=cam)
+            total = sum(losses.values())
+        total.backward()
+        params = dict(m.named_parameters())
+        norms[amp] = {n: float(params[n].grad.float().norm()) if params[n].grad is not None else 0.0 for n in names}
+    for n in names:
+        assert norms[None][n] > 0 and norms[torch.bfloat16][n] > 0.2 * norms[None][n], (n, norms[None][n], norms[torch.bfloat16][n])

@@ -248,3 +248,74 @@ def test_control_hooks_follow_reference_schedule():
     assert isinstance(runner.model.module[1], torch.nn.SyncBatchNorm) and sync.is_syncbn
     with pytest.raises(KeyError):
         dhd_amd.build_hook(dict(type='NoSuchHook'))
+
+
+def swin_from_fixture(g, **kw):
+    from dhd_amd.swin import SwinTransformer
+    net = SwinTransformer(embed_dims=16, patch_size=4, window_size=4, depths=(2, 2, 2), num_heads=(2, 4, 8), strides=(4, 2, 2),
+                          out_indices=(1, 2), drop_path_rate=0.1, with_cp=False, return_stereo_feat=True, **kw).eval()
+    ref_state = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('state.')}
+    own = net.state_dict()
+    assert list(own) == list(ref_state)                                    # same keys in the same order: checkpoints load
+    for k, v in own.items():
+        assert v.shape == ref_state[k].shape and v.dtype == ref_state[k].dtype, k
+        if 'relative_position_index' in k:
+            assert torch.equal(v, ref_state[k]), k                         # the bias lookup table itself
+    net.load_state_dict(ref_state)
+    return net
+
+
+def test_swin_backbone_matches_reference_fixture():
+    """Golden G10: the reference's models/backbones/swin.py (13 x 19 tokens: window padding, odd sizes in
+    PatchMerging, shifted windows in every second block), outputs, stereo feature and input gradient."""
+    g = golden('g10_swin')
+    net = swin_from_fixture(g)
+    x = torch.from_numpy(g['x']).requires_grad_()
+    outs = net(x)
+    assert len(outs) == 3
+    for i, o in enumerate(outs):
+        ref = g[f'out{i}']
+        assert o.shape == ref.shape
+        assert np.abs(o.detach().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), i
+    ws = [torch.from_numpy(syn.hash_signed(2000 + i, tuple(o.shape))) for i, o in enumerate(outs)]
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+    assert np.abs(x.grad.numpy() - g['x_grad']).max() <= 2e-5 * np.abs(g['x_grad']).max()
+    with torch.no_grad():
+        s0 = net.forward_first_stage(x)
+    assert np.abs(s0.numpy() - g['stage0']).max() <= 2e-5 * np.abs(g['stage0']).max()
+    assert np.array_equal(s0.numpy(), outs[0].detach().numpy())          # the stereo feature is stage 0's raw output
+    # gradient checkpointing (the reference default) changes nothing
+    cp = swin_from_fixture(g)
+    for st in cp.stages:
+        st.with_cp = True
+    x2 = torch.from_numpy(g['x']).requires_grad_()
+    o2 = cp(x2)
+    sum((o * w).sum() for o, w in zip(o2, ws)).backward()
+    assert all(torch.equal(a, b) for a, b in zip(o2, outs)) and torch.allclose(x2.grad, x.grad, atol=1e-6)
+
+
+def test_swin_official_checkpoint_conversion_and_builder():
+    import dhd_amd
+    from dhd_amd.swin import convert_official_swin
+    # PatchMerging: the official order concatenates x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2]
+    C = 3
+    w = torch.arange(4 * C, dtype=torch.float32)[None].repeat(2, 1)         # value = official input channel index
+    out = convert_official_swin({'layers.0.downsample.reduction.weight': w, 'layers.0.downsample.norm.bias': w[0],
+                                 'layers.0.blocks.1.attn.qkv.weight': w, 'layers.1.blocks.0.mlp.fc1.bias': w[0],
+                                 'layers.1.blocks.0.mlp.fc2.bias': w[0], 'patch_embed.proj.weight': w, 'head.weight': w, 'norm.weight': w})
+    assert sorted(out) == sorted(['stages.0.downsample.reduction.weight', 'stages.0.downsample.norm.bias',
+                                  'stages.0.blocks.1.attn.w_msa.qkv.weight', 'stages.1.blocks.0.ffn.layers.0.0.bias',
+                                  'stages.1.blocks.0.ffn.layers.1.bias', 'patch_embed.projection.weight', 'norm.weight'])
+    got = out['stages.0.downsample.reduction.weight'][0]
+    # unfold channel c*4 + kh*2 + kw reads official group (kh, kw) -> kw*2 + kh, channel c
+    want = torch.tensor([(kw * 2 + kh) * C + c for c in range(C) for kh in range(2) for kw in range(2)], dtype=torch.float32)
+    assert torch.equal(got, want) and torch.equal(out['stages.0.downsample.norm.bias'], want)
+    net = dhd_amd.build_backbone(dict(type='SwinTransformer', embed_dims=8, depths=[1, 1], num_heads=[1, 2], strides=(4, 2),
+                                      out_indices=(0, 1), window_size=3, frozen_stages=2, output_missing_index_as_none=False,
+                                      act_cfg=dict(type='GELU'), norm_cfg=dict(type='LN', requires_grad=True)))
+    net.init_weights()
+    assert not any(p.requires_grad for p in net.patch_embed.parameters()) and not any(p.requires_grad for p in net.stages[0].parameters())
+    net.train()
+    assert not net.stages[0].training and net.stages[1].training
+    outs = net(torch.rand(1, 3, 30, 41))
+    assert [tuple(o.shape) for o in outs] == [(1, 8, 8, 11), (1, 16, 4, 6)]
