@@ -118,11 +118,15 @@ class WindowMSA(nn.Module):
     def forward(self, x, mask=None):
         """x: (B, nW, N, C) windows; mask: (nW, N, N) additive shift mask or None."""
         B, nW, N, C = x.shape
-        qkv = self.qkv(x).view(B, nW, N, 3, self.num_heads, C // self.num_heads).permute(3, 0, 1, 4, 2, 5)
+        nh = self.num_heads
+        # windows x heads as the "head" axis of a 4-D attention call: the additive term (nW * heads, N, N) is then
+        # shared by the whole batch without being copied per image, and the fused attention kernels apply
+        qkv = self.qkv(x).view(B, nW, N, 3, nh, C // nh).permute(3, 0, 1, 4, 2, 5).reshape(3, B, nW * nh, N, C // nh)
         bias = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(N, N, -1).permute(2, 0, 1)
-        bias = bias.unsqueeze(0) if mask is None else bias.unsqueeze(0) + mask.unsqueeze(1)   # (1 | nW, heads, N, N)
-        out = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=bias.unsqueeze(0).to(qkv.dtype),
+        bias = bias.unsqueeze(0).expand(nW, nh, N, N) if mask is None else bias.unsqueeze(0) + mask.unsqueeze(1)
+        out = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=bias.reshape(1, nW * nh, N, N).to(qkv.dtype),
                                              dropout_p=self.attn_drop.p if self.training else 0., scale=self.scale)
+        out = out.view(B, nW, nh, N, C // nh)
         return self.proj_drop(self.proj(out.transpose(2, 3).reshape(B, nW, N, C)))
 
 

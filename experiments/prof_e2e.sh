@@ -9,7 +9,7 @@ import collections, csv, glob, os
 f = glob.glob(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/prof_e2e/**/e_kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 t_end = max(int(r['End_Timestamp']) for r in rows)
-win = 0.4e9
+win = float(os.environ.get('WIN', '0.4')) * 1e9
 acc = collections.defaultdict(lambda: [0, 0.0])
 tot = 0
 for r in rows:
@@ -18,6 +18,6 @@ for r in rows:
         k = r['Kernel_Name'][:110]
         acc[k][0] += 1; acc[k][1] += e - s; tot += e - s
 print('GPU busy fraction in the window', round(tot / win, 3))
-for k, (n, d) in sorted(acc.items(), key=lambda x: -x[1][1])[:45]:
+for k, (n, d) in sorted(acc.items(), key=lambda x: -x[1][1])[:int(os.environ.get('TOP', '45'))]:
     print(f'{k:110s} {n:5d} {d/1e6:8.2f} ms {100*d/win:5.1f}%')
 PY

@@ -283,7 +283,7 @@ def test_swin_backbone_matches_reference_fixture():
     with torch.no_grad():
         s0 = net.forward_first_stage(x)
     assert np.abs(s0.numpy() - g['stage0']).max() <= 2e-5 * np.abs(g['stage0']).max()
-    assert np.array_equal(s0.numpy(), outs[0].detach().numpy())          # the stereo feature is stage 0's raw output
+    assert np.allclose(s0.numpy(), outs[0].detach().numpy(), atol=1e-5)    # the stereo feature is stage 0's raw output
     # gradient checkpointing (the reference default) changes nothing
     cp = swin_from_fixture(g)
     for st in cp.stages:
