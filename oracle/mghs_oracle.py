@@ -25,7 +25,8 @@ G6 from models/losses/semkitti_loss.py), the evaluation histogram (`occ_confusio
 LiDAR rasteriser (`points_to_maps`, G7 from datasets/pipelines/loading_new.py; equal keys of the reference's
 unstable argsort are identified as ties) and the weight EMA (`ema_decay` / `ema_update`, G9 from
 core/hook/ema.py's ModelEMA, bit-exact).  The stereo sampling grid and cost volume are pinned directly against golden G8 (the reference's
-DepthNet.gen_grid / calculate_cost_volumn) without a numpy restatement.  Unpinned (no reference fixture can be
+DepthNet.gen_grid / calculate_cost_volumn) without a numpy restatement, and so is the Swin backbone mirror (golden G10,
+models/backbones/swin.py).  Unpinned (no reference fixture can be
 produced here): mmcv's DCN, which the GPU tests check against its PyTorch (grid_sample) formulation instead.
 
 All file:line citations are into /root/reference/projects/mmdet3d_plugin/.
