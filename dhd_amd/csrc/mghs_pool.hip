@@ -333,25 +333,43 @@ __global__ __launch_bounds__(kBlock) void mghs_pixel_bwd(Layout L, const float* 
       slot = L.p_slot[(e & 1) * L.P + pid];
       dv = depth[pid];
     }
-    float mine = 0.f;  // <g, f> of the candidate this lane loaded
+    // v[i] = g_i[lane] * f[lane] for the 64 candidates of this batch (0 for dead ones); <g_i, f> for all of
+    // them at once by a transposing butterfly: at distance d the lanes with bit d set keep the upper half
+    // of their values and hand the lower half to their partner (and vice versa), so the number of values
+    // per lane halves at every stage: 32 + 16 + ... + 1 = 63 exchanges for 64 dot products, against seven
+    // DPP steps per dot product for separate wave reductions.  Lane i ends up with candidate i's total.
     const unsigned long long live = __ballot(slot >= 0);
-    for (int i0 = 0; i0 < nb; i0 += kGatherUnroll) {
+    float v[DHD_WAVE];
+#pragma unroll
+    for (int i0 = 0; i0 < DHD_WAVE; i0 += kGatherUnroll) {
       float g[kGatherUnroll];
+      if (i0 < nb) {  // wave-uniform
 #pragma unroll
-      for (int j = 0; j < kGatherUnroll; ++j) {
-        const int i = i0 + j;
-        g[j] = ((live >> i) & 1ull) ? gc[(size_t)lane_i(slot, i) * kTileC] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < kGatherUnroll; ++j) {
-        const int i = i0 + j;
-        if ((live >> i) & 1ull) {
-          fg = fmaf(g[j], lane_f(dv, i), fg);
-          const float tot = wave_sum_bcast(g[j] * f);
-          if (lane == i) mine = tot;
+        for (int j = 0; j < kGatherUnroll; ++j) {
+          const int i = i0 + j;
+          g[j] = ((live >> i) & 1ull) ? gc[(size_t)lane_i(slot, i) * kTileC] : 0.f;
         }
+#pragma unroll
+        for (int j = 0; j < kGatherUnroll; ++j) {
+          fg = fmaf(g[j], lane_f(dv, i0 + j), fg);  // dead candidates: g = 0
+          v[i0 + j] = g[j] * f;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < kGatherUnroll; ++j) v[i0 + j] = 0.f;
       }
     }
+#pragma unroll
+    for (int d = DHD_WAVE / 2; d >= 1; d >>= 1) {
+      const bool upper = (lane & d) != 0;
+#pragma unroll
+      for (int k = 0; k < d; ++k) {
+        const float keep = upper ? v[k + d] : v[k];
+        const float give = upper ? v[k] : v[k + d];
+        v[k] = keep + __shfl_xor(give, d, DHD_WAVE);
+      }
+    }
+    const float mine = v[0];  // <g, f> of the candidate this lane loaded
     // the two classes of a point sit in adjacent lanes: add them and let the even lane write
     const float other = __shfl_xor(mine, 1, DHD_WAVE);
     if (lane < nb && !(lane & 1)) depth_grad[p0 + ((e0 + lane) >> 1) * L.hw] = mine + other;
