@@ -314,7 +314,11 @@ __global__ __launch_bounds__(kBlock) void mghs_pixel_bwd(Layout L, const float* 
                                                           const float* __restrict__ feat, float* __restrict__ depth_grad,
                                                           float* __restrict__ feat_grad) {
   const int lane = threadIdx.x & 63;
-  const int q = rfl(blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6));  // pixel id = row of feat_nhwc (forced scalar)
+  // Workgroups go round-robin over the 8 XCDs: XCD x takes the x-th eighth of the pixels, so that the pixels
+  // that share voxels (neighbours in the image, the same camera) gather their rows through one L2.
+  const int per_xcd = gridDim.x >> 3;
+  const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int q = rfl(wg * (kBlock / DHD_WAVE) + (threadIdx.x >> 6));  // pixel id = row of feat_nhwc (forced scalar)
   if (q >= L.B * L.N * L.hw) return;
   const int bn = q / L.hw, pl = q % L.hw;
   const int p0 = bn * L.dhw + pl;  // point id of depth bin 0; bin d is p0 + d*hw
@@ -677,7 +681,7 @@ static int backward_impl(const dhd_mghs_desc* desc, const float* depth, const fl
   if (L.compact) {
     hipLaunchKernelGGL(mghs_stream_bwd, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, in);
     DHD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mghs_pixel_bwd, dim3(dhd_cdiv((long)L.B * L.N * L.hw, kBlock / DHD_WAVE)), dim3(kBlock), 0, st, L,
+    hipLaunchKernelGGL(mghs_pixel_bwd, dim3(dhd_cdiv((long)L.B * L.N * L.hw, 8 * (kBlock / DHD_WAVE)) * 8), dim3(kBlock), 0, st, L,
                        depth, feat_nhwc, depth_grad, feat_grad_nhwc);
     DHD_LAUNCH_CHECK();
     return DHD_OK;
