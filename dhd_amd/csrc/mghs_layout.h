@@ -108,6 +108,7 @@ inline int make_layout(const dhd_mghs_desc* d, void* ws, Layout* L, size_t* byte
     if (k == 1) k = 0;
     if (k >= 2) { L->sched_heavy = heavy; L->sched_ratio = k; }
   }
+  if (ws && (reinterpret_cast<uintptr_t>(ws) & 255)) return DHD_EINVAL;  // 16-byte vector access to the carved arrays
   size_t off = 0;
   char* base = static_cast<char*>(ws);
   auto carve = [&](size_t n_words) { int* p = reinterpret_cast<int*>(base + off); off = align_up(off + n_words * 4, 256); return p; };

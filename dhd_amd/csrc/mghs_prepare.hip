@@ -277,9 +277,18 @@ __global__ __launch_bounds__(kBlock) void mghs_scan(Layout L) {
   const int first = blockIdx.x * kChunk + t * kScanItems;
   int v[kScanItems];
   int tsum = 0, tz = 0;
+  // a thread owns kScanItems = 8 consecutive counters: two 16-byte loads when the chunk lies inside [0, V)
+  // (the arrays of the workspace are 256-byte aligned), scalar loads at the ragged end
+  const bool whole = first + kScanItems <= V;
+  if (whole) {
+    const int4 a = *reinterpret_cast<const int4*>(L.count + first), b = *reinterpret_cast<const int4*>(L.count + first + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) v[k] = (first + k < V) ? L.count[first + k] : 0;
+  }
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
-    v[k] = (first + k < V) ? L.count[first + k] : 0;
     tsum += v[k];
     tz += v[k] > 0;
   }
@@ -295,22 +304,36 @@ __global__ __launch_bounds__(kBlock) void mghs_scan(Layout L) {
   for (int k = 0; k < wv; ++k) { run += ws2[0][k]; runz += ws2[1][k]; }
   run += incl - tsum;
   runz += inclz - tz;
+  int off[kScanItems], nzo[kScanItems];
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
-    if (first + k < V) {
-      L.offset[first + k] = run;
-      L.nzoff[first + k] = runz;
-      if (v[k] > 0) L.nzvox[runz] = first + k;
-    }
+    off[k] = run;
+    nzo[k] = runz;
+    if (first + k < V && v[k] > 0) L.nzvox[runz] = first + k;
     run += v[k];
     runz += v[k] > 0;
     if (first + k == V - 1) { L.offset[V] = run; L.nzoff[V] = runz; }
   }
+  if (whole) {
+    *reinterpret_cast<int4*>(L.offset + first) = make_int4(off[0], off[1], off[2], off[3]);
+    *reinterpret_cast<int4*>(L.offset + first + 4) = make_int4(off[4], off[5], off[6], off[7]);
+    *reinterpret_cast<int4*>(L.nzoff + first) = make_int4(nzo[0], nzo[1], nzo[2], nzo[3]);
+    *reinterpret_cast<int4*>(L.nzoff + first + 4) = make_int4(nzo[4], nzo[5], nzo[6], nzo[7]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+      if (first + k < V) { L.offset[first + k] = off[k]; L.nzoff[first + k] = nzo[k]; }
+  }
 }
 
-__global__ __launch_bounds__(kBlock) void mghs_scatter(Layout L) {
-  const int bn = blockIdx.y;
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kBlock) void mghs_scatter(Layout L, int blocks_per_bn) {
+  // workgroups go round-robin over the XCDs: XCD x takes the x-th eighth of the points, so that the 4-byte
+  // scatters into one cache line of the sorted arrays mostly come from one L2
+  const int per_xcd = gridDim.x >> 3;
+  const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int bn = wg / blocks_per_bn;
+  if (bn >= L.B * L.N) return;
+  const int i = (wg % blocks_per_bn) * kBlock + threadIdx.x;
   if (i >= L.dhw) return;
   const int pid = bn * L.dhw + i;
   const int pix = bn * L.hw + (i % L.hw);
@@ -384,7 +407,7 @@ int dhd_mghs_prepare(const dhd_mghs_desc* desc, const dhd_calib* calib, const ui
   DHD_LAUNCH_CHECK();
   hipLaunchKernelGGL(mghs_scan, dim3(L.n_chunks), dim3(kBlock), 0, st, L);
   DHD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(mghs_scatter, gp, dim3(kBlock), 0, st, L);
+  hipLaunchKernelGGL(mghs_scatter, dim3(dhd_cdiv((long)gp.x * gp.y, 8) * 8), dim3(kBlock), 0, st, L, (int)gp.x);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }

@@ -110,7 +110,8 @@ typedef struct dhd_calib {
   const float* frustum_d;    /* (D)  */
 } dhd_calib;
 
-/* Bytes of workspace needed by dhd_mghs_prepare/forward/backward for `desc`. */
+/* Bytes of workspace needed by dhd_mghs_prepare/forward/backward for `desc`.  The workspace pointer
+ * must be 256-byte aligned (DHD_EINVAL otherwise): its arrays are read and written as 16-byte vectors. */
 int dhd_mghs_workspace_bytes(const dhd_mghs_desc* desc, size_t* bytes);
 
 /* Height argmax -> band id per pixel (height_feature_to_height_map + create_mask_3,
