@@ -126,7 +126,12 @@ __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float
   const int T = L.offset[L.V];  // total entries (device-side value, scalar load)
   // everything that steers control flow is forced into SGPRs: the compiler cannot see that
   // threadIdx.x >> 6 is wave-uniform and would otherwise predicate every branch through EXEC
-  const int a = rfl((blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6)) * DHD_WAVE);
+  // XCD x (workgroups x, x+8, ...) takes the x-th eighth of the entries actually present: entries are
+  // sorted by voxel, so one XCD's waves gather a compact part of the feature map through their L2
+  const int per_xcd = ((T + kBlock - 1) / kBlock + 7) >> 3;
+  if ((int)(blockIdx.x >> 3) >= per_xcd) return;
+  const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int a = rfl((wg * (kBlock / DHD_WAVE) + (threadIdx.x >> 6)) * DHD_WAVE);
   if (a >= T) return;
   const int b = min(T, a + DHD_WAVE);
   const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -620,7 +625,7 @@ int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const
   if (!workspace || !depth || !feat_nhwc) return DHD_EINVAL;
   if (!L.compact) return DHD_OK;  // the generic path gathers inside its row kernel
   // 2P is an upper bound of the entry count; waves past the real count exit at once
-  hipLaunchKernelGGL(mghs_gather_sums, dim3(dhd_cdiv(2L * L.P, kBlock)), dim3(kBlock), 0, dhd_stream(stream), L, depth,
+  hipLaunchKernelGGL(mghs_gather_sums, dim3(dhd_cdiv(2L * L.P, 8 * kBlock) * 8), dim3(kBlock), 0, dhd_stream(stream), L, depth,
                      feat_nhwc);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
