@@ -129,3 +129,15 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 text = open(os.path.join(base, f)).read()
                 assert 'oracle' not in text.replace('oracle-free', ''), os.path.join(base, f)
+
+
+def test_workspace_alignment_is_checked_on_the_host():
+    """The MGHS kernels access the carved workspace arrays as 16-byte vectors: a misaligned base is refused."""
+    from dhd_amd import _lib
+    lib = _lib.load()
+    d = _lib.MghsDesc()
+    d.batch, d.n_cams, d.n_depth, d.fh, d.fw, d.channels, d.n_grids = 1, 1, 4, 4, 11, 64, 1
+    d.grid[0].n[0], d.grid[0].n[1], d.grid[0].n[2] = 8, 8, 1
+    n = C.c_size_t(0)
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == 0 and n.value > 0
+    assert lib.dhd_mghs_prepare(C.byref(d), None, None, C.c_void_p(0x10004), n.value, None) == -1
