@@ -1217,20 +1217,32 @@ __global__ __launch_bounds__(kWgBlock, 2) void pw_wgrad6_kernel(const float* __r
       }
 }
 
+// gw[i] = sum over workers of partial[w][i].  A workgroup covers 64 consecutive elements x 4 worker phases: wave
+// p sums workers p, p+4, ... with 16 loads in flight per lane, the four phase sums meet in LDS (fixed order:
+// deterministic).  One thread per element with four loads in flight left the 64 MB of partials at 3 TB/s.
 __global__ __launch_bounds__(kEwBlock) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int n,
                                                                 int n_workers) {
-  const int i = blockIdx.x * kEwBlock + threadIdx.x;
-  if (i >= n) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int w = 0;
-  for (; w + 3 < n_workers; w += 4) {
-    a0 += partial[(size_t)w * n + i];
-    a1 += partial[(size_t)(w + 1) * n + i];
-    a2 += partial[(size_t)(w + 2) * n + i];
-    a3 += partial[(size_t)(w + 3) * n + i];
+  __shared__ float sm[kEwBlock];
+  constexpr int kPhases = kEwBlock / DHD_WAVE;
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int i = blockIdx.x * DHD_WAVE + lane;
+  float acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  if (i < n) {
+    int w = ph;
+    for (; w + 15 * kPhases < n_workers; w += 16 * kPhases) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[k] += partial[(size_t)(w + k * kPhases) * n + i];
+    }
+    for (; w < n_workers; w += kPhases) acc[0] += partial[(size_t)w * n + i];
   }
-  for (; w < n_workers; ++w) a0 += partial[(size_t)w * n + i];
-  gw[i] = (a0 + a1) + (a2 + a3);
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; k += 4) t += (acc[k] + acc[k + 1]) + (acc[k + 2] + acc[k + 3]);
+  sm[threadIdx.x] = t;
+  __syncthreads();
+  if (ph == 0 && i < n) gw[i] = (sm[lane] + sm[DHD_WAVE + lane]) + (sm[2 * DHD_WAVE + lane] + sm[3 * DHD_WAVE + lane]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1441,7 +1453,7 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
 #undef DHD_WG
   DHD_LAUNCH_CHECK();
   const int n = c * c;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dhd_cdiv(n, kEwBlock)), dim3(kEwBlock), 0, st, partial, gw, n, workers);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dhd_cdiv(n, DHD_WAVE)), dim3(kEwBlock), 0, st, partial, gw, n, workers);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
