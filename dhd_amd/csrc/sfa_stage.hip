@@ -340,7 +340,9 @@ __global__ __launch_bounds__(kEwBlock) void pair_sums_kernel(const float* __rest
   float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;
   int i = lo + threadIdx.x;
   for (; i + kEwBlock < hi; i += 2 * kEwBlock) {  // two independent 16-byte streams per thread
-    f32x4 a = g4[i], v = y4[i], a2 = g4[i + kEwBlock], v2 = y4[i + kEwBlock];
+    // streamed once here: non-temporal, like plane_mean (62 -> 52 us)
+    f32x4 a = __builtin_nontemporal_load(g4 + i), v = __builtin_nontemporal_load(y4 + i), a2 = __builtin_nontemporal_load(g4 + i + kEwBlock),
+          v2 = __builtin_nontemporal_load(y4 + i + kEwBlock);
     s1 += (a.x + a.y) + (a.z + a.w);
     s2 += (a.x * (v.x - mu) + a.y * (v.y - mu)) + (a.z * (v.z - mu) + a.w * (v.w - mu));
     t1 += (a2.x + a2.y) + (a2.z + a2.w);
