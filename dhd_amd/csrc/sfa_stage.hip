@@ -92,8 +92,11 @@ __global__ __launch_bounds__(kEwBlock) void plane_mean_kernel(const float* __res
   if (threadIdx.x == 0) part[plane * kPlaneChunks + blockIdx.x] = tot;
 }
 
-// one block per sample: s = mean, h = relu(fc1 s), a = sigmoid(fc2 h); blend table (a, 1-a, 0)
-__global__ __launch_bounds__(kEwBlock) void fc_forward_kernel(const float* __restrict__ part, const float* __restrict__ w1,
+// one block per sample: s = mean, h = relu(fc1 s), a = sigmoid(fc2 h); blend table (a, 1-a, 0).  The kernel is a
+// chain of dependent L2 round trips on the stage's critical path, so each phase puts all its loads in flight at
+// once: 16 waves x 4 rows of fc1 per pass, 16-byte loads of the fc2 rows.
+constexpr int kFcBlock = 1024;
+__global__ __launch_bounds__(kFcBlock) void fc_forward_kernel(const float* __restrict__ part, const float* __restrict__ w1,
                                                               const float* __restrict__ b1, const float* __restrict__ w2,
                                                               const float* __restrict__ b2, float* __restrict__ s,
                                                               float* __restrict__ hbuf, float* __restrict__ a,
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(kEwBlock) void fc_forward_kernel(const float* __res
   float* ss = sh;
   float* hh = sh + 2 * c;
   const int b = blockIdx.x, c2 = 2 * c;
-  for (int i = threadIdx.x; i < c2; i += kEwBlock) {
+  for (int i = threadIdx.x; i < c2; i += kFcBlock) {
     const float* q = part + ((size_t)b * c2 + i) * kPlaneChunks;
     float v = ((q[0] + q[1]) + (q[2] + q[3])) / (float)hw;
     ss[i] = v;
@@ -110,8 +113,8 @@ __global__ __launch_bounds__(kEwBlock) void fc_forward_kernel(const float* __res
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // four rows per pass so that their loads are in flight together
-  for (int j0 = wv * 4; j0 < r; j0 += 4 * (kEwBlock / DHD_WAVE)) {
+  // four rows per wave and pass so that their loads are in flight together
+  for (int j0 = wv * 4; j0 < r; j0 += 4 * (kFcBlock / DHD_WAVE)) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = lane; i < c2; i += DHD_WAVE) {
       const float sv = ss[i];
@@ -130,10 +133,21 @@ __global__ __launch_bounds__(kEwBlock) void fc_forward_kernel(const float* __res
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < c; k += kEwBlock) {
+  for (int k = threadIdx.x; k < c; k += kFcBlock) {
     float acc = b2[k];
+    if ((r & 3) == 0) {
+      const f32x4* wrow = reinterpret_cast<const f32x4*>(w2 + (size_t)k * r);
 #pragma unroll 8
-    for (int j = 0; j < r; ++j) acc = fmaf(w2[(size_t)k * r + j], hh[j], acc);
+      for (int j = 0; j < (r >> 2); ++j) {
+        const f32x4 wv4 = wrow[j];
+        acc = fmaf(wv4.x, hh[4 * j], acc);
+        acc = fmaf(wv4.y, hh[4 * j + 1], acc);
+        acc = fmaf(wv4.z, hh[4 * j + 2], acc);
+        acc = fmaf(wv4.w, hh[4 * j + 3], acc);
+      }
+    } else {
+      for (int j = 0; j < r; ++j) acc = fmaf(w2[(size_t)k * r + j], hh[j], acc);
+    }
     float v = sigmoidf_(acc);
     a[(size_t)b * c + k] = v;
     float* t = tab + (size_t)b * 3 * c;
@@ -1504,7 +1518,7 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
   const int nwt = (hw + 31) / 32;
 
   hipLaunchKernelGGL(plane_mean_kernel, planes2, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw);
-  hipLaunchKernelGGL(fc_forward_kernel, dim3(b), dim3(kEwBlock), (size_t)(2 * c + r) * sizeof(float), st, sc + T.mean_part,
+  hipLaunchKernelGGL(fc_forward_kernel, dim3(b), dim3(kFcBlock), (size_t)(2 * c + r) * sizeof(float), st, sc + T.mean_part,
                      w->fc1_w, w->fc1_b, w->fc2_w, w->fc2_b, sv + S.s, sv + S.h, sv + S.a1, sv + S.tab_a, c, r, hw);
   DHD_LAUNCH_CHECK();
   int rc = launch_pack(w->conv1_w, 0, sc + T.wp1, c, st);
