@@ -282,20 +282,38 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
   const int nvec = sg.nvox / 4;
   const float* og = og_in.p[sg.g];
   const long sb = og_in.sb[sg.g], sz = og_in.sz[sg.g], sc = og_in.sc[sg.g];
+  // Only ~7 % of the voxels (~56 % of the 128-byte lines of out_grad) hold a point, and the gradient of every other
+  // voxel is never needed: a lane reads its 16 bytes only if one of its four voxels does.  The loads stay
+  // unconditional instructions (lanes without work re-read one resident dummy line), so that the four of a channel
+  // run are in flight together instead of each waiting behind a branch.
+  constexpr int kIter = kSegMaxVox / 4 / DHD_WAVE;  // float4 groups per lane and channel run
+  uint2 sl[kIter];
+  __syncthreads();  // slot_of complete
+#pragma unroll
+  for (int k = 0; k < kIter; ++k) {
+    const int i = lane + k * DHD_WAVE;
+    sl[k] = make_uint2(0u, 0u);
+    if (i < nvec) sl[k] = *reinterpret_cast<const uint2*>(slot_of + 4 * i);
+  }
   for (int c_lo = 0; c_lo < kTileC; c_lo += cp) {
     __syncthreads();
     for (int cc = wv; cc < cp; cc += kStreamWaves) {
       const vfloat4* src = reinterpret_cast<const vfloat4*>(
           og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)(c_lo + cc) * sc + (size_t)sg.y0 * sg.nx);
-      for (int i = lane; i < nvec; i += DHD_WAVE) {
-        const uint2 sl = *reinterpret_cast<const uint2*>(slot_of + 4 * i);
-        const vfloat4 v = __builtin_nontemporal_load(src + i);
-        if (sl.x | sl.y) {
-          const unsigned s0 = sl.x & 0xffffu, s1 = sl.x >> 16, s2 = sl.y & 0xffffu, s3 = sl.y >> 16;
-          if (s0) table[(s0 - 1) * cp + cc] = v.x;
-          if (s1) table[(s1 - 1) * cp + cc] = v.y;
-          if (s2) table[(s2 - 1) * cp + cc] = v.z;
-          if (s3) table[(s3 - 1) * cp + cc] = v.w;
+      vfloat4 v[kIter];
+#pragma unroll
+      for (int k = 0; k < kIter; ++k) {
+        const vfloat4* p = (sl[k].x | sl[k].y) ? src + lane + k * DHD_WAVE : reinterpret_cast<const vfloat4*>(L.vsum);
+        v[k] = __builtin_nontemporal_load(p);
+      }
+#pragma unroll
+      for (int k = 0; k < kIter; ++k) {
+        if (sl[k].x | sl[k].y) {
+          const unsigned s0 = sl[k].x & 0xffffu, s1 = sl[k].x >> 16, s2 = sl[k].y & 0xffffu, s3 = sl[k].y >> 16;
+          if (s0) table[(s0 - 1) * cp + cc] = v[k].x;
+          if (s1) table[(s1 - 1) * cp + cc] = v[k].y;
+          if (s2) table[(s2 - 1) * cp + cc] = v[k].z;
+          if (s3) table[(s3 - 1) * cp + cc] = v[k].w;
         }
       }
     }
