@@ -41,7 +41,33 @@ def _worker(rank, world, port, q):
     x, mlp = torch.randn(2, 16, 4, 6, generator=g), torch.randn(1, 2, 27, generator=g)
     ddp(x, mlp).square().mean().backward()
     grad = net.depth_conv[-1].weight.grad.clone()
-    q.put((rank, (lo, hi), slow, total, grad.flatten().tolist()))  # plain data: no fd passing after exit
+    # the runner's model is a wrapper whose .module is the detector; with the detector itself wrapped once more
+    # (DDP) the EMA hook must unwrap both levels (core/hook/ema.py:39-40,52-53): one SGD step, one EMA update
+    import logging
+    from dhd_amd import build_hook
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+    class Runner:
+        pass
+    runner = Runner()
+    runner.model, runner.epoch, runner.rank, runner.logger = Wrapper(ddp), 0, rank, logging.getLogger('t')
+    hook = build_hook(dict(type='MEGVIIEMAHook', init_updates=10560))
+    hook.before_run(runner)
+    assert runner.ema_model.ema is not net and type(runner.ema_model.ema).__name__ == 'HeightNet'
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.grad is not None:
+                p -= 0.1 * p.grad
+    hook.after_train_iter(runner)
+    ema_w = runner.ema_model.ema.depth_conv[-1].weight
+    d = 0.9990 * (1 - __import__('math').exp(-10561 / 2000))
+    moved = float((ema_w - net.depth_conv[-1].weight).abs().max())
+    want = float((d * (net.depth_conv[-1].weight + 0.1 * grad) + (1 - d) * net.depth_conv[-1].weight - ema_w).abs().max())
+    q.put((rank, (lo, hi), slow, total, grad.flatten().tolist(), ema_w.detach().flatten().tolist(), moved, want))  # plain data
     D.shutdown()
 
 
@@ -61,6 +87,9 @@ def test_gloo_world_size_2_sharding_timing_and_ddp():
     assert res[0][3] == res[1][3] == 7.0
     g0, g1 = torch.tensor(res[0][4]), torch.tensor(res[1][4])
     assert torch.allclose(g0, g1) and g0.abs().sum() > 0  # averaged gradients agree
+    e0, e1 = torch.tensor(res[0][5]), torch.tensor(res[1][5])
+    assert torch.equal(e0, e1)                                  # the EMA copies of the replicas stay identical
+    assert res[0][6] > 0 and res[0][7] < 1e-6                    # ema = d * old + (1 - d) * new
 
 
 def test_shard_range_properties():
