@@ -103,6 +103,10 @@ _PROTOTYPES = {
     'dhd_stereo_cost_volume': ([_P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P], _I),
     'dhd_deform_col2im': ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     'dhd_ema_update': ([_P, _P, _P, _I, C.c_float, C.c_float, _P], _I),
+    'dhd_bn_supported': ([_I, _I, _I, _I], _I),
+    'dhd_bn_workspace_bytes': ([_I, _I, _I], C.c_size_t),
+    'dhd_bn_train_forward': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P], _I),
+    'dhd_bn_train_backward': ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -1,0 +1,93 @@
+"""Training-mode BatchNorm2d of the dense callers as a HIP operator (csrc/batchnorm.hip).
+
+`BatchNorm2d` is `torch.nn.BatchNorm2d` (same parameters, buffers and state-dict keys) whose training
+forward/backward on a GPU run as three streaming launches each instead of MIOpen's kernels (which move these
+activations at 0.7-3.6 TB/s: 11 % of a DHD-S training step).  Everything else -- eval mode, CPU tensors, shapes
+the kernels do not cover (H*W not a multiple of 4 / 8 elements) -- takes the parent's path unchanged."""
+import torch
+from torch import nn
+
+from . import _lib
+
+_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+class _BNTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, factor, eps):
+        n, c = x.shape[:2]
+        hw = x[0, 0].numel()
+        lib = _lib.load()
+        dev = x.device
+        with torch.cuda.device(dev):
+            y = torch.empty_like(x)
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            rstd = torch.empty_like(mean)
+            ws = torch.empty(lib.dhd_bn_workspace_bytes(n, c, hw), dtype=torch.uint8, device=dev)
+            _lib.check(lib.dhd_bn_train_forward(_lib.ptr(x), _DTYPES[x.dtype], n, c, hw, _lib.ptr(weight), _lib.ptr(bias),
+                                                _lib.ptr(running_mean), _lib.ptr(running_var), factor, eps, _lib.ptr(y), _lib.ptr(mean),
+                                                _lib.ptr(rstd), _lib.ptr(ws), _lib.stream_ptr(dev)), 'dhd_bn_train_forward')
+        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        n, c = x.shape[:2]
+        hw = x[0, 0].numel()
+        lib = _lib.load()
+        dev = x.device
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        with torch.cuda.device(dev):
+            gx = torch.empty_like(x)
+            dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+            dbeta = torch.empty_like(dgamma)
+            ws = torch.empty(lib.dhd_bn_workspace_bytes(n, c, hw), dtype=torch.uint8, device=dev)
+            _lib.check(lib.dhd_bn_train_backward(_lib.ptr(x), _lib.ptr(gy), _DTYPES[x.dtype], n, c, hw, _lib.ptr(weight), _lib.ptr(mean),
+                                                 _lib.ptr(rstd), _lib.ptr(gx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
+                                                 _lib.stream_ptr(dev)), 'dhd_bn_train_backward')
+        gw = dgamma.to(weight.dtype) if weight is not None and ctx.needs_input_grad[1] else None
+        gb = dbeta if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, None, None, None
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """Drop-in for nn.BatchNorm2d; `use_hip = False` switches the operator off.
+
+    Measured on MI355X (experiments/bn_native_vs_miopen.py, forward + backward): MIOpen parallelises over channels
+    and collapses on few-channel, large-plane tensors -- (24, 64, 128, 352) float16: 922 us against 247 us here --
+    while for many-channel tensors it is on par and this Python-level operator costs more host time per call
+    (~0.2 ms).  Hence the operator only takes tensors of at least `min_numel` elements with at most
+    `max_channels` channels, or of at least `big_numel` elements."""
+
+    use_hip = True
+    min_numel, max_channels, big_numel = 1 << 24, 128, 1 << 26
+
+    def _hip_ok(self, x, force=False):
+        if not (self.use_hip and self.training and x.is_cuda and x.dim() == 4 and x.dtype in _DTYPES and x.numel() > 0):
+            return False
+        if not force and not ((x.numel() >= self.min_numel and x.shape[1] <= self.max_channels) or x.numel() >= self.big_numel):
+            return False
+        if self.weight is not None and (self.weight.dtype != torch.float32 or (self.bias is not None and self.bias.dtype != torch.float32)):
+            return False
+        if self.track_running_stats and self.running_mean.dtype != torch.float32:
+            return False
+        n, c = x.shape[:2]
+        return bool(_lib.load().dhd_bn_supported(_DTYPES[x.dtype], n, c, x[0, 0].numel()))
+
+    def forward(self, x):
+        if not self._hip_ok(x):
+            return super().forward(x)
+        self._check_input_dim(x)
+        factor = 0.0 if self.momentum is None else self.momentum
+        rm = rv = None
+        if self.track_running_stats:
+            rm, rv = self.running_mean, self.running_var
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+                if self.momentum is None:
+                    factor = 1.0 / float(self.num_batches_tracked)
+        return _BNTrain.apply(x.contiguous(), self.weight, self.bias, rm, rv, float(factor), float(self.eps))

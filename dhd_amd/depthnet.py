@@ -16,6 +16,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
+from .batchnorm import BatchNorm2d
+
 
 class BasicBlock(nn.Module):
     expansion = 1
@@ -23,9 +25,9 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
@@ -209,7 +211,7 @@ class _LiftNetBase(nn.Module):
     def _build(self, in_channels, mid_channels, depth_channels, use_dcn, use_aspp, with_cp, stereo, bias,
                aspp_mid_channels):
         self.reduce_conv = nn.Sequential(nn.Conv2d(in_channels, mid_channels, 3, stride=1, padding=1),
-                                         nn.BatchNorm2d(mid_channels), nn.ReLU(inplace=True))
+                                         BatchNorm2d(mid_channels), nn.ReLU(inplace=True))
         self.bn = nn.BatchNorm1d(27)
         self.depth_mlp = Mlp(27, mid_channels, mid_channels)
         self.depth_se = SELayer(mid_channels)
@@ -219,7 +221,7 @@ class _LiftNetBase(nn.Module):
             downsample = nn.Conv2d(conv_in, mid_channels, 1, 1, 0)
             cv = []
             for _ in range(2):
-                cv += [nn.Conv2d(depth_channels, depth_channels, 3, stride=2, padding=1), nn.BatchNorm2d(depth_channels)]
+                cv += [nn.Conv2d(depth_channels, depth_channels, 3, stride=2, padding=1), BatchNorm2d(depth_channels)]
             self.cost_volumn_net = nn.Sequential(*cv)
             self.bias = bias
         self._stack_args = (mid_channels, depth_channels, conv_in, downsample, use_dcn, use_aspp, aspp_mid_channels)

@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
+from .batchnorm import BatchNorm2d
 from .depthnet import BasicBlock
 from .registry import BACKBONES, DETECTORS, HEADS, NECKS, build_backbone, build_head, build_neck
 
@@ -37,11 +38,11 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)  # style='pytorch'
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.bn3 = BatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
@@ -64,14 +65,14 @@ class ResNet(nn.Module):
         blocks = self.arch[depth][:num_stages]
         self.out_indices, self.with_cp, self.norm_eval = tuple(out_indices), with_cp, norm_eval
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
         inplanes = 64
         self.res_layers = []
         for i, n in enumerate(blocks):
             planes, stride = 64 * 2 ** i, 1 if i == 0 else 2
-            down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+            down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), BatchNorm2d(planes * 4))
             layer = [Bottleneck(inplanes, planes, stride, down)]
             inplanes = planes * 4
             layer += [Bottleneck(inplanes, planes) for _ in range(n - 1)]
@@ -105,7 +106,7 @@ class ConvModule(nn.Module):
     def __init__(self, cin, cout, k, stride=1, padding=0, norm=False, act=False, bias='auto'):
         super().__init__()
         self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=(not norm) if bias == 'auto' else bias)
-        self.bn = nn.BatchNorm2d(cout) if norm else None
+        self.bn = BatchNorm2d(cout) if norm else None
         self.act = nn.ReLU(inplace=True) if act else None
 
     def forward(self, x):
@@ -177,16 +178,16 @@ class FPN_LSS(nn.Module):
         self.up = nn.Upsample(scale_factor=scale_factor, mode='bilinear', align_corners=True)
         f = 2 if self.extra_upsample else 1
         self.conv = nn.Sequential(
-            nn.Conv2d(in_channels, out_channels * f, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels * f), nn.ReLU(inplace=True),
-            nn.Conv2d(out_channels * f, out_channels * f, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels * f), nn.ReLU(inplace=True))
+            nn.Conv2d(in_channels, out_channels * f, 3, padding=1, bias=False), BatchNorm2d(out_channels * f), nn.ReLU(inplace=True),
+            nn.Conv2d(out_channels * f, out_channels * f, 3, padding=1, bias=False), BatchNorm2d(out_channels * f), nn.ReLU(inplace=True))
         if self.extra_upsample:
             self.up2 = nn.Sequential(
                 nn.Upsample(scale_factor=extra_upsample, mode='bilinear', align_corners=True),
-                nn.Conv2d(out_channels * f, out_channels, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True),
+                nn.Conv2d(out_channels * f, out_channels, 3, padding=1, bias=False), BatchNorm2d(out_channels), nn.ReLU(inplace=True),
                 nn.Conv2d(out_channels, out_channels, 1, padding=0))
         self.lateral = lateral is not None
         if self.lateral:
-            self.lateral_conv = nn.Sequential(nn.Conv2d(lateral, lateral, 1, bias=False), nn.BatchNorm2d(lateral), nn.ReLU(inplace=True))
+            self.lateral_conv = nn.Sequential(nn.Conv2d(lateral, lateral, 1, bias=False), BatchNorm2d(lateral), nn.ReLU(inplace=True))
 
     def forward(self, feats):
         x2, x1 = feats[self.input_feature_index[0]], feats[self.input_feature_index[1]]
@@ -200,8 +201,8 @@ class _DoubleConv(nn.Module):
     def __init__(self, cin, cout, mid=None):
         super().__init__()
         mid = mid or cout
-        self.double_conv = nn.Sequential(nn.Conv2d(cin, mid, 3, padding=1, bias=False), nn.BatchNorm2d(mid), nn.ReLU(inplace=True),
-                                         nn.Conv2d(mid, cout, 3, padding=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+        self.double_conv = nn.Sequential(nn.Conv2d(cin, mid, 3, padding=1, bias=False), BatchNorm2d(mid), nn.ReLU(inplace=True),
+                                         nn.Conv2d(mid, cout, 3, padding=1, bias=False), BatchNorm2d(cout), nn.ReLU(inplace=True))
 
     def forward(self, x):
         return self.double_conv(x)

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .batchnorm import BatchNorm2d
 from .registry import NECKS
 
 
@@ -210,9 +211,9 @@ class channel_spatial_stage(nn.Module):
                                 nn.Linear(features // reduction, self.channels), nn.Sigmoid())
         self.spacial_leanring = nn.Sequential(
             nn.Conv2d(self.channels, self.channels, kernel_size=1, stride=1, padding=0),
-            nn.BatchNorm2d(self.channels), nn.ReLU(inplace=True),
+            BatchNorm2d(self.channels), nn.ReLU(inplace=True),
             nn.Conv2d(self.channels, self.channels, kernel_size=1, stride=1, padding=0),
-            nn.BatchNorm2d(self.channels))
+            BatchNorm2d(self.channels))
         self.sigmoid = nn.Sigmoid()
 
     fused = True  # set False to force the generic path (library convolutions between the blend kernels)
@@ -233,12 +234,12 @@ class SFA(nn.Module):
         self.out_channels = out_channels
         self.mix_residual = nn.Sequential(
             nn.Conv2d(in_channels // 2, out_channels, kernel_size=3, stride=stride, padding=1, bias=False),
-            nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True),
+            BatchNorm2d(out_channels), nn.ReLU(inplace=True),
             nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1, bias=False),
-            nn.BatchNorm2d(out_channels))
+            BatchNorm2d(out_channels))
         self.mix_shortcut = nn.Sequential(
             nn.Conv2d(in_channels, out_channels, stride=stride, kernel_size=1, bias=False),
-            nn.BatchNorm2d(out_channels))
+            BatchNorm2d(out_channels))
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, inputs):

@@ -388,6 +388,24 @@ int dhd_stereo_cost_volume(const float* prev_nhwc, const float* curr_nhwc, const
 int dhd_ema_update(const uint64_t* ema_addr, const uint64_t* model_addr, const int* len, int n_chunks,
                    float decay, float one_minus_decay, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * 9. Training-mode BatchNorm2d of the dense callers (torch.nn.BatchNorm2d semantics: biased batch
+ *    variance for the normalisation, unbiased for running_var, running = (1-factor)*running +
+ *    factor*batch).  x, y, grad_y, grad_x: (n, c, hw) NCHW in `dtype` (0 float32, 1 float16,
+ *    2 bfloat16); parameters, statistics and gradients of the parameters float32; gamma / beta /
+ *    running_* / dgamma / dbeta may be NULL.  hw must be a multiple of 4 (float32) or 8 elements and
+ *    n*c <= 65535 (dhd_bn_supported).  save_mean / save_rstd carry the batch statistics to backward.
+ * ------------------------------------------------------------------------------------ */
+int dhd_bn_supported(int dtype, int n, int c, int hw);
+size_t dhd_bn_workspace_bytes(int n, int c, int hw);
+int dhd_bn_train_forward(const void* x, int dtype, int n, int c, int hw, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float factor,
+                         float eps, void* y, float* save_mean, float* save_rstd, void* workspace,
+                         void* stream);
+int dhd_bn_train_backward(const void* x, const void* grad_y, int dtype, int n, int c, int hw,
+                          const float* gamma, const float* save_mean, const float* save_rstd,
+                          void* grad_x, float* dgamma, float* dbeta, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,9 @@ def test_argument_validation_happens_on_the_host():
     assert lib.dhd_sfa_channel_mean(None, None, 1, 512, 40000, None) == -1
     assert lib.dhd_height_band(None, 6, 65, 16, 44, None, None, None, None) == -1
     assert lib.dhd_ema_update(None, None, None, 5, 0.5, 0.5, None) == -1
+    assert lib.dhd_bn_supported(1, 24, 64, 128 * 352) == 1 and lib.dhd_bn_supported(1, 4, 64, 2500) == 0 and lib.dhd_bn_supported(0, 4, 64, 2500) == 1
+    assert lib.dhd_bn_supported(0, 70000, 1, 64) == 0 and lib.dhd_bn_workspace_bytes(24, 64, 45056) == (24 * 16 * 2 * 64 + 3 * 64) * 4
+    assert lib.dhd_bn_train_forward(None, 0, 2, 8, 64, None, None, None, None, 0.1, 1e-5, None, None, None, None, None) == -1
     assert lib.dhd_ema_update(None, None, None, 0, 0.5, 0.5, None) == 0  # empty state
     d.batch = 1 << 20
     assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == -3  # beyond the int32 index space

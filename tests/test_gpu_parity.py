@@ -994,3 +994,48 @@ def test_ema_update_ragged_state_vs_oracle(gpu):
     with pytest.raises(_lib.DhdError):
         half = Net().to(gpu).half()
         ModelEMA(half).update(None, half)
+
+
+# ---------------------------------------------------------------------------------------------
+# training-mode BatchNorm2d of the dense callers (csrc/batchnorm.hip) vs torch.nn.BatchNorm2d
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize('shape', [(6, 64, 32, 88), (3, 130, 16, 44), (2, 8, 200, 200), (1, 5, 4, 4), (24, 16, 8, 22)])
+def test_batchnorm2d_training_vs_torch(gpu, dtype, tol, shape):
+    """y, running statistics, num_batches_tracked, and the gradients of x / weight / bias against torch's own
+    BatchNorm2d on float32 copies of the same (rounded) inputs; second step with momentum=None (cumulative average)."""
+    from dhd_amd.batchnorm import BatchNorm2d
+    BatchNorm2d = type('AlwaysHipBN', (BatchNorm2d,), dict(min_numel=0, big_numel=0, max_channels=1 << 30))  # no size threshold
+    torch.manual_seed(sum(shape))
+    n, c, h, w = shape
+    for momentum in (0.1, None):
+        ours = BatchNorm2d(c, momentum=momentum).to(gpu).train()
+        ref = torch.nn.BatchNorm2d(c, momentum=momentum).to(gpu).train()
+        with torch.no_grad():
+            ours.weight.copy_(torch.rand(c) + 0.5); ours.bias.copy_(torch.randn(c))
+            ours.running_mean.copy_(torch.randn(c)); ours.running_var.copy_(torch.rand(c) + 0.5)
+        ref.load_state_dict(ours.state_dict())
+        for step in range(2):
+            x = (torch.randn(shape, device=gpu) * 1.7 + 3.0).to(dtype).requires_grad_()
+            g = torch.randn(shape, device=gpu).to(dtype)
+            xr = x.detach().float().requires_grad_()
+            assert ours._hip_ok(x) == ((h * w) % (4 if dtype == torch.float32 else 8) == 0)
+            y = ours(x)
+            y.backward(g)
+            yr = ref(xr)
+            yr.backward(g.float())
+            assert y.dtype == dtype and x.grad.dtype == dtype
+            assert (y.float() - yr).abs().max() <= tol * max(1.0, float(yr.abs().max()))
+            assert (x.grad.float() - xr.grad).abs().max() <= tol * max(1.0, float(xr.grad.abs().max()))
+            for a, b in ((ours.weight.grad, ref.weight.grad), (ours.bias.grad, ref.bias.grad)):
+                assert (a - b).abs().max() <= tol * max(1.0, float(b.abs().max())) * (1 if dtype == torch.float32 else 4)
+            assert torch.allclose(ours.running_mean, ref.running_mean, atol=1e-5, rtol=1e-5)
+            assert torch.allclose(ours.running_var, ref.running_var, atol=1e-5, rtol=1e-4)
+            assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+            ours.zero_grad(); ref.zero_grad()
+    ours.eval()
+    with torch.no_grad():     # eval mode is the parent's path
+        x = torch.randn(shape, device=gpu).to(dtype)
+        assert torch.equal(ours(x), torch.nn.functional.batch_norm(x, ours.running_mean, ours.running_var, ours.weight, ours.bias, False, 0.0, ours.eps))
