@@ -4,6 +4,8 @@
 forward/backward on a GPU run as three streaming launches each instead of MIOpen's kernels (which move these
 activations at 0.7-3.6 TB/s: 11 % of a DHD-S training step).  Everything else -- eval mode, CPU tensors, shapes
 the kernels do not cover (H*W not a multiple of 4 / 8 elements) -- takes the parent's path unchanged."""
+import os
+
 import torch
 from torch import nn
 
@@ -61,10 +63,12 @@ class BatchNorm2d(nn.BatchNorm2d):
     and collapses on few-channel, large-plane tensors -- (24, 64, 128, 352) float16: 922 us against 247 us here --
     while for many-channel tensors it is on par and this Python-level operator costs more host time per call
     (~0.2 ms).  Hence the operator only takes tensors of at least `min_numel` elements with at most
-    `max_channels` channels, or of at least `big_numel` elements."""
+    `max_channels` channels, or of at least `big_numel` elements (`DHD_BN_ROUTING=min,max_c,big` overrides; lower
+    thresholds measured slower end to end: 78.1 / 78.9 / 80.4 ms per DHD-S step for 16M,128,64M / 4M,128,32M /
+    1M,256,16M)."""
 
     use_hip = True
-    min_numel, max_channels, big_numel = 1 << 24, 128, 1 << 26
+    min_numel, max_channels, big_numel = (int(v) for v in os.environ.get('DHD_BN_ROUTING', f'{1 << 24},128,{1 << 26}').split(','))
 
     def _hip_ok(self, x, force=False):
         if not (self.use_hip and self.training and x.is_cuda and x.dim() == 4 and x.dtype in _DTYPES and x.numel() > 0):
