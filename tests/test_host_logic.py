@@ -319,3 +319,20 @@ def test_swin_official_checkpoint_conversion_and_builder():
     assert not net.stages[0].training and net.stages[1].training
     outs = net(torch.rand(1, 3, 30, 41))
     assert [tuple(o.shape) for o in outs] == [(1, 8, 8, 11), (1, 16, 4, 6)]
+
+
+def test_batchnorm2d_subclass_is_transparent_off_the_gpu():
+    """dhd_amd.batchnorm.BatchNorm2d: same state-dict keys and the parent's numerics for CPU tensors / eval mode;
+    SyncBatchNorm conversion (SyncbnControlHook) still recognises it."""
+    from dhd_amd.batchnorm import BatchNorm2d
+    torch.manual_seed(0)
+    a, b = BatchNorm2d(6), torch.nn.BatchNorm2d(6)
+    assert list(a.state_dict()) == list(b.state_dict()) and isinstance(a, torch.nn.BatchNorm2d)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(3, 6, 8, 8)
+    assert not a._hip_ok(x) and not a._hip_ok(x, force=True)
+    assert torch.equal(a(x), b(x)) and torch.equal(a.running_var, b.running_var)
+    a.eval(); b.eval()
+    assert torch.equal(a(x), b(x))
+    conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(torch.nn.Sequential(BatchNorm2d(4)))
+    assert isinstance(conv[0], torch.nn.SyncBatchNorm)
