@@ -68,12 +68,32 @@ class BatchNorm2d(nn.BatchNorm2d):
     1M,256,16M)."""
 
     use_hip = True
-    min_numel, max_channels, big_numel = (int(v) for v in os.environ.get('DHD_BN_ROUTING', f'{1 << 24},128,{1 << 26}').split(','))
+    _DEFAULT_ROUTING = (1 << 24, 128, 1 << 26)
+    _routing = None
+
+    @classmethod
+    def routing(cls):
+        """(min_numel, max_channels, big_numel); DHD_BN_ROUTING is read at first use, a malformed value falls back
+        to the defaults with a warning instead of breaking `import dhd_amd`."""
+        if cls._routing is None:
+            cls._routing = cls._DEFAULT_ROUTING
+            env = os.environ.get('DHD_BN_ROUTING')
+            if env:
+                try:
+                    vals = tuple(int(v) for v in env.split(','))
+                    if len(vals) != 3:
+                        raise ValueError(env)
+                    cls._routing = vals
+                except ValueError:
+                    import warnings
+                    warnings.warn(f'DHD_BN_ROUTING={env!r} is not "min_numel,max_channels,big_numel"; using the defaults')
+        return cls._routing
 
     def _hip_ok(self, x, force=False):
         if not (self.use_hip and self.training and x.is_cuda and x.dim() == 4 and x.dtype in _DTYPES and x.numel() > 0):
             return False
-        if not force and not ((x.numel() >= self.min_numel and x.shape[1] <= self.max_channels) or x.numel() >= self.big_numel):
+        min_numel, max_channels, big_numel = self.routing()
+        if not force and not ((x.numel() >= min_numel and x.shape[1] <= max_channels) or x.numel() >= big_numel):
             return False
         if self.weight is not None and (self.weight.dtype != torch.float32 or (self.bias is not None and self.bias.dtype != torch.float32)):
             return False

@@ -179,13 +179,17 @@ class MGHS(nn.Module):
         calib, keep = self._calib(sensor2ego, cam2imgs, post_rots, post_trans, bda)
         layout = layout or ('collapsed' if self.collapse_z else 'split')
         needs_grad = torch.is_grad_enabled() and (depth.requires_grad or tran_feat.requires_grad)
-        if self.accelerate and not needs_grad:
-            # static rig at inference: geometry + grouping once, then pooling only (the reference's
-            # dormant accelerate/pre_compute idea, :234-258,374-378)
-            if self._cached is None or self._cached[1] is not plan or self._cached[2] != band.device:
+        if self.accelerate and not needs_grad and band is None:
+            # static rig at inference, single grid: geometry + grouping once, then pooling only (the reference's
+            # dormant accelerate/pre_compute idea, :234-258,374-378).  The prepared workspace bakes in the
+            # calibration, so it is reused only while the SAME calibration tensors are passed unmodified; the
+            # four-grid call also bakes in the per-frame height bands and is therefore never cached (in the
+            # reference `accelerate` is dormant for MGHS as well: view_transform_core always recomputes, :380-405).
+            stamp = (depth.device,) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (sensor2ego, cam2imgs, post_rots, post_trans, bda))
+            if self._cached is None or self._cached[1] is not plan or self._cached[2] != stamp:
                 ws = plan.new_workspace(depth.device)
-                mghs_op.prepare(plan, calib, band, ws)
-                self._cached = (ws, plan, band.device)
+                mghs_op.prepare(plan, calib, None, ws)
+                self._cached = (ws, plan, stamp, keep)
             return list(mghs_op._MGHSPool.apply(depth.float(), tran_feat.float(), plan, self._cached[0], layout))
         return list(mghs_op.mghs_pool(plan, calib, band, depth, tran_feat, layout=layout))
 

@@ -188,6 +188,17 @@ class _FusedStage(torch.autograd.Function):
         return (gx if need[0] else None, None) + tuple(g if n else None for g, n in zip(gps, need[2:]))
 
 
+def needs_cross_rank_statistics(stage):
+    """True when a BatchNorm of the stage was converted to nn.SyncBatchNorm (SyncbnControlHook, DHD-L.py) and is
+    training in a process group of more than one rank: its statistics must be all-reduced, which the stage operator
+    (this rank's batch only) does not do -- the generic path, which calls the real modules, runs instead."""
+    sp = stage.spacial_leanring
+    if not any(isinstance(bn, nn.SyncBatchNorm) and bn.training for bn in (sp[1], sp[4])):
+        return False
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def fused_stage_supported(stage, x):
     """True when libdhd_amd.so runs the whole stage itself (float32 parameters, C == 128 or C % 256 == 0)."""
     if not x.is_cuda or x.dim() != 4:
@@ -197,6 +208,8 @@ def fused_stage_supported(stage, x):
         return False
     sp = stage.spacial_leanring
     if sp[0].weight.shape != (stage.channels, stage.channels, 1, 1) or sp[1].weight is None or sp[4].weight is None:
+        return False
+    if needs_cross_rank_statistics(stage):
         return False
     return bool(_lib.load().dhd_sfa_stage_supported(stage.channels, x.shape[2] * x.shape[3]))
 

@@ -180,3 +180,24 @@ def lift_inputs(seed, batch, n_cams, n_depth, fh, fw, channels, n_height):
     feat = hash_signed(seed + 2, (bn, channels, fh, fw))
     hidx = height_index(seed + 3, (bn, fh, fw), n_height)
     return depth, feat, hidx
+
+
+def hashed_state(shapes, seed):
+    """name -> float32 array for the floating-point entries of a state dict, a pure function of
+    (seed, name, shape) -- independent of the order of the entries: matrices / kernels ~ signed / sqrt(fan_in), 1-D `weight` and `running_var`
+    in [0.5, 1.5), biases and `running_mean` ~ 0.1 * signed.  Lets a golden fixture hold only outputs."""
+    import zlib
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        j = zlib.crc32(name.encode()) % 1000003
+        leaf = name.rsplit('.', 1)[-1]
+        if len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            a = hash_signed(seed + j, shape) * np.float32(1.0 / math.sqrt(fan_in))
+        elif leaf in ('weight', 'running_var'):
+            a = hash_uniform(seed + j, shape) + np.float32(0.5)
+        else:
+            a = hash_signed(seed + j, shape) * np.float32(0.1)
+        out[name] = a.astype(np.float32)
+    return out

@@ -27,7 +27,9 @@ unstable argsort are identified as ties) and the weight EMA (`ema_decay` / `ema_
 core/hook/ema.py's ModelEMA, bit-exact).  The stereo sampling grid and cost volume are pinned directly against golden G8 (the reference's
 DepthNet.gen_grid / calculate_cost_volumn) without a numpy restatement, and so is the Swin backbone mirror (golden G10,
 models/backbones/swin.py).  Unpinned (no reference fixture can be
-produced here): mmcv's DCN, which the GPU tests check against its PyTorch (grid_sample) formulation instead.
+produced here): mmcv's DCN -- oracle/dcn_oracle.py restates its published algorithm (pins the algorithm, not mmcv's bits).
+Round 2 fixtures: G5b (SFA at C = 128, the fused operator's shape: `sfa_stage` forward in eval and train mode and its
+float64 backward), G11 (`mghs_depth_view_transform`, the z-stacked DHD-M/L variant), G3 at B = 4.
 
 All file:line citations are into /root/reference/projects/mmdet3d_plugin/.
 """
@@ -461,28 +463,93 @@ def height_loss(gt_depth, gt_height, height, ds, depth_cfg, n_depth, height_rang
 # a14: SFA channel/spatial attention stage (models/necks/mix.py:37-59)
 # --------------------------------------------------------------------------- #
 
-def sfa_stage(x, fc1_w, fc1_b, fc2_w, fc2_b, conv1_w, conv1_b, bn1, conv2_w, conv2_b, bn2, eps=1e-5):
-    """channel_spatial_stage.forward with BatchNorm in eval mode.
-    x (B,2C,H,W); bn = (gamma, beta, running_mean, running_var)."""
+def sfa_stage(x, fc1_w, fc1_b, fc2_w, fc2_b, conv1_w, conv1_b, bn1, conv2_w, conv2_b, bn2, eps=1e-5, training=False,
+              out_grad=None):
+    """channel_spatial_stage.forward (mix.py:37-59) in float64.
+    x (B,2C,H,W); bn = (gamma, beta, running_mean, running_var).  training=True: BatchNorm normalises with the
+    batch statistics (biased variance), as nn.BatchNorm2d does in train mode.
+    With out_grad (B,C,H,W) also returns the gradients of <out, out_grad>: (out, dx, dict of the 12 parameter
+    gradients keyed fc1_w, fc1_b, fc2_w, fc2_b, conv1_w, conv1_b, bn1_w, bn1_b, conv2_w, conv2_b, bn2_w, bn2_b)."""
     b, c2, h, w = x.shape
     c = c2 // 2
-    xb, xv = x[:, :c], x[:, c:]
-    s = x.astype(f64).mean(-1).mean(-1)
-    a1 = np.maximum(s @ fc1_w.T.astype(f64) + fc1_b, 0) @ fc2_w.T.astype(f64) + fc2_b
-    a1 = (1 / (1 + np.exp(-a1)))[:, :, None, None]
+    X = x.astype(f64)
+    xb, xv = X[:, :c], X[:, c:]
+    s = X.mean(-1).mean(-1)                                                   # mix.py:41
+    z1 = s @ fc1_w.T.astype(f64) + fc1_b
+    r1 = np.maximum(z1, 0)
+    z2 = r1 @ fc2_w.T.astype(f64) + fc2_b
+    a1 = (1 / (1 + np.exp(-z2)))[:, :, None, None]                            # mix.py:43-44
     xb1 = a1 * xb
     xv1 = (1 - a1) * xv
-    u = xb1 + xv1
+    u = xb1 + xv1                                                             # mix.py:49
+    W1 = conv1_w.reshape(c, c).astype(f64)
+    W2 = conv2_w.reshape(c, c).astype(f64)
 
-    def bn(t, p):
+    def bn_fwd(t, p):
         g, be, m, v = [q.astype(f64)[None, :, None, None] for q in p]
-        return (t - m) / np.sqrt(v + eps) * g + be
+        if training:
+            m = t.mean((0, 2, 3), keepdims=True)
+            v = t.var((0, 2, 3), keepdims=True)
+        rstd = 1 / np.sqrt(v + eps)
+        xh = (t - m) * rstd
+        return xh * g + be, xh, rstd
 
-    t = np.einsum('oc,bchw->bohw', conv1_w.reshape(c, c).astype(f64), u) + conv1_b[None, :, None, None]
-    t = np.maximum(bn(t, bn1), 0)
-    t = np.einsum('oc,bchw->bohw', conv2_w.reshape(c, c).astype(f64), t) + conv2_b[None, :, None, None]
-    a2 = 1 / (1 + np.exp(-bn(t, bn2)))
-    return (a2 * xb1 + (1 - a2) * xv1).astype(f32)
+    y1 = np.einsum('oc,bchw->bohw', W1, u) + conv1_b[None, :, None, None]
+    n1, xh1, rstd1 = bn_fwd(y1, bn1)
+    t1 = np.maximum(n1, 0)
+    y2 = np.einsum('oc,bchw->bohw', W2, t1) + conv2_b[None, :, None, None]
+    n2, xh2, rstd2 = bn_fwd(y2, bn2)
+    a2 = 1 / (1 + np.exp(-n2))                                                # mix.py:51-53
+    out = a2 * xb1 + (1 - a2) * xv1                                           # mix.py:55-58
+    if out_grad is None:
+        return out.astype(f32)
+
+    def bn_bwd(gn, xh, rstd, gamma):
+        gw, gb = (gn * xh).sum((0, 2, 3)), gn.sum((0, 2, 3))
+        gxh = gn * gamma.astype(f64)[None, :, None, None]
+        if training:
+            m = b * h * w
+            gy = rstd * (gxh - gxh.mean((0, 2, 3), keepdims=True) - xh * (gxh * xh).sum((0, 2, 3), keepdims=True) / m)
+        else:
+            gy = gxh * rstd
+        return gy, gw, gb
+
+    go = out_grad.astype(f64)
+    ga2 = go * (xb1 - xv1)
+    gxb1 = go * a2
+    gxv1 = go * (1 - a2)
+    gn2 = ga2 * a2 * (1 - a2)
+    gy2, g_bn2w, g_bn2b = bn_bwd(gn2, xh2, rstd2, bn2[0])
+    g_w2 = np.einsum('bohw,bchw->oc', gy2, t1)
+    g_b2 = gy2.sum((0, 2, 3))
+    gt1 = np.einsum('oc,bohw->bchw', W2, gy2)
+    gn1 = gt1 * (n1 > 0)
+    gy1, g_bn1w, g_bn1b = bn_bwd(gn1, xh1, rstd1, bn1[0])
+    g_w1 = np.einsum('bohw,bchw->oc', gy1, u)
+    g_b1 = gy1.sum((0, 2, 3))
+    gu = np.einsum('oc,bohw->bchw', W1, gy1)
+    gxb1 = gxb1 + gu
+    gxv1 = gxv1 + gu
+    ga1 = (gxb1 * xb - gxv1 * xv).sum((2, 3))                                  # (B, C)
+    gxb = gxb1 * a1
+    gxv = gxv1 * (1 - a1)
+    a1s = a1[:, :, 0, 0]
+    gz2 = ga1 * a1s * (1 - a1s)
+    g_fc2w, g_fc2b = gz2.T @ r1, gz2.sum(0)
+    gz1 = (gz2 @ fc2_w.astype(f64)) * (z1 > 0)
+    g_fc1w, g_fc1b = gz1.T @ s, gz1.sum(0)
+    gs = gz1 @ fc1_w.astype(f64)                                               # (B, 2C)
+    dx = np.concatenate([gxb, gxv], 1) + gs[:, :, None, None] / (h * w)
+    grads = dict(fc1_w=g_fc1w, fc1_b=g_fc1b, fc2_w=g_fc2w, fc2_b=g_fc2b, conv1_w=g_w1.reshape(conv1_w.shape), conv1_b=g_b1,
+                 bn1_w=g_bn1w, bn1_b=g_bn1b, conv2_w=g_w2.reshape(conv2_w.shape), conv2_b=g_b2, bn2_w=g_bn2w, bn2_b=g_bn2b)
+    return out.astype(f32), dx, grads
+
+
+def mghs_depth_view_transform(cfg, calib, depth, tran_feat, height_idx, inv_post_rot=None, combine=None):
+    """MGHS_Depth.view_transform (lss_heightmap.py:793-856) with collapse_z=False: the full-height grid as
+    (B,C,1,Dy,Dx) and the three band grids concatenated along z in the order low, mid, high (:845) -> (B,C,16,Dy,Dx)."""
+    bev, lo, mid, hi = view_transform(cfg, calib, depth, tran_feat, height_idx, inv_post_rot, combine, collapse_z=False)
+    return bev, np.concatenate([lo, mid, hi], axis=2)
 
 
 # ---------------------------------------------------------------------------------------------

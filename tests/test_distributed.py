@@ -67,6 +67,14 @@ def _worker(rank, world, port, q):
     d = 0.9990 * (1 - __import__('math').exp(-10561 / 2000))
     moved = float((ema_w - net.depth_conv[-1].weight).abs().max())
     want = float((d * (net.depth_conv[-1].weight + 0.1 * grad) + (1 - d) * net.depth_conv[-1].weight - ema_w).abs().max())
+    # SyncbnControlHook converts every BatchNorm, the SFA stage's two included: with more than one rank the stage
+    # operator (local statistics) must step aside for the generic path
+    from dhd_amd.mix import channel_spatial_stage, needs_cross_rank_statistics
+    st = channel_spatial_stage(256)
+    assert not needs_cross_rank_statistics(st)
+    st = torch.nn.SyncBatchNorm.convert_sync_batchnorm(st)
+    assert isinstance(st.spacial_leanring[1], torch.nn.SyncBatchNorm) and needs_cross_rank_statistics(st)
+    assert not needs_cross_rank_statistics(st.eval())
     q.put((rank, (lo, hi), slow, total, grad.flatten().tolist(), ema_w.detach().flatten().tolist(), moved, want))  # plain data
     D.shutdown()
 

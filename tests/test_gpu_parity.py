@@ -606,20 +606,42 @@ def test_uncollapsed_layouts_match_collapsed(gpu):
     assert m2.grid_config['z'] == [-1, 5.4, 6.4]  # MGHS_Depth resets the grid (:848-854)
 
 
-def test_accelerate_reuses_the_grouping_at_inference(gpu):
+def test_accelerate_caches_only_what_is_static(gpu):
+    """accelerate=True at inference: the single-grid call (view_transform_core) reuses its prepared workspace while the
+    same calibration tensors are passed unmodified and redoes it when they change; the four-grid view_transform bakes the
+    per-frame height bands into the grouping and is never cached -- a second frame with different heights and a
+    different calibration must give that frame's result (the cache used to be keyed on (plan, device) only)."""
     from dhd_amd import MGHS
     cfg, calib_np, depth, feat, hidx = _small64(330)
-    m = MGHS(**dict(cfg, heightnet_cfg=dict(use_dcn=False, use_aspp=False), accelerate=True)).to(gpu).eval()
+    hn = dict(use_dcn=False, use_aspp=False)
+    m = MGHS(**dict(cfg, heightnet_cfg=hn, accelerate=True)).to(gpu).eval()
+    plain = MGHS(**dict(cfg, heightnet_cfg=hn, accelerate=False)).to(gpu).eval()
     calib = [T(a, gpu) for a in calib_np]
     x = torch.zeros(1, 3, 1, 4, 11, device=gpu)
     height = T(syn.height_probs_from_index(hidx, 65), gpu)
+    calib2 = [T(a, gpu) for a in syn.make_calibration(331, 1, 3, cfg['input_size'])]
+    height2 = T(syn.height_probs_from_index(syn.height_index(332, hidx.shape, 65), 65), gpu)
     with torch.no_grad():
-        a = m.view_transform([x] + calib, T(depth, gpu), T(feat, gpu), height)
+        for cal, hgt in ((calib, height), (calib2, height2), (calib, height2)):
+            a = m.view_transform([x] + cal, T(depth, gpu), T(feat, gpu), hgt)
+            b = plain.view_transform([x] + cal, T(depth, gpu), T(feat, gpu), hgt)
+            for k in (0, 3, 4, 5):
+                assert torch.allclose(a[k], b[k], atol=1e-5), k
+        assert m._cached is None                     # nothing band-dependent was cached
+        # single grid: cached while the calibration tensors are the same objects, unmodified
+        m._set_grid(cfg['mask_2_grid'])
+        plain._set_grid(cfg['mask_2_grid'])
+        o1, _ = m.view_transform_core([x] + calib, T(depth, gpu), T(feat, gpu))
         ws = m._cached[0]
-        b = m.view_transform([x] + calib, T(2 * depth, gpu), T(feat, gpu), height)
-    assert m._cached[0] is ws
-    for k in (0, 3, 4, 5):
-        assert torch.allclose(b[k], 2 * a[k], atol=1e-4)
+        o2, _ = m.view_transform_core([x] + calib, T(2 * depth, gpu), T(feat, gpu))
+        assert m._cached[0] is ws and torch.allclose(o2, 2 * o1, atol=1e-4)
+        o3, _ = m.view_transform_core([x] + calib2, T(depth, gpu), T(feat, gpu))
+        r3, _ = plain.view_transform_core([x] + calib2, T(depth, gpu), T(feat, gpu))
+        assert m._cached[0] is not ws and torch.allclose(o3, r3, atol=1e-5)
+        calib2[0][:, :, 0, 3] += 0.37                # in-place edit of a cached calibration tensor
+        o4, _ = m.view_transform_core([x] + calib2, T(depth, gpu), T(feat, gpu))
+        r4, _ = plain.view_transform_core([x] + calib2, T(depth, gpu), T(feat, gpu))
+        assert torch.allclose(o4, r4, atol=1e-5) and not torch.allclose(o4, o3, atol=1e-5)
 
 
 def test_mghs_step_is_graph_capturable(gpu):
@@ -1007,7 +1029,7 @@ def test_batchnorm2d_training_vs_torch(gpu, dtype, tol, shape):
     """y, running statistics, num_batches_tracked, and the gradients of x / weight / bias against torch's own
     BatchNorm2d on float32 copies of the same (rounded) inputs; second step with momentum=None (cumulative average)."""
     from dhd_amd.batchnorm import BatchNorm2d
-    BatchNorm2d = type('AlwaysHipBN', (BatchNorm2d,), dict(min_numel=0, big_numel=0, max_channels=1 << 30))  # no size threshold
+    BatchNorm2d = type('AlwaysHipBN', (BatchNorm2d,), dict(_routing=(0, 1 << 30, 0)))  # no size threshold
     torch.manual_seed(sum(shape))
     n, c, h, w = shape
     for momentum in (0.1, None):

@@ -1,0 +1,313 @@
+"""HIP path (through the C ABI and the mirrored modules) against fixtures recorded from the reference's own Python:
+G5b (SFA at C = 128: the fused stage operator), G11 (MGHS_Depth.view_transform, z-stacked), G12 (MGHS.forward as a
+whole), G3 at the benchmark's batch (B = 4), G13 (HeightNet / DepthNet wiring with the HIP DCN), the independent DCN
+oracle, and the measured raw-calibration mismatch count.  Needs a real MI355X:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, golden_calib, small_dhds_cfg
+from dhd_amd import synthetic as syn
+from test_gpu_parity import T, device_calib, make_plan, run_fused, sha
+from test_oracle_golden import SFA_GRAD_KEYS, dhdm_small_cfg, g5b_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def inject_reference_matrices(module, g, gpu):
+    """Route the module's calibration packing through the reference's own inverse / combine matrices (the one
+    boundary that is not bit-pinned: torch.inverse on CPU is MKL)."""
+    from dhd_amd import mghs_op
+    inv, comb = T(g['ref_inv_post_rot'], gpu), T(g['ref_combine'], gpu)
+    module._calib = lambda s2e, k, pr, pt, bda: mghs_op.make_calib(s2e, k, pr, pt, bda, module._axes_on(s2e.device), inv, comb)
+
+
+# --------------------------------------------------------------------------- SFA, fused stage operator (a14 / a15)
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_fused_sfa_stage_vs_reference_c128(gpu, mode):
+    """Golden G5b = the reference's mix.SFA(256, 128) on (2,256,10,16): C == 128 and H*W % 4 == 0, so the stage runs
+    as ONE operator (dhd_sfa_stage_forward / backward, bf16x6 MFMA GEMMs).  Stage output, input gradient, the 12
+    parameter gradients, the BatchNorm running statistics after one training call, and the whole SFA block."""
+    from dhd_amd import SFA
+    from dhd_amd.mix import fused_stage_supported
+    g, sd, x_np = g5b_inputs()
+    sfa = SFA(in_channels=256, out_channels=128)
+    sfa.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    sfa = sfa.to(gpu).train(mode == 'train')
+    x = T(x_np, gpu).requires_grad_()
+    assert fused_stage_supported(sfa.mysk_7, x)
+    sd0 = {k: v.clone() for k, v in sfa.state_dict().items()}
+    stage = sfa.mysk_7(x)
+    np.testing.assert_allclose(stage.detach().cpu().numpy(), g[f'{mode}.stage'], atol=2e-5, rtol=1e-4)
+    if mode == 'train':
+        for k, v in sfa.mysk_7.state_dict().items():
+            if 'running' in k:
+                np.testing.assert_allclose(v.cpu().numpy(), g[f'train.after.mysk_7.{k}'], atol=1e-5, rtol=1e-5, err_msg=k)
+            elif 'num_batches' in k:
+                assert int(v) == int(g[f'train.after.mysk_7.{k}'])
+    (stage * T(syn.hash_signed(5253, tuple(stage.shape)), gpu)).sum().backward()
+    ref = g[f'{mode}.stage_xgrad']
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref, atol=1e-4 * np.abs(ref).max(), rtol=1e-3)
+    params = dict(sfa.mysk_7.named_parameters())
+    for k, name in SFA_GRAD_KEYS.items():
+        ref = g[f'{mode}.stage_pgrad.{name}']
+        np.testing.assert_allclose(params[name].grad.cpu().numpy(), ref, atol=2e-4 * max(1.0, np.abs(ref).max()), rtol=1e-3,
+                                   err_msg=name)
+    sfa.load_state_dict(sd0)
+    x.grad = None
+    sfa.zero_grad()
+    out = sfa(x)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f'{mode}.out'], atol=1e-4, rtol=1e-4)
+    if mode == 'train':
+        (out * T(syn.hash_signed(5252, tuple(out.shape)), gpu)).sum().backward()
+        ref = g['train.xgrad']
+        np.testing.assert_allclose(x.grad.cpu().numpy(), ref, atol=2e-4 * np.abs(ref).max(), rtol=1e-3)
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_fused_sfa_stage_vs_float64_oracle(gpu, mode):
+    """The same operator against the oracle's float64 forward + backward (itself held to G5b on CPU) at a size with
+    several pixel tiles and ragged tails, C = 256."""
+    from oracle import mghs_oracle as O
+    from test_oracle_golden import stage_args
+    from dhd_amd.mix import channel_spatial_stage, fused_stage_supported
+    st = channel_spatial_stage(512)
+    shapes = {k: tuple(v.shape) for k, v in st.state_dict().items() if v.dtype.is_floating_point}
+    sd = syn.hashed_state(shapes, 77)
+    st.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    st = st.to(gpu).train(mode == 'train')
+    x_np = syn.hash_signed(78, (2, 512, 18, 22)) * np.float32(0.7) + np.float32(0.1)
+    w_np = syn.hash_signed(79, (2, 256, 18, 22))
+    x = T(x_np, gpu).requires_grad_()
+    assert fused_stage_supported(st, x)
+    out = st(x)
+    (out * T(w_np, gpu)).sum().backward()
+    ref, dx, grads = O.sfa_stage(x_np, *stage_args(sd, ''), training=(mode == 'train'), out_grad=w_np)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), dx, atol=1e-4 * np.abs(dx).max(), rtol=1e-3)
+    params = dict(st.named_parameters())
+    for k, name in SFA_GRAD_KEYS.items():
+        np.testing.assert_allclose(params[name].grad.cpu().numpy(), grads[k], atol=2e-4 * max(1.0, np.abs(grads[k]).max()),
+                                   rtol=1e-3, err_msg=name)
+
+
+# --------------------------------------------------------------------------- MGHS_Depth.view_transform (a17)
+
+def test_mghs_depth_view_transform_small_vs_reference(gpu):
+    """Golden G11 small: MGHS_Depth.view_transform (lss_heightmap.py:793-856), D = 88, collapse_z=False: `bev_feat`
+    (B,C,1,200,200), `bev_feat_w_z` (B,C,16,200,200) with the bands stacked low / mid / high, both gradients, and
+    the grid_config / grid_size the call leaves behind."""
+    from dhd_amd import MGHS_Depth
+    g = golden('g11_mghs_depth_small')
+    cfg = dhdm_small_cfg()
+    hn = dict(use_dcn=False, use_aspp=False)
+    m = MGHS_Depth(**dict(cfg, heightnet_cfg=hn, depthnet_cfg=hn)).to(gpu)
+    assert m.D == 88
+    inject_reference_matrices(m, g, gpu)
+    calib = [T(a, gpu) for a in golden_calib(g)]
+    B, N = calib[0].shape[:2]
+    x = torch.zeros(B, N, 1, 4, 11, device=gpu)
+    height = T(syn.height_probs_from_index(g['height_idx'], 65), gpu)
+    dt, ft = T(g['depth'], gpu).requires_grad_(), T(g['tran_feat'], gpu).requires_grad_()
+    bev, bev_w_z, dd, hh = m.view_transform([x] + calib, dt, ft, height)
+    assert dd is dt and hh is height
+    assert tuple(bev.shape) == g['out0'].shape and tuple(bev_w_z.shape) == g['out1'].shape == (2, 8, 16, 200, 200)
+    np.testing.assert_allclose(bev.detach().cpu().numpy(), g['out0'], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(bev_w_z.detach().cpu().numpy(), g['out1'], atol=1e-5, rtol=1e-5)
+    s_w = int(g['seed_w'])
+    ((bev * T(syn.hash_signed(s_w, tuple(bev.shape)), gpu)).sum()
+     + (bev_w_z * T(syn.hash_signed(s_w + 1, tuple(bev_w_z.shape)), gpu)).sum()).backward()
+    np.testing.assert_allclose(dt.grad.cpu().numpy(), g['depth_grad'], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), g['feat_grad'], atol=2e-5, rtol=1e-5)
+    assert list(m.grid_config['z']) == list(g['final_grid_z'])
+    assert m.grid_size.tolist() == g['final_grid_size'].tolist() and m.grid_lower_bound.tolist() == g['final_grid_lower'].tolist()
+
+
+def test_mghs_depth_view_transform_dhdm_size_vs_reference(gpu):
+    """Golden G11 at the DHD-M size (6 cameras 256x704, D = 88, C = 64): index hashes, sampled voxels of both output
+    tensors, sums, sampled gradients."""
+    from dhd_amd import MGHS_Depth, mghs_op
+    g = golden('g11_mghs_depth_dhdm_b1')
+    cfg = syn.dhd_s_config()
+    cfg['grid_config'] = dict(cfg['grid_config'], depth=[1.0, 45.0, 0.5])
+    cfg['collapse_z'] = False
+    _, s_in, s_w = (int(v) for v in g['seeds'])
+    depth, feat, hidx = syn.lift_inputs(s_in, 1, 6, 88, 16, 44, 64, 65)
+    plan, axes = make_plan(cfg, 1, 6)
+    calib_s, keep = device_calib(golden_calib(g), axes, gpu, g['ref_inv_post_rot'], g['ref_combine'])
+    for k in range(4):
+        rank, ego = mghs_op.voxel_index(plan, calib_s, k, want_ego=(k == 0))
+        if k == 0:
+            assert sha(ego.cpu().numpy()) == str(g['coor_sha'])
+        assert sha(rank.cpu().numpy()) == str(g[f'rank_map_sha{k}']), k
+    hn = dict(use_dcn=False, use_aspp=False)
+    m = MGHS_Depth(**dict(cfg, heightnet_cfg=hn, depthnet_cfg=hn)).to(gpu)
+    inject_reference_matrices(m, g, gpu)
+    calib = [T(a, gpu) for a in golden_calib(g)]
+    x = torch.zeros(1, 6, 1, 16, 44, device=gpu)
+    dt, ft = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+    bev, bev_w_z, _, _ = m.view_transform([x] + calib, dt, ft, T(syn.height_probs_from_index(hidx, 65), gpu))
+    assert bev.shape == (1, 64, 1, 200, 200) and bev_w_z.shape == (1, 64, 16, 200, 200)
+    ((bev * T(syn.hash_signed(s_w, tuple(bev.shape)), gpu)).sum()
+     + (bev_w_z * T(syn.hash_signed(s_w + 1, tuple(bev_w_z.shape)), gpu)).sum()).backward()
+    for k, o in enumerate((bev, bev_w_z)):
+        o = o.detach().cpu().numpy()
+        np.testing.assert_allclose(o.reshape(-1)[g[f'out_pos{k}']], g[f'out_val{k}'], atol=3e-5, rtol=1e-5)
+        s = g[f'out_sum{k}']
+        assert abs(o.astype(np.float64).sum() - s[0]) < 1e-6 * s[1] + 1e-3
+        assert int(np.count_nonzero(o)) == int(s[2])
+    np.testing.assert_allclose(dt.grad.cpu().numpy().reshape(-1)[g['depth_grad_pos']], g['depth_grad_val'], atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(ft.grad.cpu().numpy().reshape(-1)[g['feat_grad_pos']], g['feat_grad_val'], atol=2e-4, rtol=1e-5)
+
+
+# --------------------------------------------------------------------------- MGHS.forward as a whole (a11)
+
+class _HeightStandIn(torch.nn.Module):
+    """The one-layer stand-in golden G12 was recorded with (HeightNet itself depends on un-vendored mmcv / mmdet)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(32, 65, 1)
+
+    def forward(self, x, mlp_input, stereo_metas=None):
+        return self.conv(x) + mlp_input.reshape(-1, 27)[:, :1, None, None]
+
+
+def test_mghs_forward_vs_reference(gpu):
+    """Golden G12 = the reference's MGHS.forward (lss_heightmap.py:461-490) with a stand-in height net: depth_net 1x1
+    conv -> channel split -> softmax(depth); height -> softmax -> argmax bands; the four pooled outputs; gradients
+    back to the input feature map and to depth_net (the height branch gets gradient only through its own loss term)."""
+    from dhd_amd import MGHS
+    g = golden('g12_mghs_forward')
+    cfg = small_dhds_cfg()
+    cfg['in_channels'] = 32
+    m = MGHS(**dict(cfg, heightnet_cfg=dict(use_dcn=False, use_aspp=False)))
+    m.height_net = _HeightStandIn()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+    m.load_state_dict({k: torch.from_numpy(v * np.float32(4.0)) for k, v in syn.hashed_state(shapes, int(g['seeds'][3])).items()},
+                      strict=False)
+    m = m.to(gpu)
+    inject_reference_matrices(m, g, gpu)
+    calib = [T(a, gpu) for a in golden_calib(g)]
+    B, N = calib[0].shape[:2]
+    x = T(syn.hash_signed(int(g['seeds'][1]), (B, N, 32, 4, 11)), gpu).requires_grad_()
+    mlp = m.get_mlp_input(*calib)
+    bev, depth, height, lo, mid, hi = m([x] + calib + [mlp])
+    np.testing.assert_allclose(depth.detach().cpu().numpy(), g['depth'], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(height.detach().cpu().numpy(), g['height'], atol=1e-6, rtol=1e-4)
+    # identical band choice is a precondition for comparing the band outputs: argmax of the two height tensors
+    assert np.array_equal(height.detach().cpu().numpy().argmax(1), g['height'].argmax(1))
+    outs = (bev, lo, mid, hi)
+    for k, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().cpu().numpy(), g[f'out{k}'], atol=2e-5, rtol=1e-4)
+    s_w = int(g['seeds'][2])
+    (sum((o * T(syn.hash_signed(s_w + k, tuple(o.shape)), gpu)).sum() for k, o in enumerate(outs)) + (height * height).sum()).backward()
+    ref = g['x_grad']
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref, atol=1e-4 * np.abs(ref).max(), rtol=1e-3)
+    for k, p in m.named_parameters():
+        ref = g['pgrad.' + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=2e-4 * max(1.0, np.abs(ref).max()), rtol=1e-3, err_msg=k)
+    assert m.grid_config is m.mask_3_grid
+
+
+# --------------------------------------------------------------------------- the benchmark's batch (B = 4)
+
+def test_full_dhds_size_batch4_vs_reference(gpu):
+    """Golden G3 at B = 4 (bench.py's workload): index hashes per grid, kept / interval counts, sampled voxels, sums,
+    sampled gradients -- all from the reference's own run."""
+    from dhd_amd import mghs_op
+    batch = 4
+    g = golden('g3_dhds_b4')
+    cfg = syn.dhd_s_config()
+    calib_np = golden_calib(g)
+    _, s_in, s_w = (int(v) for v in g['seeds'])
+    depth, feat, hidx = syn.lift_inputs(s_in, batch, 6, 44, 16, 44, 64, 65)
+    plan, axes = make_plan(cfg, batch, 6)
+    calib, keep = device_calib(calib_np, axes, gpu, g['ref_inv_post_rot'], g['ref_combine'])
+    for k in range(4):
+        rank, ego = mghs_op.voxel_index(plan, calib, k, want_ego=(k == 0))
+        if k == 0:
+            assert sha(ego.cpu().numpy()) == str(g['coor_sha'])
+        assert sha(rank.cpu().numpy()) == str(g[f'rank_map_sha{k}']), k
+    outs, grads, (plan, ws) = run_fused(gpu, cfg, calib_np, depth, feat, hidx, g['ref_inv_post_rot'], g['ref_combine'], s_w)
+    kept, ivs = mghs_op.stats(plan, ws)
+    assert kept[0] == int(g['n_kept0']) and ivs[0] == int(g['n_intervals0'])
+    for k, o in enumerate(outs):
+        np.testing.assert_allclose(o.reshape(-1)[g[f'out_pos{k}']], g[f'out_val{k}'], atol=3e-5, rtol=1e-5)
+        s = g[f'out_sum{k}']
+        assert abs(o.astype(np.float64).sum() - s[0]) < 1e-6 * s[1] + 1e-3
+        assert int(np.count_nonzero(o)) == int(s[2])
+    np.testing.assert_allclose(grads[0].reshape(-1)[g['depth_grad_pos']], g['depth_grad_val'], atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(grads[1].reshape(-1)[g['feat_grad_pos']], g['feat_grad_val'], atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize('batch', [1, 2, 4])
+def test_raw_calibration_index_mismatch_count_full_size(gpu, batch):
+    """From RAW calibration the device inverts post_rot / intrin itself (LAPACK algorithm; the reference's
+    torch.inverse is MKL and cannot be restated bit for bit).  Measured here instead of estimated: the maps computed
+    with the reference's matrices are first verified against the reference's SHA-256, then the raw-calibration maps are
+    compared with them point by point.  Bound: at most 1 point in 10 000 per grid lands in a neighbouring voxel or
+    crosses the grid boundary (a point sitting within an ulp of a cell face)."""
+    from dhd_amd import mghs_op
+    g = golden(f'g3_dhds_b{batch}')
+    cfg = syn.dhd_s_config()
+    calib_np = golden_calib(g)
+    plan, axes = make_plan(cfg, batch, 6)
+    ref_calib, keep1 = device_calib(calib_np, axes, gpu, g['ref_inv_post_rot'], g['ref_combine'])
+    raw_calib, keep2 = device_calib(calib_np, axes, gpu)
+    n_points = batch * 6 * 44 * 16 * 44
+    total = 0
+    for k in range(4):
+        ref_rank, _ = mghs_op.voxel_index(plan, ref_calib, k)
+        assert sha(ref_rank.cpu().numpy()) == str(g[f'rank_map_sha{k}']), k
+        raw_rank, _ = mghs_op.voxel_index(plan, raw_calib, k)
+        bad = int((ref_rank != raw_rank).sum())
+        assert bad * 10000 <= n_points, (k, bad, n_points)
+        total += bad
+    print(f'raw-calibration mismatches at B={batch}: {total} of {4 * n_points} (point, grid) pairs')
+
+
+# --------------------------------------------------------------------------- DCN (a12)
+
+@pytest.mark.parametrize('c,groups,h,w,dil,scale', [(16, 4, 16, 44, 1, 0.5), (8, 1, 7, 9, 2, 3.0), (32, 4, 12, 20, 1, 8.0)])
+def test_dcn_hip_vs_independent_oracle(gpu, c, groups, h, w, dil, scale):
+    """dhd_deform_im2col / dhd_deform_col2im and the DCN module against oracle/dcn_oracle.py (mmcv-full 1.5.3's
+    published deform_conv2d algorithm in float64, explicit neighbour gathers -- not grid_sample): columns, output,
+    input / offset / weight gradients; large offsets put many taps outside the image."""
+    from oracle import dcn_oracle as D
+    from dhd_amd.depthnet import DCN, _DeformIm2col
+    k = 3
+    x_np = syn.hash_signed(10 + c, (2, c, h, w))
+    off_np = (scale * syn.hash_signed(11 + c, (2, 2 * k * k, h, w))).astype(np.float32)
+    off_np[0, :, 0, 0] = [-1.0, -1.0, 0.0, 0.0, -1.0, 1.0, 0.5, -0.5, 0.0, 0.0, h, w, -h, -w, 1.0, 1.0, 0.25, 0.75][:2 * k * k]
+    x, off = T(x_np, gpu).requires_grad_(), T(off_np, gpu).requires_grad_()
+    col = _DeformIm2col.apply(x, off, k, dil, dil)
+    ref_col = D.deform_im2col(x_np, off_np, k, dil, dil)
+    assert (ref_col == 0).mean() > 0.02
+    np.testing.assert_allclose(col.detach().cpu().numpy(), ref_col, atol=2e-6, rtol=1e-5)
+    # through the layer: weight (2c, c/groups, 3, 3), einsum per group
+    m = DCN(c, 2 * c, kernel_size=3, padding=dil, dilation=dil, groups=groups).to(gpu)
+    w_np = syn.hash_signed(12 + c, tuple(m.weight.shape)) * np.float32(0.2)
+    with torch.no_grad():
+        m.weight.copy_(T(w_np, gpu))
+
+    class _Fixed(torch.nn.Module):
+        def forward(self, _x):
+            return off
+    m.conv_offset = _Fixed()
+    y = m(x)
+    gy_np = syn.hash_signed(13 + c, tuple(y.shape))
+    y.backward(T(gy_np, gpu))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), D.deform_conv2d(x_np, off_np, w_np, dil, dil, groups), atol=2e-5, rtol=1e-4)
+    dx, doff, dw = D.deform_conv2d_backward(gy_np, x_np, off_np, w_np, dil, dil, groups)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), dx, atol=1e-4 * np.abs(dx).max(), rtol=1e-3)
+    np.testing.assert_allclose(off.grad.cpu().numpy(), doff, atol=1e-4 * np.abs(doff).max(), rtol=1e-3)
+    np.testing.assert_allclose(m.weight.grad.cpu().numpy(), dw, atol=1e-4 * np.abs(dw).max(), rtol=1e-3)
+
+
+@pytest.mark.parametrize('name', ['height', 'depth'])
+def test_heightnet_depthnet_with_hip_dcn_vs_reference_fixture(gpu, name):
+    """Golden G13 on the GPU: the mirrored HeightNet / DepthNet with the HIP deformable sampling in the stack."""
+    from test_host_logic import check_g13
+    check_g13(name, gpu, tol=5e-4)

@@ -336,3 +336,57 @@ def test_batchnorm2d_subclass_is_transparent_off_the_gpu():
     assert torch.equal(a(x), b(x))
     conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(torch.nn.Sequential(BatchNorm2d(4)))
     assert isinstance(conv[0], torch.nn.SyncBatchNorm)
+
+
+def _g13_case(name, device='cpu'):
+    """Build the mirrored HeightNet / DepthNet with golden G13's hashed parameters and inputs."""
+    from dhd_amd.depthnet import DepthNet, HeightNet
+    g = golden('g13_depthnet')
+    net = HeightNet(32, 32, 65) if name == 'height' else DepthNet(32, 32, 8, 44)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+    sd = syn.hashed_state(shapes, 1310 if name == 'height' else 1350)
+    for k in sd:
+        if k.endswith('conv_offset.bias'):
+            sd[k] = (sd[k] * 20).astype(np.float32)
+    missing = net.load_state_dict({k: T(v) for k, v in sd.items()}, strict=False)
+    assert all('num_batches_tracked' in k for k in missing.missing_keys) and not missing.unexpected_keys
+    x = T(syn.hash_signed(1302, (6, 32, 6, 10))).to(device).requires_grad_()
+    return g, net.to(device), x, T(g['mlp_input']).to(device)
+
+
+def check_g13(name, device='cpu', tol=2e-4):
+    g, net, x, mlp = _g13_case(name, device)
+    for mode in ('train', 'eval'):
+        net.train(mode == 'train')
+        for mod in net.modules():      # the fixture was recorded with ASPP's Dropout(0.5) switched off
+            if isinstance(mod, torch.nn.Dropout):
+                mod.eval()
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        out = net(x, mlp)
+        ref = g[f'{name}.{mode}.out']
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=1e-3)
+        w = T(syn.hash_signed(1303, tuple(out.shape))).to(device)
+        x.grad = None
+        net.zero_grad()
+        (out * w).sum().backward()
+        ref = g[f'{name}.{mode}.xgrad']
+        np.testing.assert_allclose(x.grad.cpu().numpy(), ref, atol=tol * max(1.0, np.abs(ref).max()), rtol=1e-3)
+        if mode == 'train':
+            n = 0
+            for k, p in net.named_parameters():
+                key = f'{name}.pgrad.{k}'
+                if key in g.files:
+                    ref = g[key]
+                    np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=2 * tol * max(1.0, np.abs(ref).max()), rtol=2e-3,
+                                               err_msg=key)
+                    n += 1
+            assert n >= 40
+        net.load_state_dict(sd0)
+
+
+@pytest.mark.parametrize('name', ['height', 'depth'])
+def test_heightnet_depthnet_wiring_matches_reference_fixture(name):
+    """Golden G13: the reference's HeightNet / DepthNet (depthnet.py) run with stand-ins for the two un-vendored
+    blocks (mmdet BasicBlock, mmcv DCN restated from the published algorithm).  The mirror on CPU (DCN through its
+    grid_sample formulation): outputs, input gradient, parameter gradients, train and eval BatchNorm."""
+    check_g13(name)

@@ -86,7 +86,7 @@ def test_own_inverse_is_close_and_flips_few_points():
         assert bad <= 3, (k, bad)
 
 
-@pytest.mark.parametrize('batch', [1, 2])
+@pytest.mark.parametrize('batch', [1, 2, 4])
 def test_full_dhds_size_hashes_and_samples(batch):
     import hashlib
     g = golden(f'g3_dhds_b{batch}')
@@ -201,3 +201,110 @@ def test_ema_update_matches_reference_fixture():
                 assert np.array_equal(ema[k], g[f'ema{it}.{k}']), (it, k)
             else:
                 assert np.array_equal(g[f'ema{it}.{k}'], g['init.' + k])   # integer buffers are left alone
+
+
+SFA_GRAD_KEYS = {'fc1_w': 'fc.0.weight', 'fc1_b': 'fc.0.bias', 'fc2_w': 'fc.2.weight', 'fc2_b': 'fc.2.bias',
+                 'conv1_w': 'spacial_leanring.0.weight', 'conv1_b': 'spacial_leanring.0.bias',
+                 'bn1_w': 'spacial_leanring.1.weight', 'bn1_b': 'spacial_leanring.1.bias',
+                 'conv2_w': 'spacial_leanring.3.weight', 'conv2_b': 'spacial_leanring.3.bias',
+                 'bn2_w': 'spacial_leanring.4.weight', 'bn2_b': 'spacial_leanring.4.bias'}
+
+
+def g5b_inputs():
+    """Inputs of golden G5b (the reference's mix.SFA(256, 128)): hashed parameters, x, loss weights."""
+    from dhd_amd.mix import SFA
+    g = golden('g5b_sfa_c128')
+    s_sd, s_x, _ = (int(v) for v in g['seeds'])
+    shapes = {k: tuple(v.shape) for k, v in SFA(256, 128).state_dict().items() if v.dtype.is_floating_point}
+    sd = syn.hashed_state(shapes, s_sd)
+    x = syn.hash_signed(s_x, (2, 256, 10, 16)) * np.float32(0.7) + np.float32(0.1)
+    return g, sd, x
+
+
+def stage_args(sd, prefix='mysk_7.'):
+    bn = lambda i: tuple(sd[f'{prefix}spacial_leanring.{i}.{n}'] for n in ('weight', 'bias', 'running_mean', 'running_var'))
+    return (sd[prefix + 'fc.0.weight'], sd[prefix + 'fc.0.bias'], sd[prefix + 'fc.2.weight'], sd[prefix + 'fc.2.bias'],
+            sd[prefix + 'spacial_leanring.0.weight'], sd[prefix + 'spacial_leanring.0.bias'], bn(1),
+            sd[prefix + 'spacial_leanring.3.weight'], sd[prefix + 'spacial_leanring.3.bias'], bn(4))
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_sfa_stage_c128_forward_and_backward_vs_reference(mode):
+    """Golden G5b: the reference's channel_spatial_stage at C = 128 (the fused operator's shape), eval and train
+    BatchNorm: output, input gradient and all 12 parameter gradients of the oracle's float64 restatement."""
+    g, sd, x = g5b_inputs()
+    wst = syn.hash_signed(5253, (2, 128, 10, 16))
+    out, dx, grads = O.sfa_stage(x, *stage_args(sd), training=(mode == 'train'), out_grad=wst)
+    np.testing.assert_allclose(out, g[f'{mode}.stage'], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(dx, g[f'{mode}.stage_xgrad'], atol=3e-6, rtol=1e-5)
+    for k, name in SFA_GRAD_KEYS.items():
+        ref = g[f'{mode}.stage_pgrad.{name}']
+        np.testing.assert_allclose(grads[k], ref, atol=2e-5 * max(1.0, np.abs(ref).max()), rtol=1e-5, err_msg=k)
+
+
+def dhdm_small_cfg():
+    cfg = small_dhds_cfg()
+    cfg['grid_config'] = dict(cfg['grid_config'], depth=[1.0, 45.0, 0.5])
+    cfg['collapse_z'] = False
+    return cfg
+
+
+def test_mghs_depth_view_transform_vs_reference():
+    """Golden G11 (MGHS_Depth.view_transform, lss_heightmap.py:793-856): D = 88, (B,C,1,Dy,Dx) + (B,C,16,Dy,Dx) with the
+    bands stacked low / mid / high along z, gradients, and the grid_config the call leaves behind."""
+    g = golden('g11_mghs_depth_small')
+    cfg = dhdm_small_cfg()
+    calib = golden_calib(g)
+    axes = O.frustum_axes(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    assert len(axes[2]) == 88 and np.array_equal(axes[2], g['frustum'][:, 0, 0, 2])
+    coor = O.ego_coor(axes, calib[0], calib[2], calib[3], calib[4], calib[5], g['ref_inv_post_rot'], g['ref_combine'])
+    assert np.array_equal(coor, g['coor'])
+    for k, grid in enumerate(grids_of(cfg)):
+        assert np.array_equal(O.voxel_rank(coor, grid), g[f'rank_map{k}'])
+    bev, bev_w_z = O.mghs_depth_view_transform(cfg, calib, g['depth'], g['tran_feat'], g['height_idx'],
+                                               g['ref_inv_post_rot'], g['ref_combine'])
+    assert bev.shape == g['out0'].shape == (2, 8, 1, 200, 200) and bev_w_z.shape == g['out1'].shape == (2, 8, 16, 200, 200)
+    np.testing.assert_allclose(bev, g['out0'], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(bev_w_z, g['out1'], atol=1e-6, rtol=0)
+    # reset to the full grid afterwards (:848-854), unlike MGHS which stays on mask_3_grid
+    assert list(g['final_grid_z']) == [-1, 5.4, 6.4] and list(g['final_grid_size']) == [200, 200, 1]
+    # gradients of <bev, w0> + <bev_w_z, w1>: the collapsed-layout backward with w1 cut into its three z ranges
+    s_w = int(g['seed_w'])
+    w0, w1 = syn.hash_signed(s_w, bev.shape), syn.hash_signed(s_w + 1, bev_w_z.shape)
+    flat = lambda a: np.ascontiguousarray(a.transpose(0, 2, 1, 3, 4)).reshape(a.shape[0], -1, 200, 200)
+    ws = [flat(w0), flat(w1[:, :, 0:4]), flat(w1[:, :, 4:8]), flat(w1[:, :, 8:16])]
+    dg, fg = O.view_transform_backward(cfg, calib, g['depth'], g['tran_feat'], g['height_idx'], ws,
+                                       g['ref_inv_post_rot'], g['ref_combine'])
+    np.testing.assert_allclose(dg, g['depth_grad'], atol=5e-6, rtol=0)
+    np.testing.assert_allclose(fg, g['feat_grad'], atol=5e-6, rtol=0)
+
+
+def test_dcn_oracle_vs_the_grid_sample_formulation():
+    """oracle/dcn_oracle.py (explicit neighbour gathers, mmcv's published algorithm) against the package's CPU
+    formulation (F.grid_sample, zero padding, align_corners) in float64, offsets far outside the image included."""
+    import torch
+    from oracle import dcn_oracle as D
+    from dhd_amd.depthnet import DCN
+    m = DCN(8, 12, 3, padding=1, groups=4).double()
+    with torch.no_grad():
+        m.weight.copy_(torch.from_numpy(syn.hash_signed(1, (12, 2, 3, 3)).astype(np.float64)))
+        m.conv_offset.weight.copy_(torch.from_numpy(0.3 * syn.hash_signed(2, (18, 8, 3, 3)).astype(np.float64)))
+        m.conv_offset.bias.copy_(torch.from_numpy(4.0 * syn.hash_signed(3, (18,)).astype(np.float64)))
+    x = torch.from_numpy(syn.hash_signed(4, (2, 8, 7, 9)).astype(np.float64)).requires_grad_()
+    off = m.conv_offset(x).detach()
+    assert off.abs().max() > 7      # taps well outside the 7 x 9 image
+    holder = torch.nn.Parameter(off.clone())
+
+    class _Fixed(torch.nn.Module):
+        def forward(self, _x):
+            return holder
+    m.conv_offset = _Fixed()
+    y = m(x)
+    gy = torch.from_numpy(syn.hash_signed(5, tuple(y.shape)).astype(np.float64))
+    y.backward(gy)
+    xn, wn = x.detach().numpy(), m.weight.detach().numpy()
+    assert np.abs(D.deform_conv2d(xn, off.numpy(), wn, 1, 1, 4) - y.detach().numpy()).max() < 1e-12
+    dx, doff, dw = D.deform_conv2d_backward(gy.numpy(), xn, off.numpy(), wn, 1, 1, 4)
+    assert np.abs(dx - x.grad.numpy()).max() < 1e-12
+    assert np.abs(doff - holder.grad.numpy()).max() < 1e-12
+    assert np.abs(dw - m.weight.grad.numpy()).max() < 1e-11
