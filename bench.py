@@ -12,10 +12,17 @@ D=44, C=64, grids 200x200x{1,4,4,8}, samples_per_gpu=4).  Samples are independen
 shard them with no data-path collective ("weak" scaling); rank 0 prints ONE JSON line.
 
 The line also carries
-  roofline     : achieved HBM GB/s of the dominant kernel (mghs_stream_fwd), algorithmic bytes
-                  / mean launch duration from HIP events on the launch stream
-  cpu_baseline : the CPU oracle (numpy MGHS + torch-CPU SFA stage) timed on this box's host cores
-                 on a small sample of the same workload (rank 0, N=1 only)
+  roofline            : achieved HBM GB/s of the dominant kernel (mghs_stream_fwd), algorithmic bytes
+                         / mean launch duration from HIP events on the launch stream
+  roofline_bwd        : the same for the pooling backward (mghs_stream_bwd + mghs_pixel_bwd, 177.7 MB/sample)
+  roofline_operator   : the standalone operator drop-in (dhd_bev_pool_v2_forward/backward on the full grid with
+                        reference-style index lists, 13.8 MB/sample), timed after the main loop
+  roofline_sfa_stage  : the SFA stage operator's forward as a whole (328 MB/sample)
+  cpu_baseline        : the torch-CPU twin of the reference's op sequence (oracle/mghs_torch_cpu.py) on this box's
+                        host cores, all threads, 3 warm-ups + median of 5, B=1 and B=4 (rank 0, N=1 only)
+  e2e                 : the whole DHD-S detector fwd+bwd+optimizer (fp32 and fp16 autocast), 3 warm-ups + 5 steps;
+                        under DDP for N>1, with the exposed all-reduce time (DDP step - no_sync step)
+`--gpus N` without a launcher environment re-executes itself under torch.distributed.run with N ranks.
 """
 import argparse
 import json
@@ -35,18 +42,32 @@ from dhd_amd.mix import channel_spatial_stage  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 
+def kernel_source_sha256():
+    """SHA-256 over the kernel sources the library is built from (csrc/*.hip, *.h and the C header): the identity a
+    committed PMC measurement is valid for."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'dhd_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'dhd_amd', 'csrc', '*.h'))
+                   + [os.path.join(ROOT, 'include', 'dhd_amd.h')])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b'\0' + open(f, 'rb').read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel, batch):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/<round>/pmc_summary.json:
-    separate FETCH_SIZE / WRITE_SIZE runs of this same script, gfx950 correction applied).  PMC
-    counters cannot be read from inside the run, so this is the stored measurement for the same
-    per-GPU batch, or None."""
+    separate FETCH_SIZE / WRITE_SIZE runs of this same script, gfx950 correction applied).  PMC counters cannot be
+    read from inside the run, so this is the stored measurement -- returned only if it was collected for the same
+    per-GPU batch AND from the kernel sources this library was built from (`source_sha256`); otherwise None."""
     best = None
     prof = os.path.join(ROOT, 'profiles')
+    sha = kernel_source_sha256()
     for rnd in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
         f = os.path.join(prof, rnd, 'pmc_summary.json')
         if os.path.exists(f):
             d = json.load(open(f))
-            if d.get('samples_per_gpu') == batch and kernel in d.get('kernels', {}):
+            if d.get('samples_per_gpu') == batch and d.get('source_sha256') == sha and kernel in d.get('kernels', {}):
                 best = d['kernels'][kernel]['hbm_bytes_per_launch']
     return best
 
@@ -77,7 +98,9 @@ def parse():
     p.add_argument('--model', choices=['dhd-s', 'dhd-m', 'dhd-l'], default='dhd-s',
                    help='e2e: DHD-S (single frame), DHD-M (temporal stereo) or DHD-L (Swin-B, 512x1408 images, temporal stereo)')
     p.add_argument('--no-ema', action='store_true', help='e2e: leave out the per-iteration weight EMA (MEGVIIEMAHook) of the configs')
-    p.add_argument('--cpu-samples', type=int, default=2, help='samples for the CPU baseline leg (0 = skip)')
+    p.add_argument('--cpu-samples', type=int, default=4, help='largest batch of the CPU baseline leg (0 = skip)')
+    p.add_argument('--no-e2e', action='store_true', help='hotpath: leave out the end-to-end DHD-S sub-record')
+    p.add_argument('--no-operator', action='store_true', help='hotpath: leave out the standalone bev_pool_v2 operator timing')
     return p.parse_args()
 
 
@@ -120,11 +143,14 @@ class HotPath:
             self.x = torch.randn(batch, 512, 200, 200, generator=g).to(dev).requires_grad_()
             self.gy = torch.randn(batch, 256, 200, 200, generator=g).to(dev)
         self.ev = []  # (start, end) HIP events around the dominant kernel, one pair per timed step
+        self.ev_bwd = []  # (start, end) around dhd_mghs_backward (mghs_stream_bwd + mghs_pixel_bwd)
         self.ev_sfa = []  # (start, after forward, after backward) events around the SFA stage operator
         # algorithmic bytes of the forward pooling per launch (fused form): dense outputs
         # written once + depth read once + context read once.  The streaming kernel is charged with ALL
         # of them although depth/context are read by the gather kernel before it (conservative by 1%).
         self.pool_fwd_bytes = batch * (4 * C * 17 * 200 * 200 + 4 * N * D * fh * fw + 4 * N * fh * fw * C)
+        # backward: out_grad read once + depth / context read + depth_grad / feat_grad written
+        self.pool_bwd_bytes = batch * (4 * C * 17 * 200 * 200 + 2 * (4 * N * D * fh * fw + 4 * N * fh * fw * C))
 
     def step(self, record):
         cfg = self.cfg
@@ -139,7 +165,13 @@ class HotPath:
             self.ev.append((e0, e1))
         else:
             outs = mghs_op.pool_forward(self.plan, self.depth, feat_nhwc, self.ws)
+        if record:
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record()
         dg, fg = mghs_op.pool_backward(self.plan, self.depth, feat_nhwc, self.out_grads, self.ws)
+        if record:
+            b1.record()
+            self.ev_bwd.append((b0, b1))
         fg_nchw = mghs_op._nhwc_to_nchw(fg)
         if self.with_sfa:
             self.x.grad = None
@@ -256,36 +288,186 @@ def run_e2e(a, rank, world, dev):
     ddist.shutdown()
 
 
-def cpu_baseline(hp, n_samples):
-    """Oracle timing on the host: numpy MGHS view_transform fwd+bwd (the reference's op sequence,
-    4x geometry + 4x sort + pool + permute) and, for the SFA stage, the reference formula in
-    torch-CPU fp32 with all host threads."""
-    from oracle import mghs_oracle as O  # checker / baseline only
+def operator_roofline(hp, steps, warmup):
+    """The operator-level drop-in on its own (include/dhd_amd.h section 1 = bev_pool.cpp:30-39,74-85): the full-height
+    grid with reference-style index lists (ranks_depth / ranks_feat / ranks_bev sorted by voxel, interval starts /
+    lengths; for the backward re-grouped by ranks_feat as bev_pool.py:47-57 does).  Timed region per launch, as the
+    reference's wrapper issues it: zero-fill of the caller-owned output(s) + the kernel.  Algorithmic bytes:
+    out + depth + context + 12 B per kept point."""
+    import ctypes as C
+    from dhd_amd import bev_pool_v2 as op
+    lib = _lib.load()
+    dev, B = hp.dev, hp.B
+    N, D, fh, fw, Cc = hp.dims
+    rank, _ = mghs_op.voxel_index(hp.plan, hp.calib, 0)
+    pid = torch.nonzero(rank >= 0).flatten()
+    rb = rank[pid].long()
+    order = torch.argsort(rb, stable=True)
+    rb, rd = rb[order].int().contiguous(), pid[order].int().contiguous()
+    pix = (rd.long() // (D * fh * fw)) * (fh * fw) + rd.long() % (fh * fw)
+    rf = pix.int().contiguous()
+    _, ln = torch.unique_consecutive(rb, return_counts=True)
+    st = (torch.cumsum(ln, 0) - ln).int().contiguous()
+    ln = ln.int().contiguous()
+    o2 = torch.argsort(rf, stable=True)
+    rb2, rd2, rf2 = rb[o2].contiguous(), rd[o2].contiguous(), rf[o2].contiguous()
+    _, ln2 = torch.unique_consecutive(rf2, return_counts=True)
+    st2 = (torch.cumsum(ln2, 0) - ln2).int().contiguous()
+    ln2 = ln2.int().contiguous()
+    depth = hp.depth.view(B, N, D, fh, fw)
+    feat = mghs_op._nchw_to_nhwc(hp.feat).view(B, N, fh, fw, Cc)
+    out = torch.empty(B, 1, 200, 200, Cc, device=dev)
+    og = torch.randn(B, 1, 200, 200, Cc, device=dev)
+    dgrad, fgrad = torch.empty_like(depth), torch.empty_like(feat)
+    s = _lib.stream_ptr(dev)
+    ev = []
+
+    def once(record):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        out.zero_()
+        _lib.check(lib.dhd_bev_pool_v2_forward(_lib.ptr(depth), _lib.ptr(feat), _lib.ptr(out), _lib.ptr(rd), _lib.ptr(rf), _lib.ptr(rb),
+                                               _lib.ptr(ln), _lib.ptr(st), Cc, int(ln.numel()), s), 'dhd_bev_pool_v2_forward')
+        e[1].record()
+        dgrad.zero_()
+        fgrad.zero_()
+        _lib.check(lib.dhd_bev_pool_v2_backward(_lib.ptr(og), _lib.ptr(dgrad), _lib.ptr(fgrad), _lib.ptr(depth), _lib.ptr(feat), _lib.ptr(rd2),
+                                                _lib.ptr(rf2), _lib.ptr(rb2), _lib.ptr(ln2), _lib.ptr(st2), Cc, int(ln2.numel()), s),
+                   'dhd_bev_pool_v2_backward')
+        e[2].record()
+        if record:
+            ev.append(e)
+    for _ in range(warmup):
+        once(False)
+    for _ in range(steps):
+        once(True)
+    torch.cuda.synchronize()
+    # the same operator through its Python surface (zero-fill, kernel, permute; backward with the argsort re-grouping)
+    dt, ft = depth.clone().requires_grad_(), feat.clone().requires_grad_()
+    shape = (B, 1, 200, 200, Cc)
+    ogp = og.permute(0, 4, 1, 2, 3).contiguous()
+    for it in range(3 + steps):
+        if it == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        dt.grad = ft.grad = None
+        op.bev_pool_v2(dt, ft, rd, rf, rb, shape, st, ln).backward(ogp)
+    torch.cuda.synchronize()
+    py_ms = (time.perf_counter() - t0) / steps * 1e3
+    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    n_kept = int(rb.numel())
+    plane = B * 4 * Cc * 200 * 200
+    small = B * (4 * N * D * fh * fw + 4 * N * fh * fw * Cc)
+    fwd_bytes = plane + small + 12 * n_kept
+    bwd_bytes = plane + 2 * small + 12 * n_kept
+    ach = (fwd_bytes + bwd_bytes) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
+    return dict(bound='hbm', kernel='bev_pool_v2_fwd_kernel + bev_pool_v2_bwd_kernel (dhd_bev_pool_v2_forward/backward, incl. the '
+                                    'zero-fill of the caller-owned outputs)', achieved=ach, peak=HBM_PEAK_GBPS, unit='GB/s',
+                frac=ach / HBM_PEAK_GBPS, traffic=None, launch_ms=fwd_ms + bwd_ms, forward_ms=fwd_ms, backward_ms=bwd_ms,
+                algorithmic_bytes=fwd_bytes + bwd_bytes, forward_bytes=fwd_bytes, backward_bytes=bwd_bytes, kept_points=n_kept,
+                intervals=int(ln.numel()), python_op_fwd_bwd_ms=py_ms,
+                note='full-height grid only (Dz=1); python_op_fwd_bwd_ms = dhd_amd.bev_pool_v2(...).backward() incl. permute and the '
+                     'backward re-grouping argsort the reference also performs (bev_pool.py:47-57)')
+
+
+def cpu_baseline(hp, max_batch, warmups=3, reps=5):
+    """SURVEY 8(d) / BASELINE.md 2.3: the torch-CPU twin of the reference's op sequence (oracle/mghs_torch_cpu.py: 4 x
+    geometry, 4 x index preparation with argsort, pool as index_add_, permute, cat; backward by autograd) plus the SFA
+    stage formula on torch-CPU modules, `torch.set_num_threads(os.cpu_count())`, same synthetic inputs as the GPU run,
+    B = 1 and B = max_batch, `warmups` warm-ups and the median of `reps` runs each."""
+    from oracle import mghs_torch_cpu as TC  # checker / baseline only
     cfg = hp.cfg
-    n = min(n_samples, hp.B)
-    calib = [a[:n] for a in hp.calib_np]
-    depth, feat, hidx = (a[:n * 6] for a in hp.inputs_np)
-    t0 = time.perf_counter()
-    outs = O.view_transform(cfg, calib, depth, feat, hidx)
-    gr = [np.ones_like(o) for o in outs]
-    O.view_transform_backward(cfg, calib, depth, feat, hidx, gr)
-    t_mghs = time.perf_counter() - t0
-    t_sfa = 0.0
-    if hp.with_sfa:
-        torch.set_num_threads(os.cpu_count())
-        st = channel_spatial_stage(512)
-        x = torch.randn(n, 512, 200, 200, requires_grad=True)
+    threads = os.cpu_count()
+    torch.set_num_threads(threads)
+    fr = TC.frustum(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+    res = {}
+    for b in sorted({1, min(max_batch, hp.B)}):
+        calib = [t(x[:b]) for x in hp.calib_np]
+        depth, feat, hidx = (x[:b * 6] for x in hp.inputs_np)
+        height = t(syn.height_probs_from_index(hidx, 65))
+        dt, ft = t(depth).requires_grad_(), t(feat).requires_grad_()
+        gr = None
+        times = []
+        for it in range(warmups + reps):
+            dt.grad = ft.grad = None
+            t0 = time.perf_counter()
+            outs = TC.view_transform(cfg, fr, calib, dt, ft, height)
+            t1 = time.perf_counter()
+            gr = gr or [torch.ones_like(o) for o in outs]
+            torch.autograd.backward(outs, gr)
+            t2 = time.perf_counter()
+            if it >= warmups:
+                times.append((t1 - t0, t2 - t1))
+        res[b] = dict(mghs_fwd_s=float(np.median([x[0] for x in times])), mghs_bwd_s=float(np.median([x[1] for x in times])))
+        del outs, gr
+        if hp.with_sfa:
+            st = channel_spatial_stage(512).train()
+            x = torch.randn(b, 512, 200, 200, requires_grad=True)
+            gy = torch.randn(b, 256, 200, 200)
+            times = []
+            for it in range(warmups + reps):
+                x.grad = None
+                t0 = time.perf_counter()
+                TC.sfa_stage(st, x).backward(gy)
+                if it >= warmups:
+                    times.append(time.perf_counter() - t0)
+            res[b]['sfa_stage_fwd_bwd_s'] = float(np.median(times))
+            del x, gy
+        r = res[b]
+        r['samples_per_s'] = b / (r['mghs_fwd_s'] + r['mghs_bwd_s'] + r.get('sfa_stage_fwd_bwd_s', 0.0))
+        r['mghs_only_samples_per_s'] = b / (r['mghs_fwd_s'] + r['mghs_bwd_s'])
+    top = max(res)
+    return dict(value=res[top]['samples_per_s'], unit='samples/s', cores=threads, kind='port',
+                sample=f'the same synthetic workload at B={top} (value) and B=1: oracle/mghs_torch_cpu.py view_transform fwd+bwd '
+                       f'(torch-CPU twin of the reference op sequence; the reference has no CPU pool, bev_pool.cpp:7-14)'
+                       + (' + SFA stage fwd+bwd on torch-CPU modules' if hp.with_sfa else '') +
+                       f'; torch.set_num_threads({threads}), {warmups} warm-ups, median of {reps}',
+                by_batch={str(b): r for b, r in res.items()})
+
+
+def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
+    """north_star's target number, observed by the driver inside the default line: the whole DHD-S detector
+    (forward_train + backward + grad clip + AdamW + weight EMA) in fp32 and under fp16 autocast, B samples per GPU,
+    `warmup` warm-ups + `steps` timed steps.  N > 1: DDP over RCCL (64 MB buckets, overlapped with backward); the
+    exposed (non-overlapped) all-reduce time is measured as step(DDP) - step(DDP.no_sync())."""
+    out = {}
+
+    def fence():
+        torch.cuda.synchronize()
+        ddist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(job, n):
+        fence()
         t0 = time.perf_counter()
-        xb, xv = torch.split(x, 256, dim=1)
-        a1 = st.fc(x.mean(-1).mean(-1))[:, :, None, None]
-        xb1, xv1 = a1 * xb, (1 - a1) * xv
-        a2 = torch.sigmoid(st.spacial_leanring(xb1 + xv1))
-        (a2 * xb1 + (1 - a2) * xv1).sum().backward()
-        t_sfa = time.perf_counter() - t0
-    return dict(value=n / (t_mghs + t_sfa), unit='samples/s', cores=os.cpu_count(), kind='port',
-                sample=f'{n} sample(s) of the same workload: oracle/mghs_oracle.py view_transform fwd+bwd '
-                       f'({t_mghs:.2f} s, numpy, mostly 1 thread)' +
-                       (f' + SFA stage fwd+bwd in torch-CPU fp32 ({t_sfa:.2f} s, {os.cpu_count()} threads)' if hp.with_sfa else ''))
+        for _ in range(n):
+            job.step(True)
+        fence()
+        return ddist.max_over_ranks(time.perf_counter() - t0, dev) / n
+
+    for amp in ('off', 'fp16'):
+        job = EndToEnd(dev, a.batch, 1000 + rank, world, amp, 'dhd-s', True)
+        for _ in range(warmup):
+            job.step(False)
+        per_step = timed(job, steps)
+        rec = dict(samples_per_s=a.batch * world / per_step, ms_per_step=1e3 * per_step, steps=steps, warmup=warmup)
+        if world > 1:
+            with job.net.no_sync():
+                job.step(False)
+                rec['ms_per_step_no_allreduce'] = 1e3 * timed(job, steps)
+            rec['exposed_allreduce_ms'] = max(0.0, rec['ms_per_step'] - rec['ms_per_step_no_allreduce'])
+            rec['allreduce_bytes'] = 4 * job.n_params
+        out['fp32' if amp == 'off' else 'fp16'] = rec
+        n_params = job.n_params
+        del job
+        torch.cuda.empty_cache()
+    out['config'] = dict(workload='DHD-S (configs[1]/[2]) whole detector: ResNet-50 + FPN, MGHS (HIP), BEV encoder, 3 UNets, SFA (HIP stage), '
+                                  'predictor + losses (HIP); forward_train + backward + grad-clip + AdamW + weight EMA (HIP); random init',
+                         samples_per_gpu=a.batch, global_batch=a.batch * world, params=n_params,
+                         parallelism=f'DDP x{world} (RCCL bucketed all-reduce, 64 MB buckets, overlapped with backward)' if world > 1 else 'single GPU')
+    return out
 
 
 def run_occ_loss(a, rank, world, dev):
@@ -404,11 +586,23 @@ def run_ema(a, rank, world, dev):
 
 def main():
     a = parse()
-    rank, local, world = ddist.env_world()
-    if world != a.gpus and world > 1:
-        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        # no launcher environment: start one rank per GPU ourselves (the reference's tools/dist_train.sh:11-20 does the same
+        # with torch.distributed.launch), then this process becomes the launcher
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            raise SystemExit(f'--gpus {a.gpus} requested but only {have} GPU(s) are visible')
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
+                                  '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    rank, local, world = ddist.env_world()
+    if world != a.gpus:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or without a launcher)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     ddist.init_from_env(backend='nccl', device=dev)  # RCCL; used only for the barrier / MAX around the timed region
@@ -436,6 +630,7 @@ def main():
     fence()
     elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
 
+    line = None
     if rank == 0:
         kern_ms = float(np.mean([s.elapsed_time(e) for s, e in hp.ev]))
         achieved = hp.pool_fwd_bytes / (kern_ms * 1e-3) / 1e9
@@ -450,13 +645,19 @@ def main():
             roofline=dict(bound='hbm', kernel='mghs_stream_fwd', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s',
                           frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic('mghs_stream_fwd', a.batch), launch_ms=kern_ms,
                           algorithmic_bytes=hp.pool_fwd_bytes))
+        bwd_ms = float(np.mean([s.elapsed_time(e) for s, e in hp.ev_bwd]))
+        bwd_ach = hp.pool_bwd_bytes / (bwd_ms * 1e-3) / 1e9
+        line['roofline_bwd'] = dict(bound='hbm', kernel='mghs_stream_bwd + mghs_pixel_bwd (dhd_mghs_backward)', achieved=bwd_ach,
+                                    peak=HBM_PEAK_GBPS, unit='GB/s', frac=bwd_ach / HBM_PEAK_GBPS,
+                                    traffic=(lambda p: None if None in p else int(sum(p)))([pmc_traffic(k, a.batch) for k in ('mghs_stream_bwd', 'mghs_pixel_bwd')]),
+                                    launch_ms=bwd_ms, algorithmic_bytes=hp.pool_bwd_bytes)
         if hp.ev_sfa:
             # second roofline, for the SFA stage operator as a whole (a dozen kernels per call): SURVEY 8(d) gives its forward
             # algorithmic traffic as x read twice + u/out written + the two 1x1 convs reading and writing (B,C,H,W) once each
             fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in hp.ev_sfa]))
             bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in hp.ev_sfa]))
             c, hw = 256, 200 * 200
-            fwd_bytes = a.batch * 4 * hw * (2 * 2 * c + 2 * c + 4 * c)
+            fwd_bytes = a.batch * 4 * hw * (2 * 2 * c + 4 * c)   # 2 reads of (2C,H,W) + 4 passes over (C,H,W) = 328 MB/sample
             gemm_flop = 2.0 * c * c * hw * a.batch
             line['roofline_sfa_stage'] = dict(
                 bound='hbm', kernel='dhd_sfa_stage_forward (plane_mean, fc, 2 x pw_gemm6, stat reductions, blend2_bn)',
@@ -465,8 +666,19 @@ def main():
                 algorithmic_bytes=fwd_bytes,
                 backward_ms=bwd_ms, gemm_tflops_fp32_equivalent=6 * gemm_flop / ((fwd_ms + bwd_ms) * 1e-3) / 1e12,
                 note='float32 GEMMs computed as 6 bf16 MFMA products each (exact three-way split); f32-MFMA peak is 157 TFLOP/s')
-        if world == 1 and a.cpu_samples > 0:
-            line['cpu_baseline'] = cpu_baseline(hp, a.cpu_samples)
+    if a.geometry == 'dhd-s' and not a.no_operator:
+        op_roof = operator_roofline(hp, max(5, min(a.steps, 20)), 3)   # every rank runs it, rank 0 reports
+        if rank == 0:
+            line['roofline_operator'] = op_roof
+    if rank == 0 and world == 1 and a.cpu_samples > 0:
+        line['cpu_baseline'] = cpu_baseline(hp, a.cpu_samples)
+    if a.geometry == 'dhd-s' and not a.no_sfa and not a.no_e2e:
+        del hp
+        torch.cuda.empty_cache()
+        e2e = e2e_subrecord(a, rank, world, dev)
+        if rank == 0:
+            line['e2e'] = e2e
+    if rank == 0:
         print(json.dumps(line), flush=True)
     ddist.shutdown()
 

@@ -308,3 +308,41 @@ def test_dcn_oracle_vs_the_grid_sample_formulation():
     assert np.abs(dx - x.grad.numpy()).max() < 1e-12
     assert np.abs(doff - holder.grad.numpy()).max() < 1e-12
     assert np.abs(dw - m.weight.grad.numpy()).max() < 1e-11
+
+
+@pytest.mark.parametrize('name', ['g2_smoke', 'g2b_small_dhds', 'g2c_no_band', 'g2d_out_of_grid'])
+def test_torch_cpu_twin_vs_reference_fixtures(name):
+    """oracle/mghs_torch_cpu.py (the multi-threaded torch-CPU restatement that bench.py times as `cpu_baseline`)
+    against the reference's own results: frustum, ego coordinates and index lists equal, outputs / gradients to rounding."""
+    import torch
+    from oracle import mghs_torch_cpu as TC
+    g = golden(name)
+    cfg = syn.smoke_config() if name == 'g2_smoke' else small_dhds_cfg()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    calib = [t(a) for a in golden_calib(g)]
+    fr = TC.frustum(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    assert np.array_equal(fr.numpy(), g['frustum'])
+    inv, comb = t(g['ref_inv_post_rot']), t(g['ref_combine'])
+    coor = TC.get_ego_coor(fr, calib[0], calib[2], calib[3], calib[4], calib[5], inv, comb)
+    assert np.array_equal(coor.numpy(), g['coor'])
+    for k, grid in enumerate(grids_of(cfg)):
+        rb, rd, rf, st, ln = TC.prepare_v2(coor, grid)
+        if rb is None:
+            assert len(g[f'ranks_bev{k}']) == 0
+            continue
+        order = np.lexsort((rd.numpy(), rb.numpy()))          # canonical order inside a voxel (the argsort is unstable)
+        assert np.array_equal(rb.numpy()[order], g[f'ranks_bev{k}']) and np.array_equal(rd.numpy()[order], g[f'ranks_depth{k}'])
+        assert np.array_equal(rf.numpy()[order], g[f'ranks_feat{k}'])
+        assert np.array_equal(st.numpy(), g[f'interval_starts{k}']) and np.array_equal(ln.numpy(), g[f'interval_lengths{k}'])
+    depth, feat = t(g['depth']).requires_grad_(), t(g['tran_feat']).requires_grad_()
+    height = t(syn.height_probs_from_index(g['height_idx'], len(cfg['height_range'])))
+    outs = TC.view_transform(cfg, fr, calib, depth, feat, height, inv, comb)
+    for k, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().numpy(), g[f'out{k}'], atol=1e-6, rtol=0)
+    loss = sum((o * t(syn.hash_signed(int(g['seed_w']) + k, tuple(o.shape)))).sum() for k, o in enumerate(outs))
+    if loss.requires_grad:
+        loss.backward()
+        np.testing.assert_allclose(depth.grad.numpy(), g['depth_grad'], atol=5e-6, rtol=0)
+        np.testing.assert_allclose(feat.grad.numpy(), g['feat_grad'], atol=5e-6, rtol=0)
+    else:
+        assert not g['depth_grad'].any() and not g['feat_grad'].any()
