@@ -295,7 +295,7 @@ def operator_roofline(hp, steps, warmup):
     reference's wrapper issues it: zero-fill of the caller-owned output(s) + the kernel.  Algorithmic bytes:
     out + depth + context + 12 B per kept point."""
     import ctypes as C
-    from dhd_amd import bev_pool_v2 as op
+    from dhd_amd.bev_pool_v2 import bev_pool_v2 as bev_pool_v2_op
     lib = _lib.load()
     dev, B = hp.dev, hp.B
     N, D, fh, fw, Cc = hp.dims
@@ -351,7 +351,7 @@ def operator_roofline(hp, steps, warmup):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         dt.grad = ft.grad = None
-        op.bev_pool_v2(dt, ft, rd, rf, rb, shape, st, ln).backward(ogp)
+        bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln).backward(ogp)
     torch.cuda.synchronize()
     py_ms = (time.perf_counter() - t0) / steps * 1e3
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
@@ -371,37 +371,68 @@ def operator_roofline(hp, steps, warmup):
                      'backward re-grouping argsort the reference also performs (bev_pool.py:47-57)')
 
 
-def cpu_baseline(hp, max_batch, warmups=3, reps=5):
+def cpu_baseline(hp, max_batch, warmups=3, reps=5, budget_s=75.0):
     """SURVEY 8(d) / BASELINE.md 2.3: the torch-CPU twin of the reference's op sequence (oracle/mghs_torch_cpu.py: 4 x
     geometry, 4 x index preparation with argsort, pool as index_add_, permute, cat; backward by autograd) plus the SFA
-    stage formula on torch-CPU modules, `torch.set_num_threads(os.cpu_count())`, same synthetic inputs as the GPU run,
-    B = 1 and B = max_batch, `warmups` warm-ups and the median of `reps` runs each."""
+    stage formula on torch-CPU modules, on the same synthetic inputs as the GPU run, B = 1 and B = max_batch,
+    `warmups` warm-ups and the median of `reps` runs each.
+
+    Threads: SURVEY asks for torch.set_num_threads(os.cpu_count()).  On the GPU box (256 hardware threads) that setting
+    makes this op sequence ~200x SLOWER than 8 threads (measured: 46 s against 0.24 s per sample for the forward; the
+    185 856 batched 3x3 matmuls and the index ops are dominated by fork/join overhead), which is neither a fair baseline
+    nor affordable inside a benchmark run.  The thread count is therefore calibrated: one B = 1 forward+backward at
+    8, 16, 32, ... threads up to os.cpu_count(), stopping at the first count that is slower than its predecessor; the
+    fastest count is used and reported as `cores`, the calibration times are reported too.  A wall-clock budget bounds
+    the leg: when it runs out the remaining repetitions are dropped (the counts actually used are reported)."""
     from oracle import mghs_torch_cpu as TC  # checker / baseline only
     cfg = hp.cfg
-    threads = os.cpu_count()
-    torch.set_num_threads(threads)
+    t_leg = time.perf_counter()
     fr = TC.frustum(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x))
-    res = {}
-    for b in sorted({1, min(max_batch, hp.B)}):
+
+    def inputs(b):
         calib = [t(x[:b]) for x in hp.calib_np]
         depth, feat, hidx = (x[:b * 6] for x in hp.inputs_np)
-        height = t(syn.height_probs_from_index(hidx, 65))
-        dt, ft = t(depth).requires_grad_(), t(feat).requires_grad_()
-        gr = None
+        return calib, t(depth).requires_grad_(), t(feat).requires_grad_(), t(syn.height_probs_from_index(hidx, 65))
+
+    def mghs_once(calib, dt, ft, height):
+        dt.grad = ft.grad = None
+        t0 = time.perf_counter()
+        outs = TC.view_transform(cfg, fr, calib, dt, ft, height)
+        t1 = time.perf_counter()
+        torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+        return t1 - t0, time.perf_counter() - t1
+
+    # thread calibration on one sample
+    one = inputs(1)
+    calib_times, best, n = {}, None, 8
+    top = os.cpu_count() or 8
+    while True:
+        n = min(n, top)
+        torch.set_num_threads(n)
+        mghs_once(*one)                                   # warm-up at this thread count
+        calib_times[n] = sum(mghs_once(*one))
+        if best is not None and calib_times[n] > calib_times[best]:
+            break
+        best = n
+        if n >= top or time.perf_counter() - t_leg > 0.3 * budget_s:
+            break
+        n *= 2
+    threads = best
+    torch.set_num_threads(threads)
+
+    res = {}
+    for b in sorted({1, min(max_batch, hp.B)}):
+        args = inputs(b)
         times = []
         for it in range(warmups + reps):
-            dt.grad = ft.grad = None
-            t0 = time.perf_counter()
-            outs = TC.view_transform(cfg, fr, calib, dt, ft, height)
-            t1 = time.perf_counter()
-            gr = gr or [torch.ones_like(o) for o in outs]
-            torch.autograd.backward(outs, gr)
-            t2 = time.perf_counter()
+            ft_, bt_ = mghs_once(*args)
             if it >= warmups:
-                times.append((t1 - t0, t2 - t1))
-        res[b] = dict(mghs_fwd_s=float(np.median([x[0] for x in times])), mghs_bwd_s=float(np.median([x[1] for x in times])))
-        del outs, gr
+                times.append((ft_, bt_))
+            if time.perf_counter() - t_leg > budget_s and times:
+                break
+        res[b] = dict(mghs_fwd_s=float(np.median([x[0] for x in times])), mghs_bwd_s=float(np.median([x[1] for x in times])),
+                      mghs_reps=len(times))
         if hp.with_sfa:
             st = channel_spatial_stage(512).train()
             x = torch.randn(b, 512, 200, 200, requires_grad=True)
@@ -413,18 +444,23 @@ def cpu_baseline(hp, max_batch, warmups=3, reps=5):
                 TC.sfa_stage(st, x).backward(gy)
                 if it >= warmups:
                     times.append(time.perf_counter() - t0)
+                if time.perf_counter() - t_leg > 1.5 * budget_s and times:
+                    break
             res[b]['sfa_stage_fwd_bwd_s'] = float(np.median(times))
+            res[b]['sfa_reps'] = len(times)
             del x, gy
         r = res[b]
         r['samples_per_s'] = b / (r['mghs_fwd_s'] + r['mghs_bwd_s'] + r.get('sfa_stage_fwd_bwd_s', 0.0))
         r['mghs_only_samples_per_s'] = b / (r['mghs_fwd_s'] + r['mghs_bwd_s'])
-    top = max(res)
-    return dict(value=res[top]['samples_per_s'], unit='samples/s', cores=threads, kind='port',
-                sample=f'the same synthetic workload at B={top} (value) and B=1: oracle/mghs_torch_cpu.py view_transform fwd+bwd '
+    top_b = max(res)
+    return dict(value=res[top_b]['samples_per_s'], unit='samples/s', cores=threads, kind='port',
+                sample=f'the same synthetic workload at B={top_b} (value) and B=1: oracle/mghs_torch_cpu.py view_transform fwd+bwd '
                        f'(torch-CPU twin of the reference op sequence; the reference has no CPU pool, bev_pool.cpp:7-14)'
                        + (' + SFA stage fwd+bwd on torch-CPU modules' if hp.with_sfa else '') +
-                       f'; torch.set_num_threads({threads}), {warmups} warm-ups, median of {reps}',
-                by_batch={str(b): r for b, r in res.items()})
+                       f'; {threads} torch threads (fastest of the calibrated counts, host has {top} hardware threads), '
+                       f'{warmups} warm-ups, median of up to {reps}',
+                host_threads=top, thread_calibration_s={str(k): v for k, v in calib_times.items()},
+                by_batch={str(b): r for b, r in res.items()}, leg_seconds=time.perf_counter() - t_leg)
 
 
 def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
@@ -666,18 +702,22 @@ def main():
                 algorithmic_bytes=fwd_bytes,
                 backward_ms=bwd_ms, gemm_tflops_fp32_equivalent=6 * gemm_flop / ((fwd_ms + bwd_ms) * 1e-3) / 1e12,
                 note='float32 GEMMs computed as 6 bf16 MFMA products each (exact three-way split); f32-MFMA peak is 157 TFLOP/s')
+    t_stage = time.perf_counter()
     if a.geometry == 'dhd-s' and not a.no_operator:
         op_roof = operator_roofline(hp, max(5, min(a.steps, 20)), 3)   # every rank runs it, rank 0 reports
         if rank == 0:
             line['roofline_operator'] = op_roof
     if rank == 0 and world == 1 and a.cpu_samples > 0:
         line['cpu_baseline'] = cpu_baseline(hp, a.cpu_samples)
+        print(f'[bench] cpu_baseline leg {time.perf_counter() - t_stage:.1f} s', file=sys.stderr, flush=True)
+    t_stage = time.perf_counter()
     if a.geometry == 'dhd-s' and not a.no_sfa and not a.no_e2e:
         del hp
         torch.cuda.empty_cache()
         e2e = e2e_subrecord(a, rank, world, dev)
         if rank == 0:
             line['e2e'] = e2e
+            print(f'[bench] e2e leg {time.perf_counter() - t_stage:.1f} s', file=sys.stderr, flush=True)
     if rank == 0:
         print(json.dumps(line), flush=True)
     ddist.shutdown()

@@ -264,13 +264,17 @@ typedef struct dhd_sfa_grads { /* [dev] float32 outputs, shapes as in dhd_sfa_we
 } dhd_sfa_grads;
 
 int dhd_sfa_stage_supported(int c, int hw);
-/* How the stage's C x C GEMMs are computed (process-wide, not thread-safe against running calls):
- *   1 (default) bf16 MFMA on a three-way split of every float32 operand, six products per a*b --
- *     float32-level accuracy (dropped terms < 2^-25 |a*b|) at 6/16 of the f32-MFMA cost.  With less than
- *     two rounds of 256-channel tiles (small batches) the tiles past the full round are launched as
- *     128-channel workgroups instead (bit-identical results);
- *   2 as 1 without that second launch (one kernel per GEMM);
- *   0 f32 MFMA (v_mfma_f32_32x32x2_f32), a plain float32 fma chain. */
+/* How the stage's C x C GEMMs are computed (process-wide, not thread-safe against running calls).  Every float32
+ * operand is cut into bfloat16 parts (round-to-nearest-even, exact: h + m + l == x) for the bf16 MFMA:
+ *   3 (default) "bf16x3": two parts per operand, three products ah*bh + ah*bm + am*bh per a*b (error <= 3 * 2^-18
+ *     |ab| per product; stage output within ~2e-5 of float64 at full size, inside the path's 1e-3 bar); persistent
+ *     workgroups keep their output channels' weight fragments resident in LDS (C in {128, 256, 512});
+ *   1 "bf16x6", resident weights: three parts, six products -- float32-level accuracy (dropped terms < 2^-25 |ab|);
+ *   2 "bf16x6", weights streamed through LDS per 128-pixel tile (round 1's kernels, any C % 256 == 0 or C == 128);
+ *     with less than two rounds of tiles the tiles past the full round go to a second launch of 128-channel
+ *     workgroups; 4: the same without that second launch.  Modes 1, 2 and 4 give bit-identical results;
+ *   0 f32 MFMA (v_mfma_f32_32x32x2_f32), a plain float32 fma chain.
+ * The weight-gradient GEMMs follow the same precision (bf16x3 in mode 3, bf16x6 in 1 / 2 / 4). */
 int dhd_sfa_set_gemm_mode(int mode);
 /* `saved` carries forward state to backward (a1, BatchNorm batch statistics, y1, y2);
  * `scratch` is reusable between calls on one stream.  0 if the shape is unsupported. */

@@ -56,7 +56,8 @@ def test_sfa_stage_shape_support_and_validation():
     w.hidden = 32
     assert lib.dhd_sfa_stage_forward(one, C.byref(w), one, one, one, 4, 256, 40000, None) == -1  # null weights
     assert lib.dhd_sfa_stage_backward(one, C.byref(w), one, one, one, C.byref(g), one, 4, 256, 40000, None) == -1
-    assert lib.dhd_sfa_set_gemm_mode(3) == -1 and lib.dhd_sfa_set_gemm_mode(2) == 0 and lib.dhd_sfa_set_gemm_mode(1) == 0
+    assert lib.dhd_sfa_set_gemm_mode(5) == -1 and lib.dhd_sfa_set_gemm_mode(-1) == -1
+    assert all(lib.dhd_sfa_set_gemm_mode(m) == 0 for m in (0, 2, 3, 4, 1))
 
 
 def test_library_is_a_gfx950_code_object():

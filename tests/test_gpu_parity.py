@@ -414,23 +414,46 @@ def _plain_stage(st, x, margin=0.0):
 
 _TIE = 2e-6
 
+# GEMM modes of the stage operator (include/dhd_amd.h: dhd_sfa_set_gemm_mode) and the tolerance factor the tests grant
+# them relative to the float32-level modes: bf16x3 (the default) drops product terms of relative size <= 3 * 2^-18, the
+# path's bar is 1e-3 (BASELINE.json north_star)
+GEMM_MODES = {'x3_resident': (3, 20.0), 'x6_resident': (1, 1.0), 'x6_streamed': (2, 1.0)}
 
-def _check_stage_against_torch(st, x, tol_x=1e-4, tol_p=5e-4):
+
+class gemm_mode:
+    """with gemm_mode('x6_resident') as tol_factor: ...  -- restores the default mode afterwards."""
+
+    def __init__(self, name):
+        self.mode, self.factor = GEMM_MODES[name]
+
+    def __enter__(self):
+        from dhd_amd import _lib
+        _lib.check(_lib.load().dhd_sfa_set_gemm_mode(self.mode), 'mode')
+        return self.factor
+
+    def __exit__(self, *exc):
+        from dhd_amd import _lib
+        _lib.check(_lib.load().dhd_sfa_set_gemm_mode(3), 'mode')
+        return False
+
+
+def _check_stage_against_torch(st, x, tol_x=1e-4, tol_p=5e-4, tol_out=1e-4, tie=_TIE):
     """Forward + backward of `st` (HIP) on x against plain PyTorch fp32 on a copy of the module.
 
     A pre-ReLU activation within rounding of zero (measured: 1.4e-7 at the one or two pixels that
     differ at full size) can fall on either side of the ReLU in two correct float32 implementations
     (BatchNorm folded into scale/shift here, (y - mean) * rstd in PyTorch); the gradient through that
     element is then passed by one and blocked by the other.  The reference is therefore evaluated with
-    the ReLU gradient cut at +_TIE and at -_TIE: every gradient must agree with the first up to
-    tol * scale plus the (element-wise) difference between the two -- zero unless a tie touches it."""
+    the ReLU gradient cut at +tie and at -tie: every gradient must agree with the first up to
+    tol * scale plus the (element-wise) difference between the two -- zero unless a tie touches it.
+    (bf16x3 mode: the conv output carries an error of ~2e-5, so `tie` widens by the same factor as the tolerances.)"""
     import copy
     refs = [copy.deepcopy(st) for _ in range(2)]
     out = st(x)
     g = torch.randn_like(out)
     out.backward(g)
     res = []
-    for ref, margin in zip(refs, (_TIE, -_TIE)):
+    for ref, margin in zip(refs, (tie, -tie)):
         x2 = x.detach().clone().requires_grad_()
         o2 = _plain_stage(ref, x2, margin)
         o2.backward(g)
@@ -441,7 +464,7 @@ def _check_stage_against_torch(st, x, tol_x=1e-4, tol_p=5e-4):
         scale = max(1.0, ra.abs().max().item())
         excess = ((mine - ra).abs() - 1.01 * (ra - rb).abs()).max().item()
         assert excess <= tol * scale, (what, excess, scale)
-    close(out.detach(), o_a, o_a, 1e-4, 'out')
+    close(out.detach(), o_a, o_a, tol_out, 'out')
     close(x.grad, gx_a, gx_b, tol_x, 'gx')
     for (k, p), qa, qb in zip(st.named_parameters(), gp_a, gp_b):
         close(p.grad, qa, qb, tol_p, k)
@@ -449,18 +472,21 @@ def _check_stage_against_torch(st, x, tol_x=1e-4, tol_p=5e-4):
         close(u.float(), v.float(), v.float(), 1e-5, k)
 
 
-def test_sfa_stage_full_size_vs_torch(gpu):
+@pytest.mark.parametrize('gemm', list(GEMM_MODES))
+def test_sfa_stage_full_size_vs_torch(gpu, gemm):
     """(1,512,200,200): the fused stage against the same math in plain PyTorch fp32."""
     from dhd_amd.mix import channel_spatial_stage
     torch.manual_seed(1)
     st = channel_spatial_stage(512).to(gpu)
     x = torch.randn(1, 512, 200, 200, device=gpu, requires_grad=True)
-    _check_stage_against_torch(st, x)
+    with gemm_mode(gemm) as f:
+        _check_stage_against_torch(st, x, tol_x=1e-4 * f, tol_p=5e-4 * f, tol_out=1e-4 * min(f, 3.0), tie=_TIE * f)
 
 
+@pytest.mark.parametrize('gemm', list(GEMM_MODES))
 @pytest.mark.parametrize('c,b,h,w,train', [(128, 3, 36, 40, True), (128, 2, 20, 28, False), (256, 2, 52, 60, True),
                                            (512, 1, 24, 40, True), (64, 2, 20, 20, True)])
-def test_sfa_stage_vs_torch(gpu, c, b, h, w, train):
+def test_sfa_stage_vs_torch(gpu, c, b, h, w, train, gemm):
     """The stage operator (dhd_sfa_stage_forward/backward: f32-MFMA 1x1 convs with fused blends /
     BatchNorm / ReLU; C = 64 takes the generic path) against plain PyTorch fp32 on the same parameters:
     output, input gradient, all 12 parameter gradients and the running statistics."""
@@ -476,7 +502,8 @@ def test_sfa_stage_vs_torch(gpu, c, b, h, w, train):
     st.train(train)
     x = (torch.randn(b, 2 * c, h, w, device=gpu) * 0.7 + 0.1).requires_grad_()
     assert fused_stage_supported(st, x) == (c != 64)
-    _check_stage_against_torch(st, x)
+    with gemm_mode(gemm) as f:
+        _check_stage_against_torch(st, x, tol_x=1e-4 * f, tol_p=5e-4 * f, tol_out=1e-4 * min(f, 3.0), tie=_TIE * f)
 
 
 @pytest.mark.parametrize('c,b,h,w', [(128, 2, 20, 28), (256, 2, 36, 40), (512, 1, 24, 40)])
@@ -492,14 +519,15 @@ def test_sfa_stage_f32_mfma_mode_vs_torch(gpu, c, b, h, w):
     try:
         _check_stage_against_torch(st, x)
     finally:
-        _lib.check(lib.dhd_sfa_set_gemm_mode(1), 'mode')
+        _lib.check(lib.dhd_sfa_set_gemm_mode(3), 'mode')
 
 
-@pytest.mark.parametrize('c,b,h,w', [(256, 2, 200, 200), (512, 1, 200, 200), (256, 1, 64, 72)])
-def test_sfa_stage_tail_launch_is_bit_identical_to_one_launch(gpu, c, b, h, w):
-    """GEMM mode 1 sends the tiles beyond the full rounds of 2 x CUs workgroups to a second launch of
-    128-channel workgroups (full rounds + tail at (2,256) / (1,512), tail only at the small size); mode 2
-    is one launch.  Same accumulation order per output element: every result must be bit-identical."""
+@pytest.mark.parametrize('c,b,h,w', [(256, 2, 200, 200), (512, 1, 200, 200), (256, 1, 64, 72), (128, 3, 36, 40)])
+def test_sfa_stage_x6_modes_are_bit_identical(gpu, c, b, h, w):
+    """The three bf16x6 GEMM modes accumulate every output element in the same order: mode 2 streams the weights
+    through LDS per 128-pixel tile and sends the tiles beyond the full rounds of 2 x CUs workgroups to a second launch
+    of 128-channel workgroups, mode 4 is the same in one launch, mode 1 keeps the weights resident in LDS in
+    persistent workgroups (teams of C / 64 workgroups per pixel tile).  Every result must be bit-identical."""
     from dhd_amd import _lib
     from dhd_amd.mix import channel_spatial_stage
     torch.manual_seed(c + h)
@@ -509,7 +537,7 @@ def test_sfa_stage_tail_launch_is_bit_identical_to_one_launch(gpu, c, b, h, w):
     lib = _lib.load()
     res = []
     try:
-        for mode in (1, 2):
+        for mode in (2, 4, 1):
             _lib.check(lib.dhd_sfa_set_gemm_mode(mode), 'mode')
             for p in st.parameters():
                 p.grad = None
@@ -518,9 +546,10 @@ def test_sfa_stage_tail_launch_is_bit_identical_to_one_launch(gpu, c, b, h, w):
             out.backward(g)
             res.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in st.parameters()])
     finally:
-        _lib.check(lib.dhd_sfa_set_gemm_mode(1), 'mode')
-    for a, bb in zip(*res):
-        assert torch.equal(a, bb)
+        _lib.check(lib.dhd_sfa_set_gemm_mode(3), 'mode')
+    for other in res[1:]:
+        for a, bb in zip(res[0], other):
+            assert torch.equal(a, bb)
 
 
 def test_fused_sfa_stage_matches_generic_path(gpu):
