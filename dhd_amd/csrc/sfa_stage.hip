@@ -1538,6 +1538,173 @@ __global__ __launch_bounds__(kWgBlock, 2) void pw_wgrad6_kernel(const float* __r
       }
 }
 
+// Weight gradient in the bf16x3 mode: G[co][ci] = sum_{b,p} A(co,p) * B(ci,p) with two bf16 parts per operand and the
+// three products ah*bh + ah*bm + am*bh.  Same organisation as pw_wgrad6_kernel (items of 8 pixels are loaded,
+// prologue'd and split ONCE by one thread and written to LDS in MFMA fragment order), but a step is 32 pixels = two
+// MFMA k-steps: every channel row contributes one whole 128-byte line per step (a thread loads 64 contiguous bytes
+// per input), so no line is fetched twice -- the 16-pixel steps of the x6 kernel re-fetch the other half of each line
+// one step later, after the XCD's L2 has been turned over (PMC: 980 MB against 656 MB algorithmic) -- and there is one
+// workgroup barrier per 32 pixels instead of per 16.  Two parts instead of three make the 32-pixel double buffer fit
+// in LDS (2 x 64 KB at OT = 256).
+template <int OT, bool A_TWO, bool B_TWO, bool B_RELU>
+__global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
+                                                                const float* __restrict__ acoef, size_t a_bstride,
+                                                                const float* __restrict__ b0, const float* __restrict__ b1,
+                                                                const float* __restrict__ bcoef, size_t b_bstride,
+                                                                float* __restrict__ partial, int c, int hw, int nb, int n_workers) {
+  constexpr int TA = OT / 64, TB = OT / 128;     // 32x32 tiles per wave
+  constexpr int kTiles = OT / 32;                // 32-row tiles per operand
+  constexpr int kOp = kTiles * 2 * 64;           // 16-byte units of one staged operand k-step: [tile][term][lane]
+  constexpr int kBuf = 2 * 2 * kOp;              // [k-step 2][operand 2]
+  constexpr int kOps = OT == 256 ? 2 : 1;        // operands a thread stages: OT = 256 both, OT = 128 one (by wave)
+  extern __shared__ u32x4 ldsw[];                // [buf 2][k-step 2][operand 2][tile][term 2][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nob = c / OT;
+  const int ob_co = (blockIdx.y / nob) * OT, ob_ci = (blockIdx.y % nob) * OT;
+  const int wco = (wv >> 2) * (OT / 2), wci = (wv & 3) * (OT / 4);
+  const int sps = (hw + 31) >> 5;                // steps per sample
+  const long n_steps = (long)nb * sps;
+  const int s0 = (int)(n_steps * blockIdx.x / n_workers), s1 = (int)(n_steps * (blockIdx.x + 1) / n_workers);
+
+  // this thread's share of a step: row it_row of operand(s), pixels 16 * it_s .. + 15 (= k-step it_s, both lane halves)
+  const int it_row = OT == 256 ? (tid >> 1) : ((tid & 255) >> 1);
+  const int it_s = tid & 1;
+  const bool single_is_b = tid >= 256;           // OT = 128: waves 0-3 stage A, waves 4-7 stage B (wave-uniform)
+  const int it_slot = (it_row >> 5) * 128 + (it_row & 31);   // + term * 64 + 32 * (lane half j)
+
+  f32x16 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  f32x4 raw[kOps][2][4];                         // [operand][input][16 pixels]
+  float cfa[3], cfb[3];
+  int cur_b = -1;
+  auto load_coefs = [&](int b) {
+    const float* ca = acoef + (size_t)b * 3 * c + ob_co + it_row;
+    const float* cb = bcoef + (size_t)b * 3 * c + ob_ci + it_row;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { cfa[q] = ca[q * c]; cfb[q] = cb[q * c]; }
+    cur_b = b;
+  };
+  auto fetch = [&](int s, auto only) {            // only = -1: every operand of this thread
+    constexpr int ONLY = decltype(only)::value;
+    const int b = s / sps, p = (s % sps) * 32 + 16 * it_s;
+#pragma unroll
+    for (int it = 0; it < kOps; ++it) {
+      if (ONLY >= 0 && it != ONLY) continue;
+      const bool is_b = OT == 256 ? it == 1 : single_is_b;
+      const float* src0 = is_b ? b0 : a0;
+      const float* src1 = is_b ? b1 : a1;
+      const bool two = is_b ? B_TWO : A_TWO;
+      const size_t base = (size_t)b * (is_b ? b_bstride : a_bstride) + (size_t)((is_b ? ob_ci : ob_co) + it_row) * hw;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pq = p + 4 * q;
+        const size_t off = base + (pq < hw ? pq : 0);
+        raw[it][0][q] = *reinterpret_cast<const f32x4*>(src0 + off);
+        if (two) raw[it][1][q] = *reinterpret_cast<const f32x4*>(src1 + off);
+      }
+    }
+  };
+  auto stage = [&](int s, int buf, auto only) {
+    constexpr int ONLY = decltype(only)::value;
+    const int b = s / sps, p = (s % sps) * 32 + 16 * it_s;
+    if (b != cur_b) load_coefs(b);  // block-uniform, at most twice per worker
+#pragma unroll
+    for (int it = 0; it < kOps; ++it) {
+      if (ONLY >= 0 && it != ONLY) continue;
+      const bool is_b = OT == 256 ? it == 1 : single_is_b;
+      const bool two = is_b ? B_TWO : A_TWO;
+      const float k0 = is_b ? cfb[0] : cfa[0], k1 = is_b ? cfb[1] : cfa[1], k2 = is_b ? cfb[2] : cfa[2];
+      const f32x2 k0v = {k0, k0}, k1v = {k1, k1}, k2v = {k2, k2};
+      u32x4* dst = ldsw + buf * kBuf + (it_s * 2 + (is_b ? 1 : 0)) * kOp + it_slot;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {              // lane half j = pixels 8j .. 8j + 7 of this k-step
+        u32x4 th, tm;
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+          const int q = 2 * j + (jp >> 1), e = 2 * (jp & 1);
+          const bool in = p + 4 * q < hw;
+          const f32x2 x0 = {raw[it][0][q][e], raw[it][0][q][e + 1]};
+          f32x2 t = __builtin_elementwise_fma(k0v, x0, k2v);
+          if (two) {
+            const f32x2 x1 = {raw[it][1][q][e], raw[it][1][q][e + 1]};
+            t = __builtin_elementwise_fma(k1v, x1, t);
+          }
+          if (is_b && B_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); }
+          if (!in) { t.x = 0.f; t.y = 0.f; }
+          unsigned hh, mm;
+          split2_hm(t.x, t.y, hh, mm);
+          th[jp] = hh; tm[jp] = mm;
+        }
+        dst[32 * j] = th;
+        dst[64 + 32 * j] = tm;
+      }
+    }
+  };
+
+  using All = std::integral_constant<int, -1>;
+  using Op0 = std::integral_constant<int, 0>;
+  using Op1 = std::integral_constant<int, 1>;
+  if (s0 < s1) {
+    fetch(s0, All{});
+    stage(s0, 0, All{});
+    fetch(min(s0 + 1, s1 - 1), All{});
+  }
+  __syncthreads();
+  for (int s = s0; s < s1; ++s) {
+    const int buf = (s - s0) & 1;
+    // unconditional (indices clamped to the last step, whose re-staged copy nobody reads), see pw_wgrad6_kernel
+    // (tried: operand by operand -- stage A(s+1), request A(s+2), stage B(s+1), request B(s+2) -- so that requests are
+    // always queued while the wave waits: 164 -> 176 us, no gain)
+    stage(min(s + 1, s1 - 1), buf ^ 1, All{});
+    fetch(min(s + 2, s1 - 1), All{});
+    // keep the loads of step s + 2 ahead of this step's MFMAs (the scheduler sinks them to the end)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const u32x4* ta = ldsw + buf * kBuf + (ks * 2) * kOp + lane;
+      const u32x4* tb = ta + kOp;
+      u32x4 fb[TB][2];
+#pragma unroll
+      for (int j = 0; j < TB; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fb[j][t] = tb[(((wci >> 5) + j) * 2 + t) * 64];
+#pragma unroll
+      for (int i = 0; i < TA; ++i) {
+        u32x4 fa[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa[t] = ta[(((wco >> 5) + i) * 2 + t) * 64];
+        // terms: 0 = high, 1 = mid; smallest products first
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(fa[1], fb[j][0], acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(fa[0], fb[j][1], acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(fa[0], fb[j][0], acc[i][j]);
+      }
+    }
+    __syncthreads();
+  }
+
+  float* po = partial + (size_t)blockIdx.x * c * c;
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = ob_co + wco + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int ci = ob_ci + wci + 32 * j + r;
+        po[(size_t)co * c + ci] = acc[i][j][e];
+      }
+}
+
 // gw[i] = sum over workers of partial[w][i].  A workgroup covers 64 consecutive elements x 4 worker phases: wave
 // p sums workers p, p+4, ... with 16 loads in flight per lane, the four phase sums meet in LDS (fixed order:
 // deterministic).  One thread per element with four loads in flight left the 64 MB of partials at 3 TB/s.
@@ -1860,7 +2027,26 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
   } while (0)
   const bool btwo = b1 != nullptr;
   if (a1 == nullptr) return DHD_EUNSUPPORTED;
-  if (g_gemm_mode >= 1) {
+  if (g_gemm_mode == 3) {
+    const size_t shmem3 = (size_t)2 * 2 * 2 * (ot / 32) * 2 * 64 * 16;
+#define DHD_WG3(OT, ATWO, BTWO, BRELU)                                                                             \
+  do {                                                                                                             \
+    auto kern = pw_wgrad3_kernel<OT, ATWO, BTWO, BRELU>;                                                           \
+    DHD_LDS_ATTR_ONCE(kern, shmem3);                                                                               \
+    hipLaunchKernelGGL(kern, grid, dim3(kWgBlock), shmem3, st, a0, a1, acoef, a_bs, b0, b1, bcoef, b_bs, partial,  \
+                       c, hw, b, workers);                                                                         \
+  } while (0)
+    if (ot == 128) {
+      if (btwo) DHD_WG3(128, true, true, false);
+      else if (b_relu) DHD_WG3(128, true, false, true);
+      else return DHD_EUNSUPPORTED;
+    } else {
+      if (btwo) DHD_WG3(256, true, true, false);
+      else if (b_relu) DHD_WG3(256, true, false, true);
+      else return DHD_EUNSUPPORTED;
+    }
+#undef DHD_WG3
+  } else if (g_gemm_mode >= 1) {
     const size_t shmem6 = (size_t)2 * 2 * (ot / 32) * 3 * 64 * 16;
 #define DHD_WG6(OT, ATWO, BTWO, BRELU)                                                                             \
   do {                                                                                                             \
