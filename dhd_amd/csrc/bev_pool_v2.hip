@@ -47,13 +47,20 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_fwd_kernel(int c, int n_in
         dv = depth[ranks_depth[start + s0 + lane]];
       }
       const int steps = (nb + nsub - 1) / nsub;
-      for (int k = 0; k < steps; ++k) {
-        const int i = k * nsub + sub;
-        const bool live = i < nb;
-        int q = __shfl(rf, live ? i : 0, DHD_WAVE);
-        float d = __shfl(dv, live ? i : 0, DHD_WAVE);
-        float f = (live && ok) ? feat[(size_t)q * c + ch] : 0.f;
-        acc = fmaf(f, d, acc);
+      // eight independent row gathers in flight per lane (a dependent one-at-a-time loop left the kernel at the
+      // latency of ~8 serial L2 round trips per interval: 118 -> see DESIGN.md)
+      for (int k0 = 0; k0 < steps; k0 += 8) {
+        float f[8], d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = (k0 + u) * nsub + sub;
+          const bool live = i < nb;
+          const int q = __shfl(rf, live ? i : 0, DHD_WAVE);
+          d[u] = __shfl(dv, live ? i : 0, DHD_WAVE);
+          f[u] = (live && ok) ? feat[(size_t)q * c + ch] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(f[u], d[u], acc);
       }
     }
     for (int m = CL; m < DHD_WAVE; m <<= 1) acc += __shfl_xor(acc, m, DHD_WAVE);
@@ -119,6 +126,76 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_kernel(int c, int n_in
   }
 }
 
+// Backward, single pass, for C <= 64 * NCC: every out_grad row of the pixel's points is gathered ONCE (eight rows in
+// flight), used for both gradients; the per-point dot product is a DPP wave reduction (no LDS crossbar).
+template <int NCC>
+__global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_fast_kernel(int c, int n_intervals, const float* __restrict__ out_grad,
+                                                                       const float* __restrict__ depth,
+                                                                       const float* __restrict__ feat,
+                                                                       const int* __restrict__ ranks_depth,
+                                                                       const int* __restrict__ ranks_feat,
+                                                                       const int* __restrict__ ranks_bev,
+                                                                       const int* __restrict__ interval_starts,
+                                                                       const int* __restrict__ interval_lengths,
+                                                                       float* __restrict__ depth_grad,
+                                                                       float* __restrict__ feat_grad) {
+  const int lane = threadIdx.x & 63;
+  const int iv = blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (iv >= n_intervals) return;
+  const int start = __builtin_amdgcn_readfirstlane(interval_starts[iv]);
+  const int len = __builtin_amdgcn_readfirstlane(interval_lengths[iv]);
+  const int pix = __builtin_amdgcn_readfirstlane(ranks_feat[start]);
+  float fv[NCC], facc[NCC];
+#pragma unroll
+  for (int cc = 0; cc < NCC; ++cc) {
+    const int ch = cc * DHD_WAVE + lane;
+    fv[cc] = ch < c ? feat[(size_t)pix * c + ch] : 0.f;
+    facc[cc] = 0.f;
+  }
+  for (int s0 = 0; s0 < len; s0 += DHD_WAVE) {
+    const int nb = min(DHD_WAVE, len - s0);
+    int rb = 0, rd = 0;
+    float dv = 0.f;
+    if (lane < nb) {
+      rb = ranks_bev[start + s0 + lane];
+      rd = ranks_depth[start + s0 + lane];
+      dv = depth[rd];
+    }
+    float mine = 0.f;
+    for (int i0 = 0; i0 < nb; i0 += 8) {
+      float g[8][NCC], d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = min(i0 + u, nb - 1);     // uniform; past the end: a harmless re-read of the last point
+        const int vox = __builtin_amdgcn_readlane(rb, i);
+        d[u] = i0 + u < nb ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), i)) : 0.f;
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) {
+          const int ch = cc * DHD_WAVE + lane;
+          g[u][cc] = ch < c ? out_grad[(size_t)vox * c + ch] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float part = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) {
+          part = fmaf(g[u][cc], fv[cc], part);
+          facc[cc] = fmaf(g[u][cc], d[u], facc[cc]);
+        }
+        const float tot = wave_sum_bcast(part);
+        if (lane == i0 + u) mine = tot;
+      }
+    }
+    if (lane < nb) depth_grad[rd] = mine;
+  }
+#pragma unroll
+  for (int cc = 0; cc < NCC; ++cc) {
+    const int ch = cc * DHD_WAVE + lane;
+    if (ch < c) feat_grad[(size_t)pix * c + ch] = facc[cc];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -145,9 +222,14 @@ int dhd_bev_pool_v2_backward(const float* out_grad, float* depth_grad, float* fe
   if (!out_grad || !depth_grad || !feat_grad || !depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev ||
       !interval_lengths_bp || !interval_starts_bp)
     return DHD_EINVAL;
-  hipLaunchKernelGGL(bev_pool_v2_bwd_kernel, dim3(dhd_cdiv(n_intervals_bp, kWaves)), dim3(kBlock), 0, dhd_stream(stream),
-                     c, n_intervals_bp, out_grad, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts_bp,
-                     interval_lengths_bp, depth_grad, feat_grad);
+  const dim3 grid(dhd_cdiv(n_intervals_bp, kWaves));
+#define DHD_BWD(KERN)                                                                                                    \
+  hipLaunchKernelGGL(KERN, grid, dim3(kBlock), 0, dhd_stream(stream), c, n_intervals_bp, out_grad, depth, feat, ranks_depth, \
+                     ranks_feat, ranks_bev, interval_starts_bp, interval_lengths_bp, depth_grad, feat_grad)
+  if (c <= 64) DHD_BWD(bev_pool_v2_bwd_fast_kernel<1>);
+  else if (c <= 128) DHD_BWD(bev_pool_v2_bwd_fast_kernel<2>);
+  else DHD_BWD(bev_pool_v2_bwd_kernel);
+#undef DHD_BWD
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }

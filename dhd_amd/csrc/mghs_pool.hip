@@ -233,27 +233,36 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
     }
     __syncthreads();
     if (ABL(16)) continue;
-    for (int cc = wv; cc < cp; cc += kStreamWaves) {
-      // channel c_lo+cc of this segment: nvox contiguous floats starting at row y0 of its plane
-      vfloat4* dst = reinterpret_cast<vfloat4*>(
-          og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)(c_lo + cc) * sc + (size_t)sg.y0 * sg.nx);
-      for (int i = lane; i < nvec; i += DHD_WAVE) {
-        vfloat4 v = {0.f, 0.f, 0.f, 0.f};
-        const uint2 sl = *reinterpret_cast<const uint2*>(slot_of + 4 * i);
-        if (sl.x | sl.y) {
-          const unsigned s0 = sl.x & 0xffffu, s1 = sl.x >> 16, s2 = sl.y & 0xffffu, s3 = sl.y >> 16;
-          if (s0) v.x = table[(s0 - 1) * cp + cc];
-          if (s1) v.y = table[(s1 - 1) * cp + cc];
-          if (s2) v.z = table[(s2 - 1) * cp + cc];
-          if (s3) v.w = table[(s3 - 1) * cp + cc];
-        }
-#ifdef DHD_PLAIN_STORES
-        dst[i] = v;
-#else
-        // streamed once, not re-read here: non-temporal, so the output stream does not evict vsum from L2
-        __builtin_nontemporal_store(v, dst + i);
-#endif
+    // The cp channel runs of this pass (nvec 16-byte vectors each) are one flat index space: iteration `it` of wave
+    // `wv` stores vectors [(it * waves + wv) * 64, + 64).  With a wave per channel run, 200 vectors were 3 full
+    // stores + one 8-lane store (32 store instructions per wave and pass for 25 stores' worth of bytes); flat, every
+    // store but the last of the pass is a full 1 KB and the workgroup writes 8 KB contiguous per iteration.
+    float* base = og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)c_lo * sc + (size_t)sg.y0 * sg.nx;
+    const int total = cp * nvec;
+    constexpr int kStride = kStreamWaves * DHD_WAVE;
+    const int q_step = kStride / nvec, r_step = kStride % nvec;
+    int idx = wv * DHD_WAVE + lane;
+    int cc = idx / nvec, i = idx % nvec;
+    for (; idx < total; idx += kStride) {
+      vfloat4 v = {0.f, 0.f, 0.f, 0.f};
+      const uint2 sl = *reinterpret_cast<const uint2*>(slot_of + 4 * i);
+      if (sl.x | sl.y) {
+        const unsigned s0 = sl.x & 0xffffu, s1 = sl.x >> 16, s2 = sl.y & 0xffffu, s3 = sl.y >> 16;
+        if (s0) v.x = table[(s0 - 1) * cp + cc];
+        if (s1) v.y = table[(s1 - 1) * cp + cc];
+        if (s2) v.z = table[(s2 - 1) * cp + cc];
+        if (s3) v.w = table[(s3 - 1) * cp + cc];
       }
+      vfloat4* dst = reinterpret_cast<vfloat4*>(base + (size_t)cc * sc) + i;
+#ifdef DHD_PLAIN_STORES
+      *dst = v;
+#else
+      // streamed once, not re-read here: non-temporal, so the output stream does not evict vsum from L2
+      __builtin_nontemporal_store(v, dst);
+#endif
+      cc += q_step;
+      i += r_step;
+      if (i >= nvec) { i -= nvec; ++cc; }
     }
   }
 }
