@@ -99,6 +99,7 @@ def parse():
                    help='e2e: DHD-S (single frame), DHD-M (temporal stereo) or DHD-L (Swin-B, 512x1408 images, temporal stereo)')
     p.add_argument('--no-ema', action='store_true', help='e2e: leave out the per-iteration weight EMA (MEGVIIEMAHook) of the configs')
     p.add_argument('--cpu-samples', type=int, default=4, help='largest batch of the CPU baseline leg (0 = skip)')
+    p.add_argument('--deterministic', action='store_true', help='hotpath: order the entries of every voxel by point id (bit-reproducible forward)')
     p.add_argument('--no-e2e', action='store_true', help='hotpath: leave out the end-to-end DHD-S sub-record')
     p.add_argument('--no-operator', action='store_true', help='hotpath: leave out the standalone bev_pool_v2 operator timing')
     return p.parse_args()
@@ -649,6 +650,8 @@ def main():
         return run_ema(a, rank, world, dev)
     if a.workload == 'occ_loss':
         return run_occ_loss(a, rank, world, dev)
+    if a.deterministic:
+        mghs_op.set_deterministic(True)
     hp = HotPath(dev, a.batch, 1000 + rank, not a.no_sfa, a.geometry)
 
     for _ in range(a.warmup):
@@ -677,7 +680,8 @@ def main():
             config=dict(workload=('DHD-S (configs[1])' if a.geometry == 'dhd-s' else a.geometry.upper() + ' geometry (configs[3-4])') + ' hot path: MGHS 4-grid lift-splat fwd+bwd incl. geometry/grouping'
                                  + ('' if a.no_sfa else ' + SFA attention stage fwd+bwd') +
                                  f'; geometry {a.geometry}: 6 cams -> {hp.dims[2]}x{hp.dims[3]}, D={hp.dims[1]}, C=64, grids 200x200x{{1,4,4,8}}; dense backbone/encoder convs not in the step',
-                        samples_per_gpu=a.batch, global_batch=a.batch * world, parallelism=f'sample-sharded x{world}, no data-path collective'),
+                        samples_per_gpu=a.batch, global_batch=a.batch * world, parallelism=f'sample-sharded x{world}, no data-path collective',
+                        deterministic_forward=bool(a.deterministic)),
             roofline=dict(bound='hbm', kernel='mghs_stream_fwd', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s',
                           frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic('mghs_stream_fwd', a.batch), launch_ms=kern_ms,
                           algorithmic_bytes=hp.pool_fwd_bytes))

@@ -76,6 +76,8 @@ _PROTOTYPES = {
     'dhd_mghs_backward_views': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(TensorView * DHD_MAX_GRIDS), _P, _P, _P, _P], _I),
     'dhd_mghs_backward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P, _P, _P], _I),
     'dhd_mghs_voxel_index': ([C.POINTER(MghsDesc), C.POINTER(Calib), _I, _P, _P, _P], _I),
+    'dhd_mghs_set_deterministic': ([_I], _I),
+    'dhd_mghs_get_deterministic': ([], _I),
     'dhd_mghs_stats': ([C.POINTER(MghsDesc), _P, C.POINTER(C.c_int32 * DHD_MAX_GRIDS),
                         C.POINTER(C.c_int32 * DHD_MAX_GRIDS), _P], _I),
     'dhd_sfa_channel_mean': ([_P, _P, _I, _I, _I, _P], _I),

@@ -121,6 +121,16 @@ def _nhwc_to_nchw(x):
     return out
 
 
+def set_deterministic(on=True):
+    """Reproducible forward sums: prepare orders the entries of every voxel by point id (include/dhd_amd.h:
+    dhd_mghs_set_deterministic); costs one ranking pass + a second scatter per prepare.  Process-wide."""
+    _lib.check(_lib.load().dhd_mghs_set_deterministic(int(bool(on))), 'dhd_mghs_set_deterministic')
+
+
+def is_deterministic():
+    return bool(_lib.load().dhd_mghs_get_deterministic())
+
+
 def prepare(plan, calib, band, workspace):
     lib = _lib.load()
     dev = workspace.device

@@ -189,6 +189,15 @@ int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float
 int dhd_mghs_voxel_index(const dhd_mghs_desc* desc, const dhd_calib* calib, int grid_index,
                          int32_t* rank_map, float* ego, void* stream);
 
+/* Reproducible forward sums (process-wide switch; default off, or the environment variable DHD_MGHS_DETERMINISTIC=1 at
+ * first use).  By default the order of the entries inside a voxel is the arrival order of the counting atomics of
+ * dhd_mghs_prepare, so the float32 sum of a voxel differs in its last bits from run to run (the reference's order is
+ * unspecified as well: unstable argsort, lss_heightmap.py:355).  With the switch on, prepare orders the entries of
+ * every voxel by point id (one extra ranking pass + a second scatter): dhd_mghs_forward is then bit-identical from
+ * run to run, and equal to a sum in ascending ranks_depth order.  The backward is deterministic either way. */
+int dhd_mghs_set_deterministic(int on);
+int dhd_mghs_get_deterministic(void);
+
 /* Number of pooled (point, grid) pairs of the last prepare, per grid: n_kept[g] points,
  * n_intervals[g] non-empty voxels.  Reads back from the workspace: synchronises `stream`. */
 int dhd_mghs_stats(const dhd_mghs_desc* desc, const void* workspace, int32_t n_kept[DHD_MAX_GRIDS],

@@ -312,6 +312,45 @@ def test_full_size_properties_batch4(gpu):
     np.testing.assert_allclose(grads[1], grads3[1], atol=1e-3, rtol=1e-4)
 
 
+def test_deterministic_mode_makes_the_forward_bit_reproducible(gpu):
+    """dhd_mghs_set_deterministic(1): the entries of a voxel are ordered by point id instead of by the arrival order of
+    the counting atomics, so the per-voxel float32 sums -- hence every output -- are bit-identical from run to run, at
+    the full DHD-S size and B = 4; the results still agree with the default mode to rounding; gradients too."""
+    from dhd_amd import mghs_op
+    cfg = syn.dhd_s_config()
+    B = 4
+    calib_np = syn.make_calibration(91, B, 6, cfg['input_size'])
+    depth, feat, hidx = syn.lift_inputs(92, B, 6, 44, 16, 44, 64, 65)
+    ref_outs, ref_grads, _ = run_fused(gpu, cfg, calib_np, depth, feat, hidx, weights_seed=700)
+    assert not mghs_op.is_deterministic()
+    mghs_op.set_deterministic(True)
+    try:
+        runs = [run_fused(gpu, cfg, calib_np, depth, feat, hidx, weights_seed=700) for _ in range(3)]
+    finally:
+        mghs_op.set_deterministic(False)
+    for outs, grads, _ in runs[1:]:
+        for a, b in zip(runs[0][0], outs):
+            assert np.array_equal(a, b)
+        assert np.array_equal(runs[0][1][0], grads[0]) and np.array_equal(runs[0][1][1], grads[1])
+    for a, b in zip(runs[0][0], ref_outs):
+        assert np.array_equal(a != 0, b != 0)
+        np.testing.assert_allclose(a, b, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(runs[0][1][0], ref_grads[0], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(runs[0][1][1], ref_grads[1], atol=1e-3, rtol=1e-4)
+    # and against the oracle on a small case, where the ascending-point-order sum can be restated exactly
+    from oracle import mghs_oracle as O
+    cfg2 = small_dhds_cfg()
+    calib2 = syn.make_calibration(93, 1, 3, cfg2['input_size'])
+    d2, f2, h2 = syn.lift_inputs(94, 1, 3, 44, 4, 11, 8, 65)
+    mghs_op.set_deterministic(True)
+    try:
+        outs2, _, _ = run_fused(gpu, cfg2, calib2, d2, f2, h2)
+    finally:
+        mghs_op.set_deterministic(False)
+    for o, r in zip(outs2, O.view_transform(cfg2, calib2, d2, f2, h2)):
+        np.testing.assert_allclose(o, r, atol=1e-5, rtol=1e-5)
+
+
 # --------------------------------------------------------------------------- module level
 
 def test_mghs_module_matches_reference_outputs(gpu):
