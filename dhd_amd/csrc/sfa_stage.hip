@@ -998,6 +998,8 @@ __global__ __launch_bounds__(kEwBlock) void pack_weight_res_kernel(const float* 
   if (nt == 3) dst[128] = l;
 }
 
+constexpr int kResTrPitch = 36;
+
 #ifndef RESABL
 #define RESABL 0  // timing experiments only (results wrong when non-zero): 1 no stores, 2 every tile reads the pixels of tile 0 (L2-resident), 4 no MFMA
 #endif
@@ -1014,9 +1016,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
   static_assert(KCN % D == 0 && KCN >= 2 * D, "K steps: a multiple of the prefetch distance, at least two rounds");
   constexpr int nfrag = KCN * COB * NT;   // c == 16 * KCN
   float* cf = reinterpret_cast<float*>(ldsr + (size_t)nfrag * 64);
+  constexpr int kTrPitch = kResTrPitch;    // floats per row of the store patch: 32 pixels + 4 (conflict-free b128 rows)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
+  float* tr = cf + ((nb * 3 * c + 3) & ~3) + wv * (16 * kTrPitch);   // wave-private: 16 channel rows x 32 pixels
   // blocks i, i + 8, ... run on one XCD: `groups` consecutive ones of them form a team (same pixels, different channels)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int team = xcd + 8 * (slot / groups), g = slot % groups;
@@ -1190,33 +1194,50 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
     step(J2{}, F0{}, cur, KCN - D + 2, nxt, 2);
     step(J3{}, F0{}, cur, KCN - D + 3, nxt, 3);
 
-    // acc[t][4q + e] = pixel p0 + 8q + 4h + e, channel g*32*COB + 32t + r
+    // acc[t][4q + e] = pixel p0 + 8q + 4h + e, channel g*32*COB + 32t + r.  Stored straight from this layout a
+    // store instruction would write 64 separate 16-byte pieces (adjacent lanes = different channel rows): measured 40 us
+    // of a 125 us GEMM.  Each half tile (16 channels x 32 pixels) goes through a wave-private LDS patch instead and is
+    // written row-wise: 8 adjacent lanes = one whole 128-byte line, 8 lines per store instruction.
     const int p0 = cur.wt * 32;
     const int co0 = g * 32 * COB + r;
 #pragma unroll
     for (int t = 0; t < COB; ++t) {
       const int co = co0 + 32 * t;
-      const size_t row = ((size_t)cur.b * c + co) * hw;
       float bs = 0.f, s1 = 0.f, s2 = 0.f;
       unsigned word = 0;
       if (EPI == 0) bs = bias[co];
       if (EPI == 1) word = relu_mask[((size_t)cur.b * c + co) * nwt + cur.wt] >> (4 * h);
+      f32x4 vq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int p = p0 + 8 * q + 4 * h;
-        if (p >= hw) continue;
         f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
         if (EPI == 0) {
-          s1 += (v.x + v.y) + (v.z + v.w);
-          s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          if (p0 + 8 * q + 4 * h < hw) {   // hw % 4 == 0: a 4-pixel group is inside or outside as a whole
+            s1 += (v.x + v.y) + (v.z + v.w);
+            s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          }
           v.x += bs; v.y += bs; v.z += bs; v.w += bs;
         }
         if (EPI == 1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = ((word >> (8 * q + e)) & 1u) ? v[e] : 0.f;
         }
-        if ((RESABL & 1) && v.x != 12345.678f) continue;
-        *reinterpret_cast<f32x4*>(y + row + p) = v;
+        vq[q] = v;
+      }
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        if ((r >> 4) == ph) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(tr + (r & 15) * kTrPitch + 8 * q + 4 * h) = vq[q];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int rr = (lane >> 3) + 8 * k, p = p0 + 4 * (lane & 7);
+          const f32x4 w = *reinterpret_cast<const f32x4*>(tr + rr * kTrPitch + 4 * (lane & 7));
+          const size_t row = ((size_t)cur.b * c + g * 32 * COB + 32 * t + 16 * ph + rr) * hw;
+          if ((RESABL & 1) && w.x != 12345.678f) continue;
+          if (p < hw) *reinterpret_cast<f32x4*>(y + row + p) = w;
+        }
       }
       if (EPI == 0 && stat_part != nullptr) {  // block-uniform
         s1 += __shfl_xor(s1, 32, DHD_WAVE);
@@ -1821,6 +1842,7 @@ inline bool mode_resident() { return g_gemm_mode == 1 || g_gemm_mode == 3; }
 inline int mode_terms() { return g_gemm_mode == 3 ? 2 : 3; }
 
 constexpr int kResWaves = 8;                       // waves per resident workgroup
+constexpr size_t kResTrBytes = (size_t)kResWaves * 16 * kResTrPitch * sizeof(float);  // store patches of the waves
 constexpr size_t kLdsBytes = 160 * 1024;           // per-CU LDS of gfx950
 constexpr size_t kResWeightMax = 128 * 1024;       // budget for the weight fragments
 // 32-channel output tiles per resident workgroup: the largest of 4 / 2 / 1 whose fragments fit; 0 = does not fit
@@ -1883,7 +1905,7 @@ int launch_pw_gemm_res(const float* in0, const float* in1, size_t in_bstride, in
   const int groups = c / (32 * cob);
   const int kcn = c / 16, nwt = (hw + 31) / 32;
   const size_t wbytes = (size_t)kcn * cob * nt * 1024;
-  const int max_b = (int)((kLdsBytes - wbytes - 256) / ((size_t)3 * c * sizeof(float)));  // samples whose tables fit next to the weights
+  const int max_b = (int)((kLdsBytes - wbytes - kResTrBytes - 64) / ((size_t)3 * c * sizeof(float)));  // samples whose tables fit next to the weights
   if (max_b < 1) return DHD_EUNSUPPORTED;
   const bool two = in1 != nullptr;
   const unsigned in_bytes = (unsigned)((size_t)in_channels * hw * sizeof(float));
@@ -1897,7 +1919,7 @@ int launch_pw_gemm_res(const float* in0, const float* in1, size_t in_bstride, in
     const int need = dhd_cdiv(total, kResWaves);
     if (need < nteams) nteams = dhd_cdiv(need, 8) * 8;
     const dim3 grid(nteams * groups);
-    const size_t shmem = wbytes + (size_t)nb * 3 * c * sizeof(float);
+    const size_t shmem = wbytes + (((size_t)nb * 3 * c + 3) & ~(size_t)3) * sizeof(float) + kResTrBytes;
     const float* i0 = in0 + (size_t)b0 * in_bstride;
     const float* i1 = two ? in1 + (size_t)b0 * in_bstride : nullptr;
     const float* cf = coef + (size_t)b0 * 3 * c;
