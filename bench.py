@@ -74,8 +74,8 @@ def pmc_traffic(kernel, batch):
 
 def sfa_forward_traffic(batch):
     """Sum of the committed PMC traffic of the kernels one dhd_sfa_stage_forward call launches, or None."""
-    calls = {'plane_mean_kernel': 1, 'fc_forward_kernel': 1, 'pack_weight6_kernel': 2, 'pw_gemm6_kernel<8,true,false,0>': 1,
-             'pw_gemm6_kernel<8,false,true,0>': 1, 'stat_reduce_kernel': 2, 'bn_train_finalize_kernel': 2, 'blend2_bn_kernel': 1}
+    calls = {'plane_mean_kernel': 1, 'fc_forward_kernel': 1, 'pack_weight_res_kernel': 2, 'pw_gemm_res_kernel<2,4,16,true,false,0,8,0>': 1,
+             'pw_gemm_res_kernel<2,4,16,false,true,0,8,0>': 1, 'stat_reduce_kernel': 2, 'bn_train_finalize_kernel': 2, 'blend2_bn_kernel': 1}
     parts = [pmc_traffic(k, batch) for k in calls]
     if any(p is None for p in parts):
         return None
@@ -700,12 +700,13 @@ def main():
             fwd_bytes = a.batch * 4 * hw * (2 * 2 * c + 4 * c)   # 2 reads of (2C,H,W) + 4 passes over (C,H,W) = 328 MB/sample
             gemm_flop = 2.0 * c * c * hw * a.batch
             line['roofline_sfa_stage'] = dict(
-                bound='hbm', kernel='dhd_sfa_stage_forward (plane_mean, fc, 2 x pw_gemm6, stat reductions, blend2_bn)',
+                bound='hbm', kernel='dhd_sfa_stage_forward (plane_mean, fc, 2 x pw_gemm_res, stat reductions, blend2_bn)',
                 achieved=fwd_bytes / (fwd_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit='GB/s',
                 frac=fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, traffic=sfa_forward_traffic(a.batch), launch_ms=fwd_ms,
                 algorithmic_bytes=fwd_bytes,
                 backward_ms=bwd_ms, gemm_tflops_fp32_equivalent=6 * gemm_flop / ((fwd_ms + bwd_ms) * 1e-3) / 1e12,
-                note='float32 GEMMs computed as 6 bf16 MFMA products each (exact three-way split); f32-MFMA peak is 157 TFLOP/s')
+                note='six C x C GEMMs per forward+backward; default GEMM mode bf16x3: float32 operands as two bf16 parts, three bf16 MFMA '
+                     'products per a*b (include/dhd_amd.h: dhd_sfa_set_gemm_mode); f32-MFMA peak is 157 TFLOP/s')
     t_stage = time.perf_counter()
     if a.geometry == 'dhd-s' and not a.no_operator:
         op_roof = operator_roofline(hp, max(5, min(a.steps, 20)), 3)   # every rank runs it, rank 0 reports

@@ -2035,6 +2035,8 @@ int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in
 int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t a_bs, const float* b0, const float* b1,
                     const float* bcoef, size_t b_bs, bool b_relu, float* partial, float* gw, int b, int c, int hw,
                     hipStream_t st) {
+  // (tried at C = 256 in the bf16x3 mode: 128 x 128 tiles, two workgroups per CU, operands read twice through L2: 233 / 189 us
+  // against 166 / 138 us for one 256 x 256 tile per CU)
   const int ot = c == 128 ? 128 : 256;
   const int nob = (c / ot) * (c / ot);
   const int workers = kWgWorkers / nob > 0 ? kWgWorkers / nob : 1;
