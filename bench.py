@@ -100,6 +100,7 @@ def parse():
     p.add_argument('--no-ema', action='store_true', help='e2e: leave out the per-iteration weight EMA (MEGVIIEMAHook) of the configs')
     p.add_argument('--cpu-samples', type=int, default=4, help='largest batch of the CPU baseline leg (0 = skip)')
     p.add_argument('--deterministic', action='store_true', help='hotpath: order the entries of every voxel by point id (bit-reproducible forward)')
+    p.add_argument('--no-graph', action='store_true', help='e2e: issue the step eagerly instead of replaying it as one HIP graph (N = 1)')
     p.add_argument('--no-e2e', action='store_true', help='hotpath: leave out the end-to-end DHD-S sub-record')
     p.add_argument('--no-operator', action='store_true', help='hotpath: leave out the standalone bev_pool_v2 operator timing')
     return p.parse_args()
@@ -197,7 +198,7 @@ class EndToEnd:
     """DHD-S exactly as projects/configs/DHD/DHD-S.py:42-155 (random init, synthetic 6-camera batch,
     SURVEY.md 8d config 2): forward_train -> sum of the four losses -> backward -> grad clip 5 -> AdamW."""
 
-    def __init__(self, dev, batch, seed, world, amp, model='dhd-s', ema=True):
+    def __init__(self, dev, batch, seed, world, amp, model='dhd-s', ema=True, graph=False):
         import dhd_amd
         from dhd_amd.detector import dhd_l_model_cfg, dhd_m_model_cfg, dhd_s_model_cfg
         torch.manual_seed(seed)
@@ -208,13 +209,15 @@ class EndToEnd:
         self.model = dhd_amd.build_detector(cfg).to(dev).train()
         if model == 'dhd-l':
             self.model.img_backbone.init_weights()   # trunc-normal init of the Swin linears / bias tables (swin.py:876-890)
+        # (tried: every dense module in channels_last, with and without PYTORCH_MIOPEN_SUGGEST_NHWC[_BATCHNORM]: 81.7 / 81.9 ms per
+        # fp16 step against 76.1 ms in NCHW -- MIOpen's NCHW path with its own transposes is the faster one here)
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         self.n_params = sum(p.numel() for p in self.params)
         self.net = self.model
         if world > 1:
             self.net = torch.nn.parallel.DistributedDataParallel(self.model, device_ids=[dev.index], bucket_cap_mb=64,
                                                                  gradient_as_bucket_view=True)
-        self.opt = torch.optim.AdamW(self.params, lr=2e-4, weight_decay=1e-2, fused=True)  # DHD-S.py:262
+        self.opt = torch.optim.AdamW(self.params, lr=2e-4, weight_decay=1e-2, fused=True, capturable=bool(graph))  # DHD-S.py:262
         # custom_hooks of all three configs (DHD-S.py:272-278): weight EMA after every iteration
         self.ema = dhd_amd.ModelEMA(self.model, 0.9990, updates=10560) if ema else None
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -235,8 +238,28 @@ class EndToEnd:
         self.amp = {'off': None, 'bf16': torch.bfloat16, 'fp16': torch.float16}[amp]
         self.scaler = torch.amp.GradScaler('cuda') if amp == 'fp16' else None
         self.B = batch
+        self.graphed = None
+        self.graph_error = None
+        self.want_graph = bool(graph) and world == 1
+
+    def capture(self):
+        """After the eager warm-up: the whole step as one HIP graph (dhd_amd/graph.py); falls back to eager on failure."""
+        if not self.want_graph:
+            return
+        from dhd_amd.graph import GraphedStep
+        try:
+            self.graphed = GraphedStep(lambda: self._eager_step(), warmup=2)
+        except Exception as e:  # noqa: BLE001 -- report and keep measuring eagerly
+            self.graph_error = f'{type(e).__name__}: {e}'[:300]
+            self.graphed = None
+            torch.cuda.synchronize()
 
     def step(self, record):
+        if self.graphed is not None:
+            return self.graphed()
+        return self._eager_step()
+
+    def _eager_step(self):
         self.opt.zero_grad(set_to_none=True)
         with torch.autocast('cuda', dtype=self.amp, enabled=self.amp is not None):
             losses = self.net(return_loss=True, **self.kw)
@@ -257,9 +280,10 @@ class EndToEnd:
 
 
 def run_e2e(a, rank, world, dev):
-    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp, a.model, not a.no_ema)
+    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp, a.model, not a.no_ema, graph=not a.no_graph)
     for _ in range(a.warmup):
         job.step(False)
+    job.capture()
 
     def fence():
         torch.cuda.synchronize()
@@ -285,7 +309,7 @@ def run_e2e(a, rank, world, dev):
                                  'forward_train + backward + grad-clip + AdamW' + ('' if a.no_ema else ' + weight EMA (HIP)') + '; random init',
                         samples_per_gpu=a.batch, global_batch=a.batch * world, params=job.n_params,
                         parallelism=f'DDP x{world} (RCCL bucketed all-reduce overlapped with backward)' if world > 1 else 'single GPU',
-                        final_loss=float(loss)))), flush=True)
+                        hip_graph=job.graphed is not None, hip_graph_error=job.graph_error, final_loss=float(loss)))), flush=True)
     ddist.shutdown()
 
 
@@ -485,11 +509,18 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
         return ddist.max_over_ranks(time.perf_counter() - t0, dev) / n
 
     for amp in ('off', 'fp16'):
-        job = EndToEnd(dev, a.batch, 1000 + rank, world, amp, 'dhd-s', True)
+        job = EndToEnd(dev, a.batch, 1000 + rank, world, amp, 'dhd-s', True, graph=not a.no_graph)
         for _ in range(warmup):
             job.step(False)
+        eager = timed(job, 2) if job.want_graph else None
+        job.capture()
         per_step = timed(job, steps)
-        rec = dict(samples_per_s=a.batch * world / per_step, ms_per_step=1e3 * per_step, steps=steps, warmup=warmup)
+        rec = dict(samples_per_s=a.batch * world / per_step, ms_per_step=1e3 * per_step, steps=steps, warmup=warmup,
+                   hip_graph=job.graphed is not None)
+        if eager is not None:
+            rec['ms_per_step_eager'] = 1e3 * eager
+        if job.graph_error:
+            rec['hip_graph_error'] = job.graph_error
         if world > 1:
             with job.net.no_sync():
                 job.step(False)

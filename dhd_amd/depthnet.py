@@ -97,7 +97,7 @@ class DCN(nn.Module):
         b, c, h, w = x.shape
         k = self.k
         g = self.groups
-        wgt = self.weight.view(g, self.out_channels // g, (c // g) * k * k)
+        wgt = self.weight.reshape(g, self.out_channels // g, (c // g) * k * k)
         if self.use_hip and x.is_cuda and h * w * 4 <= 48 * 1024:
             # sampling in HIP (float32); the GEMM with the layer's weight follows the ambient autocast dtype
             col = _DeformIm2col.apply(x.float(), self.conv_offset(x).float(), k, self.padding, self.dilation)

@@ -384,7 +384,10 @@ class predictor(nn.Module):
         if occ_loss.supported(preds):
             # one HIP operator: two streaming passes, no host round trips (csrc/occ_loss.hip)
             scale = getattr(self.loss_occ, 'loss_weight', 1.0)
-            l_ce, l_sem, l_geo = occ_loss.occ_losses(preds, voxel_semantics, mask_camera, self.cls_weights,
+            cw = getattr(self, '_cls_weights_dev', None)   # device copy made once (a per-step host-to-device copy also
+            if cw is None or cw.device != preds.device:    # cannot be captured into a HIP graph)
+                cw = self._cls_weights_dev = self.cls_weights.to(device=preds.device, dtype=torch.float32)
+            l_ce, l_sem, l_geo = occ_loss.occ_losses(preds, voxel_semantics, mask_camera, cw,
                                                      ignore_index=self.loss_occ.ignore_index, non_empty_idx=17)
             return dict(loss_occ=self.weight_ce * scale * l_ce, loss_voxel_sem_scal=self.weight_sem * l_sem,
                         loss_voxel_geo_scal=self.weight_geo * l_geo)
@@ -407,6 +410,20 @@ class predictor(nn.Module):
 
 
 # ------------------------------------------------------------------ detector
+
+def _affine_inverse(m):
+    """Inverse of (..., 4, 4) affine matrices [[A, t], [0, 1]] by the adjugate of A: element-wise tensor ops only."""
+    a = m[..., :3, :3]
+    r0, r1, r2 = a[..., 0, :], a[..., 1, :], a[..., 2, :]
+    c0, c1, c2 = torch.cross(r1, r2, dim=-1), torch.cross(r2, r0, dim=-1), torch.cross(r0, r1, dim=-1)
+    det = (r0 * c0).sum(-1, keepdim=True)
+    inv_a = torch.stack((c0, c1, c2), dim=-1) / det.unsqueeze(-1)
+    t = m[..., :3, 3:4]
+    top = torch.cat((inv_a, -(inv_a @ t)), dim=-1)
+    bottom = torch.zeros_like(m[..., 3:4, :])
+    bottom[..., 0, 3] = 1.0
+    return torch.cat((top, bottom), dim=-2)
+
 
 @DETECTORS.register_module()
 class DHD(nn.Module):
@@ -446,13 +463,17 @@ class DHD(nn.Module):
                 x = x[0]
         return x.view(B, N, *x.shape[1:]), stereo_feat
 
-    def prepare_inputs(self, inputs):
+    def prepare_inputs(self, inputs):  # noqa: D401
         """sensor -> key-ego transforms in float64, then float32 (bevdet.py:60-78)."""
         assert len(inputs) == 7
         imgs, s2e, e2g, intrins, post_rots, post_trans, bda = inputs
         B, N = imgs.shape[:2]
         s2e, e2g = s2e.view(B, N, 4, 4), e2g.view(B, N, 4, 4)
-        key_inv = torch.inverse(e2g[:, 0:1].double())
+        key = e2g[:, 0:1].double()
+        # torch.inverse goes through the solver library (workspace allocation + synchronisation): not capturable.
+        # While the step is being captured into a HIP graph (dhd_amd/graph.py) the ego pose, an affine matrix with last
+        # row (0,0,0,1), is inverted in closed form instead (float64; equal to the LU inverse to ~1e-15 before the cast)
+        key_inv = _affine_inverse(key) if key.is_cuda and torch.cuda.is_current_stream_capturing() else torch.inverse(key)
         s2k = (key_inv @ e2g.double() @ s2e.double()).float()
         return [imgs, s2k, e2g, intrins, post_rots, post_trans, bda]
 

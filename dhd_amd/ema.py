@@ -85,8 +85,14 @@ class ModelEMA:
             if not v.is_cuda:
                 cpu.append((v, m))
                 continue
-            if v.dtype != torch.float32 or m.dtype != torch.float32 or not v.is_contiguous() or not m.is_contiguous():
-                raise _lib.DhdError('ModelEMA: GPU state must be contiguous float32 (the reference keeps the EMA in FP32)')
+            # the kernel walks the two buffers linearly: any dense layout will do as long as both tensors share it
+            # (contiguous, or e.g. both channels_last)
+            dense = (v.is_contiguous() and m.is_contiguous()) or (
+                v.stride() == m.stride() and v.is_contiguous(memory_format=torch.channels_last)
+                and m.is_contiguous(memory_format=torch.channels_last)) if v.dim() == 4 else (v.is_contiguous() and m.is_contiguous())
+            if v.dtype != torch.float32 or m.dtype != torch.float32 or not dense:
+                raise _lib.DhdError('ModelEMA: GPU state must be dense float32 with one layout in the model and its EMA copy '
+                                    '(the reference keeps the EMA in FP32)')
             if v.device != m.device or v.shape != m.shape:
                 raise _lib.DhdError('ModelEMA: EMA and model state differ in device or shape')
             by_dev.setdefault(v.device, []).append((v, m))
