@@ -254,3 +254,49 @@ def test_stereo_detector_under_autocast_trains_the_shared_weights(gpu):
         norms[amp] = {n: float(params[n].grad.float().norm()) if params[n].grad is not None else 0.0 for n in names}
     for n in names:
         assert norms[None][n] > 0 and norms[torch.bfloat16][n] > 0.2 * norms[None][n], (n, norms[None][n], norms[torch.bfloat16][n])
+
+
+@pytest.mark.gpu
+def test_whole_step_hip_graph_replays_the_eager_step(gpu):
+    """dhd_amd.graph.GraphedStep: a training step around the HIP operators (MGHS module + SFA + optimizer) captured once and
+    replayed gives the same parameters as the same number of eager steps."""
+    import copy
+    from dhd_amd import MGHS, SFA
+    from dhd_amd import synthetic as syn
+    from dhd_amd.graph import GraphedStep
+    cfg = syn.dhd_s_config()
+    cfg['input_size'] = (64, 176)
+    cfg['out_channels'] = 8
+    cfg['in_channels'] = 16
+    torch.manual_seed(0)
+    base = torch.nn.ModuleDict(dict(vt=MGHS(**dict(cfg, heightnet_cfg=dict(use_dcn=False, use_aspp=False))), sfa=SFA(64, 32))).to(gpu)
+    calib = [torch.from_numpy(a).to(gpu) for a in syn.make_calibration(5, 1, 2, cfg['input_size'])]
+    x = torch.randn(1, 2, 16, 4, 11, device=gpu)
+
+    def make(model):
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, eps=1e-2, fused=True, capturable=True)   # large eps: no 1/|g| amplification of rounding
+        mlp = model['vt'].get_mlp_input(*calib)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            bev, depth, height, lo, mid, hi = model['vt']([x] + calib + [mlp])
+            loss = model['sfa'](torch.cat([lo, mid], 1)).square().mean() + bev.square().mean() + hi.mean()
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        return step
+    from dhd_amd import mghs_op
+    eager_model, graph_model = copy.deepcopy(base), copy.deepcopy(base)
+    mghs_op.set_deterministic(True)   # bit-reproducible pooling sums: the two runs see identical gradients
+    try:
+        eager = make(eager_model)
+        for _ in range(3 + 3):
+            eager()
+        graphed = GraphedStep(make(graph_model), warmup=3)   # 3 eager warm-up steps on a side stream, then capture (not executed)
+        for _ in range(3):
+            graphed()
+        torch.cuda.synchronize()
+    finally:
+        mghs_op.set_deterministic(False)
+    for (k, p), q in zip(eager_model.named_parameters(), graph_model.parameters()):
+        assert torch.allclose(p, q, atol=1e-4, rtol=1e-3), k

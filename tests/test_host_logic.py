@@ -390,3 +390,16 @@ def test_heightnet_depthnet_wiring_matches_reference_fixture(name):
     blocks (mmdet BasicBlock, mmcv DCN restated from the published algorithm).  The mirror on CPU (DCN through its
     grid_sample formulation): outputs, input gradient, parameter gradients, train and eval BatchNorm."""
     check_g13(name)
+
+
+def test_affine_inverse_matches_torch_inverse():
+    """detector._affine_inverse (the capturable closed form used while a step is recorded into a HIP graph) against
+    torch.inverse on ego poses: rotation + translation of hundreds of metres, float64."""
+    from dhd_amd.detector import _affine_inverse
+    g = torch.Generator().manual_seed(0)
+    m = torch.eye(4, dtype=torch.double).repeat(5, 1, 1, 1)
+    m[..., :3, :3] = torch.linalg.qr(torch.randn(5, 1, 3, 3, dtype=torch.double, generator=g))[0]
+    m[..., :3, 3] = torch.randn(5, 1, 3, dtype=torch.double, generator=g) * 500
+    ref = torch.inverse(m)
+    assert (ref - _affine_inverse(m)).abs().max() < 1e-11
+    assert torch.equal(ref.float(), _affine_inverse(m).float()) or (ref.float() - _affine_inverse(m).float()).abs().max() < 1e-4
