@@ -300,3 +300,47 @@ def test_whole_step_hip_graph_replays_the_eager_step(gpu):
         mghs_op.set_deterministic(False)
     for (k, p), q in zip(eager_model.named_parameters(), graph_model.parameters()):
         assert torch.allclose(p, q, atol=1e-4, rtol=1e-3), k
+
+
+@pytest.mark.gpu
+def test_config5_four_temporal_frames_with_swin_l_dimensions(gpu):
+    """BASELINE.json configs[4] ("DHD-L, Swin-L, 4-frame temporal stereo") has no reference config; the nearest wiring
+    is DHD-L.py with `multi_adj_frame_id_cfg=(1, 4, 1)` (three adjacent frames + the stereo reference frame = five loaded
+    frames, four lifted) and Swin-L's widths (embed 192, heads 6/12/24/48).  Built here with those widths, shallow stages
+    and reduced images: forward_train + backward through every frame's lift (D = 88), the BEV alignment of three history
+    frames, SFA with C = 256, finite gradients everywhere that matters."""
+    import dhd_amd
+    from dhd_amd.detector import dhd_l_model_cfg
+    torch.manual_seed(0)
+    H, W = 128, 352
+    cfg = dhd_l_model_cfg(input_size=(H, W))
+    n, adj = 64, 3
+    cfg['num_adj'] = adj
+    cfg['img_backbone'].update(embed_dims=192, depths=[2, 2, 2, 2], num_heads=[6, 12, 24, 48])
+    cfg['img_neck'].update(in_channels=768 + 1536)
+    cfg['img_bev_encoder_backbone'].update(numC_input=n * (adj + 1))
+    for k, nz in (('img_voxel_encoder0_backbone', 4), ('img_voxel_encoder1_backbone', 4), ('img_voxel_encoder2_backbone', 8)):
+        cfg[k].update(n_channels=n * nz * (adj + 1))
+    m = dhd_amd.build_detector(cfg).to(gpu).train()
+    B, N, Fr = 1, 2, adj + 2
+    imgs = torch.randn(B, N * Fr, 3, H, W, device=gpu)
+    per = [syn.make_calibration(50 + f, B, N, (H, W)) for f in range(Fr)]
+    cat = lambda k: T(np.concatenate([p[k] for p in per], 1), gpu)
+    e2g = cat(1).clone()
+    for f in range(1, Fr):
+        e2g[:, f * N:(f + 1) * N, 0, 3] += 0.8 * f
+    calib = [cat(0), e2g, cat(2), cat(3), cat(4), T(per[0][5], gpu)]
+    gt_d = T(np.where(syn.hash_uniform(1, (B, N, H, W)) < 0.05, 1 + 40 * syn.hash_uniform(2, (B, N, H, W)), 0).astype(np.float32), gpu)
+    gt_h = T(np.where(syn.hash_uniform(1, (B, N, H, W)) < 0.05, -1 + 6 * syn.hash_uniform(3, (B, N, H, W)), 0).astype(np.float32), gpu)
+    sem = torch.randint(0, 18, (B, 200, 200, 16), device=gpu)
+    cam = torch.rand(B, 200, 200, 16, device=gpu) < 0.3
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        losses = m(return_loss=True, img_inputs=[imgs] + calib, gt_depth=gt_d, gt_height=gt_h, voxel_semantics=sem, mask_camera=cam)
+        total = sum(losses.values())
+    assert set(losses) == {'loss_depth', 'loss_height', 'loss_occ', 'loss_voxel_sem_scal', 'loss_voxel_geo_scal'} and torch.isfinite(total)
+    total.backward()
+    for name in ('img_backbone.patch_embed.projection.weight', 'img_backbone.stages.3.blocks.1.ffn.layers.1.weight', 'img_neck.conv.0.weight',
+                 'img_view_transformer.depth_net.cost_volumn_net.0.weight', 'img_bev_encoder_backbone.layers.2.0.conv1.weight',
+                 'img_voxel_encoder2.inc.double_conv.0.weight', 'mix.mysk_7.spacial_leanring.3.weight', 'occ_head.predicter.0.weight'):
+        gr = dict(m.named_parameters())[name].grad
+        assert gr is not None and torch.isfinite(gr).all() and gr.abs().sum() > 0, name
