@@ -64,6 +64,13 @@ class ResNet(nn.Module):
         super().__init__()
         blocks = self.arch[depth][:num_stages]
         self.out_indices, self.with_cp, self.norm_eval = tuple(out_indices), with_cp, norm_eval
+        self.frozen_stages = frozen_stages
+        if pretrained:
+            # mmdet loads e.g. 'torchvision://resnet50' here; neither torchvision nor a network exists in this
+            # environment, so say so instead of silently training from random initialisation
+            import warnings
+            warnings.warn(f'ResNet(pretrained={pretrained!r}): checkpoint loading is not implemented, weights stay at their '
+                          'random initialisation; load a state dict explicitly', stacklevel=2)
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
@@ -93,6 +100,29 @@ class ResNet(nn.Module):
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)
+
+    def _freeze_stages(self):
+        """mmdet ResNet._freeze_stages: stem (frozen_stages >= 0) and the first `frozen_stages` stages in eval mode, no gradients."""
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            layer = getattr(self, f'layer{i}')
+            layer.eval()
+            for p in layer.parameters():
+                p.requires_grad = False
+
+    def train(self, mode=True):
+        """mmdet ResNet.train: frozen stages stay frozen; with norm_eval every BatchNorm keeps its running statistics."""
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
 
     def forward_first_stage(self, x):
         """Stem + first residual stage only: the stereo reference feature of BEVStereo4D (bevstereo4d.py:29-40)."""

@@ -403,3 +403,15 @@ def test_affine_inverse_matches_torch_inverse():
     ref = torch.inverse(m)
     assert (ref - _affine_inverse(m)).abs().max() < 1e-11
     assert torch.equal(ref.float(), _affine_inverse(m).float()) or (ref.float() - _affine_inverse(m).float()).abs().max() < 1e-4
+
+
+def test_resnet_honours_frozen_stages_norm_eval_and_warns_about_pretrained():
+    from dhd_amd.detector import ResNet
+    with pytest.warns(UserWarning, match='not implemented'):
+        net = ResNet(depth=50, frozen_stages=1, norm_eval=True, pretrained='torchvision://resnet50')
+    net.train()
+    assert not net.conv1.weight.requires_grad and not net.layer1[0].conv1.weight.requires_grad
+    assert net.layer2[0].conv1.weight.requires_grad
+    assert not net.bn1.training and not net.layer3[0].bn1.training      # norm_eval: every BatchNorm in eval mode
+    plain = ResNet(depth=50).train()
+    assert plain.bn1.training and plain.conv1.weight.requires_grad
