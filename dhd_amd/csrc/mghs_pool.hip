@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
   if (t == 1) ctl[1] = L.nzoff[sg.v0 + sg.nvox];
   for (int i = t; i < kSegMaxVox / 2; i += kStreamBlock) reinterpret_cast<unsigned*>(slot_of)[i] = 0u;
   __syncthreads();
-  const int k0 = rfl(ctl[0]), nnz = rfl(ctl[1]) - k0;
+  const int k0 = rfl(ctl[0]), nnz = ABL(32) ? 0 : rfl(ctl[1]) - k0;   // ABL(32): a pure zero stream through the same code
   for (int j = t; j < nnz; j += kStreamBlock) slot_of[L.nzvox[k0 + j] - sg.v0] = (unsigned short)(j + 1);
   const int cp = channels_per_pass(nnz);
   const int nvec = sg.nvox / 4;

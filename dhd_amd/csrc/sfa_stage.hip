@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kEwBlock) void blend2_bn_bwd_kernel(const float* __
   chunk_range4(hw, &lo, &hi);
   float s1 = 0.f, s2 = 0.f, sa = 0.f;
   for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
-    f32x4 p = b4[i], q = v4[i], s = y4[i], o = __builtin_nontemporal_load(o4 + i), r;
+    f32x4 p = __builtin_nontemporal_load(b4 + i), q = __builtin_nontemporal_load(v4 + i), s = y4[i], o = __builtin_nontemporal_load(o4 + i), r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float g = sigmoidf_(fmaf(sc, s[j], sh));

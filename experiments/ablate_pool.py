@@ -20,7 +20,7 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for name, mask in (('full', 0), ('fwd stream: no table load', 8), ('fwd stream: no stores', 16), ('bwd entry: no feat atomics', 1)):
+for name, mask in (('full', 0), ('fwd stream: no table load', 8), ('fwd stream: no stores', 16), ('fwd stream: zero stream only (no patches)', 32), ('bwd entry: no feat atomics', 1)):
     lib.dhd_debug_set_ablation(mask)
     f = timeit(lambda: mghs_op.pool_forward(hp.plan, hp.depth, feat, hp.ws))
     b = timeit(lambda: mghs_op.pool_backward(hp.plan, hp.depth, feat, hp.out_grads, hp.ws))
