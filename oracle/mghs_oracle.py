@@ -21,7 +21,7 @@ the inverse is measured (a handful of boundary points per 185 856).
 
 Also restated here, each pinned the same way: the SFA attention stage (`sfa_stage`, golden G5 from the
 reference's mix.py), the height loss and its label builders (G4), the occupancy-head losses (`occ_losses`,
-G6 from models/losses/semkitti_loss.py), the evaluation histogram (`occ_confusion`, definitional) and the
+G6 from models/losses/semkitti_loss.py), the evaluation histogram (`occ_confusion`, G14 from the reference's Metric_mIoU) and the
 LiDAR rasteriser (`points_to_maps`, G7 from datasets/pipelines/loading_new.py; equal keys of the reference's
 unstable argsort are identified as ties) and the weight EMA (`ema_decay` / `ema_update`, G9 from
 core/hook/ema.py's ModelEMA, bit-exact).  The stereo sampling grid and cost volume are pinned directly against golden G8 (the reference's

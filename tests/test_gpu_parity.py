@@ -873,6 +873,24 @@ def test_occ_argmax_and_confusion_histogram_vs_oracle(gpu):
     assert abs(miou - float(np.nanmean(iu_ref[:17]) * 100)) < 1e-9
 
 
+def test_occ_histogram_and_miou_vs_reference_metric(gpu):
+    """Golden G14, recorded from the reference's Metric_mIoU (core/evaluation/occ_metrics.py:78-169) over three samples:
+    dhd_occ_argmax_hist accumulating into one device histogram must reproduce its 18 x 18 counts exactly, and
+    miou_from_hist its rounded mIoU."""
+    from dhd_amd.occ_loss import miou_from_hist, occ_argmax_hist
+    from test_oracle_golden import g14_inputs
+    g = golden('g14_miou')
+    shape = tuple(int(v) for v in g['shape'])
+    hist = None
+    for k in range(3):
+        logits, gt, cam = g14_inputs(k, shape)
+        _, hist = occ_argmax_hist(T(logits.reshape(-1, 18), gpu), T(gt.reshape(-1), gpu), T(cam.reshape(-1), gpu), hist=hist)
+    assert np.array_equal(hist.cpu().numpy(), g['hist'])
+    miou, iu = miou_from_hist(hist)
+    np.testing.assert_allclose(iu.cpu().numpy(), g['per_class_iou'], rtol=1e-12)
+    assert round(miou, 2) == float(g['miou'])
+
+
 # --------------------------------------------------------------------------- height / depth supervision (a16)
 
 def test_height_loss_labels_and_value_vs_reference_golden(gpu):

@@ -346,3 +346,29 @@ def test_torch_cpu_twin_vs_reference_fixtures(name):
         np.testing.assert_allclose(feat.grad.numpy(), g['feat_grad'], atol=5e-6, rtol=0)
     else:
         assert not g['depth_grad'].any() and not g['feat_grad'].any()
+
+
+def g14_inputs(k, shape):
+    """Sample k of golden G14 (same hashes as tests/golden/make_golden.py)."""
+    logits = 3.0 * syn.hash_signed(1400 + k, tuple(shape) + (18,))
+    gt = (syn.hash_u32(1410 + k, int(np.prod(shape))) % 18).astype(np.uint8).reshape(shape)
+    gt[::7, ::5] = 255
+    cam = syn.hash_uniform(1420 + k, tuple(shape)) < 0.4
+    return logits.astype(np.float32), gt, cam
+
+
+def test_evaluation_histogram_vs_reference_metric():
+    """Golden G14: the reference's Metric_mIoU (core/evaluation/occ_metrics.py) fed three samples; oracle.occ_confusion
+    (get_occ + hist_info restated) must accumulate the same 18 x 18 histogram, per-class IoU and mIoU."""
+    g = golden('g14_miou')
+    shape = tuple(int(v) for v in g['shape'])
+    hist = np.zeros((18, 18))
+    for k in range(3):
+        logits, gt, cam = g14_inputs(k, shape)
+        _, h, _ = O.occ_confusion(logits.reshape(-1, 18), gt.reshape(-1), cam.reshape(-1))
+        hist += h
+    assert np.array_equal(hist, g['hist'])
+    with np.errstate(divide='ignore', invalid='ignore'):
+        iu = np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
+    np.testing.assert_allclose(iu, g['per_class_iou'], rtol=1e-12)
+    assert round(float(np.nanmean(iu[:17]) * 100), 2) == float(g['miou'])
