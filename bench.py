@@ -101,6 +101,8 @@ def parse():
     p.add_argument('--cpu-samples', type=int, default=4, help='largest batch of the CPU baseline leg (0 = skip)')
     p.add_argument('--deterministic', action='store_true', help='hotpath: order the entries of every voxel by point id (bit-reproducible forward)')
     p.add_argument('--no-graph', action='store_true', help='e2e: issue the step eagerly instead of replaying it as one HIP graph (N = 1)')
+    p.add_argument('--dist-backend', choices=['nccl', 'gloo'], default='nccl',
+                   help="process-group backend; 'gloo' lets several ranks share one GPU (testing the N > 1 code path on a one-GPU box)")
     p.add_argument('--no-e2e', action='store_true', help='hotpath: leave out the end-to-end DHD-S sub-record')
     p.add_argument('--no-operator', action='store_true', help='hotpath: leave out the standalone bev_pool_v2 operator timing')
     return p.parse_args()
@@ -534,7 +536,8 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
     out['config'] = dict(workload='DHD-S (configs[1]/[2]) whole detector: ResNet-50 + FPN, MGHS (HIP), BEV encoder, 3 UNets, SFA (HIP stage), '
                                   'predictor + losses (HIP); forward_train + backward + grad-clip + AdamW + weight EMA (HIP); random init',
                          samples_per_gpu=a.batch, global_batch=a.batch * world, params=n_params,
-                         parallelism=f'DDP x{world} (RCCL bucketed all-reduce, 64 MB buckets, overlapped with backward)' if world > 1 else 'single GPU')
+                         parallelism=f'DDP x{world} ({"RCCL" if a.dist_backend == "nccl" else "gloo, test only"} bucketed all-reduce, 64 MB buckets, '
+                                     f'overlapped with backward)' if world > 1 else 'single GPU')
     return out
 
 
@@ -671,9 +674,12 @@ def main():
     rank, local, world = ddist.env_world()
     if world != a.gpus:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or without a launcher)')
+    if a.dist_backend == 'gloo':
+        local = local % torch.cuda.device_count()   # ranks may share a device (RCCL refuses that, gloo does not)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    ddist.init_from_env(backend='nccl', device=dev)  # RCCL; used only for the barrier / MAX around the timed region
+    # RCCL ("nccl"); the hot path uses it only for the barrier / MAX around the timed region, the e2e sub-record for DDP
+    ddist.init_from_env(backend=a.dist_backend, device=dev if a.dist_backend == 'nccl' else None)
     _lib.load()
     if a.workload == 'e2e':
         return run_e2e(a, rank, world, dev)
@@ -750,7 +756,10 @@ def main():
     if a.geometry == 'dhd-s' and not a.no_sfa and not a.no_e2e:
         del hp
         torch.cuda.empty_cache()
-        e2e = e2e_subrecord(a, rank, world, dev)
+        try:
+            e2e = e2e_subrecord(a, rank, world, dev)
+        except Exception as exc:  # noqa: BLE001 -- the hot-path line must still be printed
+            e2e = dict(error=f'{type(exc).__name__}: {exc}'[:400])
         if rank == 0:
             line['e2e'] = e2e
             print(f'[bench] e2e leg {time.perf_counter() - t_stage:.1f} s', file=sys.stderr, flush=True)

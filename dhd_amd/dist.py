@@ -48,6 +48,8 @@ def max_over_ranks(value, device='cpu'):
     """MAX of a python float over all ranks (the slowest rank defines the step time)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return float(value)
+    if dist.get_backend() == 'gloo':
+        device = 'cpu'
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -56,6 +58,8 @@ def max_over_ranks(value, device='cpu'):
 def sum_over_ranks(value, device='cpu'):
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return float(value)
+    if dist.get_backend() == 'gloo':
+        device = 'cpu'
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
