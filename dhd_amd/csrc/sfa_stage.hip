@@ -1560,13 +1560,17 @@ __global__ __launch_bounds__(kWgBlock, 2) void pw_wgrad6_kernel(const float* __r
 }
 
 // Weight gradient in the bf16x3 mode: G[co][ci] = sum_{b,p} A(co,p) * B(ci,p) with two bf16 parts per operand and the
-// three products ah*bh + ah*bm + am*bh.  Same organisation as pw_wgrad6_kernel (items of 8 pixels are loaded,
-// prologue'd and split ONCE by one thread and written to LDS in MFMA fragment order), but a step is 32 pixels = two
-// MFMA k-steps: every channel row contributes one whole 128-byte line per step (a thread loads 64 contiguous bytes
-// per input), so no line is fetched twice -- the 16-pixel steps of the x6 kernel re-fetch the other half of each line
-// one step later, after the XCD's L2 has been turned over (PMC: 980 MB against 656 MB algorithmic) -- and there is one
-// workgroup barrier per 32 pixels instead of per 16.  Two parts instead of three make the 32-pixel double buffer fit
-// in LDS (2 x 64 KB at OT = 256).
+// three products ah*bh + ah*bm + am*bh.  Same organisation as pw_wgrad6_kernel (items of 8 pixels are prologue'd and
+// split ONCE by one thread and written to LDS in MFMA fragment order), but
+//   * a step is 32 pixels = two MFMA k-steps: every channel row contributes one whole 128-byte line per step, so no line
+//     is fetched twice -- the 16-pixel steps of the x6 kernel re-fetch the other half of each line one step later, after
+//     the XCD's L2 has been turned over (PMC: 980 MB against 656 MB algorithmic) -- and there is one workgroup barrier
+//     per 32 pixels instead of per 16.  Two parts instead of three make the 32-pixel double buffer fit in LDS (2 x 64 KB);
+//   * the loads are line-coalesced: in one load instruction 8 adjacent lanes read the 8 four-pixel pieces of ONE row's
+//     line (a wave instruction = 8 whole lines), instead of every lane reading 16 bytes of a different row (64 lines
+//     touched per instruction, each line touched by four instructions).  An 8-pixel item is then assembled with one
+//     lane-pair exchange (DPP quad_perm): of the rows loaded by instructions 2a and 2a+1, the even lane keeps its piece
+//     of row 2a and takes its neighbour's, the odd lane does the same for row 2a+1.
 template <int OT, bool A_TWO, bool B_TWO, bool B_RELU>
 __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
                                                                 const float* __restrict__ acoef, size_t a_bstride,
@@ -1577,7 +1581,8 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
   constexpr int kTiles = OT / 32;                // 32-row tiles per operand
   constexpr int kOp = kTiles * 2 * 64;           // 16-byte units of one staged operand k-step: [tile][term][lane]
   constexpr int kBuf = 2 * 2 * kOp;              // [k-step 2][operand 2]
-  constexpr int kOps = OT == 256 ? 2 : 1;        // operands a thread stages: OT = 256 both, OT = 128 one (by wave)
+  constexpr int NJ = OT / 64;                    // load instructions per operand input and step (64 rows each)
+  constexpr int NA = NJ / 2;                     // 8-pixel items per thread, operand and step
   extern __shared__ u32x4 ldsw[];                // [buf 2][k-step 2][operand 2][tile][term 2][lane]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -1588,11 +1593,11 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
   const long n_steps = (long)nb * sps;
   const int s0 = (int)(n_steps * blockIdx.x / n_workers), s1 = (int)(n_steps * (blockIdx.x + 1) / n_workers);
 
-  // this thread's share of a step: row it_row of operand(s), pixels 16 * it_s .. + 15 (= k-step it_s, both lane halves)
-  const int it_row = OT == 256 ? (tid >> 1) : ((tid & 255) >> 1);
-  const int it_s = tid & 1;
-  const bool single_is_b = tid >= 256;           // OT = 128: waves 0-3 stage A, waves 4-7 stage B (wave-uniform)
-  const int it_slot = (it_row >> 5) * 128 + (it_row & 31);   // + term * 64 + 32 * (lane half j)
+  // loads: instruction j reads rows 64 j + 8 wv + (lane >> 3), four pixels 4 (lane & 7) ..
+  const int ld_row = 8 * wv + (lane >> 3), ld_px = 4 * (lane & 7);
+  // items after the pair exchange: row 64 (2a + odd) + ld_row, pixels 8 chunk .. 8 chunk + 7, chunk = (lane & 7) >> 1
+  const int odd = lane & 1, chunk = (lane & 7) >> 1;
+  const int it_ks = chunk >> 1, it_h = chunk & 1;   // MFMA k-step and lane half of the item
 
   f32x16 acc[TA][TB];
 #pragma unroll
@@ -1602,89 +1607,98 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  f32x4 raw[kOps][2][4];                         // [operand][input][16 pixels]
-  float cfa[3], cfb[3];
+  f32x4 raw[2][2][NJ];                           // [operand][input][load instruction]
+  float cfa[NA][3], cfb[NA][3];                  // prologue coefficients of this thread's item rows
   int cur_b = -1;
   auto load_coefs = [&](int b) {
-    const float* ca = acoef + (size_t)b * 3 * c + ob_co + it_row;
-    const float* cb = bcoef + (size_t)b * 3 * c + ob_ci + it_row;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { cfa[q] = ca[q * c]; cfb[q] = cb[q * c]; }
+    for (int a = 0; a < NA; ++a) {
+      const int row = 64 * (2 * a + odd) + ld_row;
+      const float* ca = acoef + (size_t)b * 3 * c + ob_co + row;
+      const float* cb = bcoef + (size_t)b * 3 * c + ob_ci + row;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { cfa[a][q] = ca[q * c]; cfb[a][q] = cb[q * c]; }
+    }
     cur_b = b;
   };
-  auto fetch = [&](int s, auto only) {            // only = -1: every operand of this thread
-    constexpr int ONLY = decltype(only)::value;
-    const int b = s / sps, p = (s % sps) * 32 + 16 * it_s;
+  auto fetch = [&](int s) {
+    const int b = s / sps, p = (s % sps) * 32 + ld_px;
+    const size_t off = p < hw ? p : 0;
 #pragma unroll
-    for (int it = 0; it < kOps; ++it) {
-      if (ONLY >= 0 && it != ONLY) continue;
-      const bool is_b = OT == 256 ? it == 1 : single_is_b;
-      const float* src0 = is_b ? b0 : a0;
-      const float* src1 = is_b ? b1 : a1;
-      const bool two = is_b ? B_TWO : A_TWO;
-      const size_t base = (size_t)b * (is_b ? b_bstride : a_bstride) + (size_t)((is_b ? ob_ci : ob_co) + it_row) * hw;
+    for (int op = 0; op < 2; ++op) {
+      const float* src0 = op ? b0 : a0;
+      const float* src1 = op ? b1 : a1;
+      const bool two = op ? B_TWO : A_TWO;
+      const size_t base = (size_t)b * (op ? b_bstride : a_bstride) + (size_t)((op ? ob_ci : ob_co) + ld_row) * hw + off;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int pq = p + 4 * q;
-        const size_t off = base + (pq < hw ? pq : 0);
-        raw[it][0][q] = *reinterpret_cast<const f32x4*>(src0 + off);
-        if (two) raw[it][1][q] = *reinterpret_cast<const f32x4*>(src1 + off);
+      for (int j = 0; j < NJ; ++j) {
+        raw[op][0][j] = *reinterpret_cast<const f32x4*>(src0 + base + (size_t)(64 * j) * hw);
+        if (two) raw[op][1][j] = *reinterpret_cast<const f32x4*>(src1 + base + (size_t)(64 * j) * hw);
       }
     }
   };
-  auto stage = [&](int s, int buf, auto only) {
-    constexpr int ONLY = decltype(only)::value;
-    const int b = s / sps, p = (s % sps) * 32 + 16 * it_s;
+  // neighbour lane's value (lanes 2k <-> 2k+1): DPP quad_perm [1,0,3,2]
+  auto swap1 = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); };
+  auto stage = [&](int s, int buf) {
+    const int b = s / sps, p = (s % sps) * 32 + 8 * chunk;
     if (b != cur_b) load_coefs(b);  // block-uniform, at most twice per worker
+    const bool in_lo = p < hw, in_hi = p + 4 < hw;
 #pragma unroll
-    for (int it = 0; it < kOps; ++it) {
-      if (ONLY >= 0 && it != ONLY) continue;
-      const bool is_b = OT == 256 ? it == 1 : single_is_b;
-      const bool two = is_b ? B_TWO : A_TWO;
-      const float k0 = is_b ? cfb[0] : cfa[0], k1 = is_b ? cfb[1] : cfa[1], k2 = is_b ? cfb[2] : cfa[2];
-      const f32x2 k0v = {k0, k0}, k1v = {k1, k1}, k2v = {k2, k2};
-      u32x4* dst = ldsw + buf * kBuf + (it_s * 2 + (is_b ? 1 : 0)) * kOp + it_slot;
+    for (int op = 0; op < 2; ++op) {
+      const bool two = op ? B_TWO : A_TWO;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {              // lane half j = pixels 8j .. 8j + 7 of this k-step
+      for (int a = 0; a < NA; ++a) {
+        const float k0 = op ? cfb[a][0] : cfa[a][0], k1 = op ? cfb[a][1] : cfa[a][1], k2 = op ? cfb[a][2] : cfa[a][2];
+        const f32x2 k0v = {k0, k0}, k1v = {k1, k1}, k2v = {k2, k2};
+        // assemble the item: [lo 4 pixels | hi 4 pixels] of this thread's row, per input
+        float x[2][8];
+#pragma unroll
+        for (int in = 0; in < 2; ++in) {
+          if (in == 1 && !two) continue;
+          const f32x4 even_row = raw[op][in][2 * a], odd_row = raw[op][in][2 * a + 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float keep = odd ? odd_row[e] : even_row[e];
+            const float recv = swap1(odd ? even_row[e] : odd_row[e]);
+            x[in][e] = odd ? recv : keep;       // even lane holds the lower piece, odd lane the higher one
+            x[in][4 + e] = odd ? keep : recv;
+          }
+        }
         u32x4 th, tm;
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-          const int q = 2 * j + (jp >> 1), e = 2 * (jp & 1);
-          const bool in = p + 4 * q < hw;
-          const f32x2 x0 = {raw[it][0][q][e], raw[it][0][q][e + 1]};
+          const f32x2 x0 = {x[0][2 * jp], x[0][2 * jp + 1]};
           f32x2 t = __builtin_elementwise_fma(k0v, x0, k2v);
           if (two) {
-            const f32x2 x1 = {raw[it][1][q][e], raw[it][1][q][e + 1]};
+            const f32x2 x1 = {x[1][2 * jp], x[1][2 * jp + 1]};
             t = __builtin_elementwise_fma(k1v, x1, t);
           }
-          if (is_b && B_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); }
-          if (!in) { t.x = 0.f; t.y = 0.f; }
+          if (op == 1 && B_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); }
+          if (!(jp < 2 ? in_lo : in_hi)) { t.x = 0.f; t.y = 0.f; }
           unsigned hh, mm;
           split2_hm(t.x, t.y, hh, mm);
           th[jp] = hh; tm[jp] = mm;
         }
-        dst[32 * j] = th;
-        dst[64 + 32 * j] = tm;
+        const int row = 64 * (2 * a + odd) + ld_row;
+        u32x4* dst = ldsw + buf * kBuf + (it_ks * 2 + op) * kOp + (row >> 5) * 128 + (row & 31) + 32 * it_h;
+        dst[0] = th;
+        dst[64] = tm;
       }
     }
   };
 
-  using All = std::integral_constant<int, -1>;
-  using Op0 = std::integral_constant<int, 0>;
-  using Op1 = std::integral_constant<int, 1>;
   if (s0 < s1) {
-    fetch(s0, All{});
-    stage(s0, 0, All{});
-    fetch(min(s0 + 1, s1 - 1), All{});
+    fetch(s0);
+    stage(s0, 0);
+    fetch(min(s0 + 1, s1 - 1));
   }
   __syncthreads();
   for (int s = s0; s < s1; ++s) {
     const int buf = (s - s0) & 1;
-    // unconditional (indices clamped to the last step, whose re-staged copy nobody reads), see pw_wgrad6_kernel
-    // (tried: operand by operand -- stage A(s+1), request A(s+2), stage B(s+1), request B(s+2) -- so that requests are
-    // always queued while the wave waits: 164 -> 176 us, no gain)
-    stage(min(s + 1, s1 - 1), buf ^ 1, All{});
-    fetch(min(s + 2, s1 - 1), All{});
+    // unconditional (indices clamped to the last step, whose re-staged copy nobody reads), see pw_wgrad6_kernel.
+    // (tried: operand by operand -- stage A(s+1), request A(s+2), stage B(s+1), request B(s+2): no gain)
+    stage(min(s + 1, s1 - 1), buf ^ 1);
+    fetch(min(s + 2, s1 - 1));
     // keep the loads of step s + 2 ahead of this step's MFMAs (the scheduler sinks them to the end)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
