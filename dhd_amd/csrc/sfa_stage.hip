@@ -859,7 +859,7 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
           if (lane == j) word = (unsigned)bal;
           if (lane == 8 + j) word = (unsigned)(bal >> 32);
         }
-        if (lane < 16) relu_mask[((size_t)b * c + 16 * kc + lane) * nwt + wt] = word;
+        if (lane < 16) relu_mask[((size_t)b * nwt + wt) * c + 16 * kc + lane] = word;   // [sample][wave tile][channel]: 64 contiguous bytes
       }
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
     float bs = 0.f, s1 = 0.f, s2 = 0.f;
     unsigned word = 0;
     if (EPI == 0) bs = bias[co];
-    if (EPI == 1 && wt < nwt) word = relu_mask[((size_t)b * c + co) * nwt + wt] >> (4 * h);
+    if (EPI == 1 && wt < nwt) word = relu_mask[((size_t)b * nwt + wt) * c + co] >> (4 * h);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int p = p0 + 8 * q + 4 * h;
@@ -970,8 +970,10 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
 
 // Weight (rows x k; or its transpose) -> per-team-member slices of MFMA B fragments:
 //   packed16[(((g*KC + kc)*COB + t)*NT + term)*64 + lane] = term(M[g*32*COB + 32 t + (lane&31)][16 kc + 8 (lane>>5) + j]), j = 0..7
-__global__ __launch_bounds__(kEwBlock) void pack_weight_res_kernel(const float* __restrict__ w, int transpose, u32x4* __restrict__ packed,
-                                                                   int c, int cob, int nt) {
+__global__ __launch_bounds__(kEwBlock) void pack_weight_res_kernel(const float* __restrict__ w, const float* __restrict__ w_second,
+                                                                   int transpose, u32x4* __restrict__ packed,
+                                                                   u32x4* __restrict__ packed_second, int c, int cob, int nt) {
+  if (blockIdx.y == 1) { w = w_second; packed = packed_second; }   // both convolutions' weights in one launch
   const int idx = blockIdx.x * kEwBlock + threadIdx.x;  // (g, kc, t, lane)
   const int kcn = c / 16;
   if (idx >= (c / 32) * kcn * 64) return;
@@ -1116,7 +1118,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
           if (lane == j) word = (unsigned)bal;
           if (lane == 8 + j) word = (unsigned)(bal >> 32);
         }
-        if (lane < 16) relu_mask[((size_t)cur.b * c + 16 * kc + lane) * nwt + cur.wt] = word;
+        if (lane < 16) relu_mask[((size_t)cur.b * nwt + cur.wt) * c + 16 * kc + lane] = word;   // [sample][wave tile][channel]
       }
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
@@ -1206,7 +1208,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
       float bs = 0.f, s1 = 0.f, s2 = 0.f;
       unsigned word = 0;
       if (EPI == 0) bs = bias[co];
-      if (EPI == 1) word = relu_mask[((size_t)cur.b * c + co) * nwt + cur.wt] >> (4 * h);
+      if (EPI == 1) word = relu_mask[((size_t)cur.b * nwt + cur.wt) * c + co] >> (4 * h);
       f32x4 vq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1787,7 +1789,7 @@ SavedLayout saved_layout(int b, int c, int hw, int r) {
   L.tab_a = take((size_t)b * 3 * c);
   L.mean1 = take(c); L.rstd1 = take(c); L.scsh1 = take(2 * c); L.tab1 = take((size_t)b * 3 * c);
   L.mean2 = take(c); L.rstd2 = take(c); L.scsh2 = take(2 * c);
-  L.mask = take((size_t)b * c * ((hw + 31) / 32));  // ReLU pass bits, one word per (channel, 32 pixels)
+  L.mask = take((size_t)b * c * ((hw + 31) / 32));  // ReLU pass bits, one word per (32 pixels, channel): [sample][wave tile][channel]
   L.y1 = take((size_t)b * c * hw);
   L.y2 = take((size_t)b * c * hw);
   L.total = o;
@@ -1894,14 +1896,19 @@ int cu_count() {
   return n[dev];
 }
 
-int launch_pack(const float* w, int transpose, float* packed, int c, hipStream_t st) {
+int launch_pack(const float* w, int transpose, float* packed, int c, hipStream_t st, const float* w2 = nullptr,
+                float* packed2 = nullptr) {
   const int cot = pw_cot(c);
   if (res_supported(c)) {
     const int nt = mode_terms();
-    hipLaunchKernelGGL(pack_weight_res_kernel, dim3(dhd_cdiv((c / 32) * (c / 16) * 64, kEwBlock)), dim3(kEwBlock), 0, st, w, transpose,
-                       reinterpret_cast<u32x4*>(packed), c, res_cob(c, nt), nt);
+    hipLaunchKernelGGL(pack_weight_res_kernel, dim3(dhd_cdiv((c / 32) * (c / 16) * 64, kEwBlock), w2 ? 2 : 1), dim3(kEwBlock), 0, st, w,
+                       w2, transpose, reinterpret_cast<u32x4*>(packed), reinterpret_cast<u32x4*>(packed2), c, res_cob(c, nt), nt);
     DHD_LAUNCH_CHECK();
     return DHD_OK;
+  }
+  if (w2) {   // the streamed / f32 forms pack one weight per launch
+    const int rc = launch_pack(w, transpose, packed, c, st);
+    return rc != DHD_OK ? rc : launch_pack(w2, transpose, packed2, c, st);
   }
   if (g_gemm_mode >= 1)
     hipLaunchKernelGGL(pack_weight6_kernel, dim3(dhd_cdiv((c / 32) * (c / 16) * 64, kEwBlock)), dim3(kEwBlock), 0, st, w, transpose,
@@ -1937,7 +1944,7 @@ int launch_pw_gemm_res(const float* in0, const float* in1, size_t in_bstride, in
     const float* i0 = in0 + (size_t)b0 * in_bstride;
     const float* i1 = two ? in1 + (size_t)b0 * in_bstride : nullptr;
     const float* cf = coef + (size_t)b0 * 3 * c;
-    unsigned* rm = relu_mask ? relu_mask + (size_t)b0 * c * nwt : nullptr;
+    unsigned* rm = relu_mask ? relu_mask + (size_t)b0 * nwt * c : nullptr;
     float* sp = stat_part ? stat_part + (size_t)b0 * nwt * 2 * c : nullptr;
     float* yo = y + (size_t)b0 * c * hw;
 #define DHD_RES(NT, COB, KCN, TWO, RELU, EPI)                                                                            \
@@ -2165,9 +2172,7 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
   hipLaunchKernelGGL(fc_forward_kernel, dim3(b), dim3(kFcBlock), (size_t)(2 * c + r) * sizeof(float), st, sc + T.mean_part,
                      w->fc1_w, w->fc1_b, w->fc2_w, w->fc2_b, sv + S.s, sv + S.h, sv + S.a1, sv + S.tab_a, c, r, hw);
   DHD_LAUNCH_CHECK();
-  int rc = launch_pack(w->conv1_w, 0, sc + T.wp1, c, st);
-  if (rc != DHD_OK) return rc;
-  rc = launch_pack(w->conv2_w, 0, sc + T.wp2, c, st);
+  int rc = launch_pack(w->conv1_w, 0, sc + T.wp1, c, st, w->conv2_w, sc + T.wp2);
   if (rc != DHD_OK) return rc;
 
   // y1 = conv1(blend1(x))
@@ -2235,9 +2240,7 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
   const dim3 per_ch(dhd_cdiv(c, kEwBlock));
   const size_t cs = (size_t)c * hw;
 
-  int rc = launch_pack(w->conv1_w, 1, sc + T.wp1t, c, st);
-  if (rc != DHD_OK) return rc;
-  rc = launch_pack(w->conv2_w, 1, sc + T.wp2t, c, st);
+  int rc = launch_pack(w->conv1_w, 1, sc + T.wp1t, c, st, w->conv2_w, sc + T.wp2t);
   if (rc != DHD_OK) return rc;
   // g2 = dL/ds2, BatchNorm-2 sums, go-part of dL/da
   hipLaunchKernelGGL(blend2_bn_bwd_kernel, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, sv + S.mean2, gout,
