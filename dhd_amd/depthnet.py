@@ -240,11 +240,12 @@ class _LiftNetBase(nn.Module):
     def gen_grid(self, metas, B, N, D, H, W, hi, wi):
         """Current-frame stereo frustum -> sampling grid in the adjacent frame's image (reference depthnet.py:249-305)."""
         pts = metas['frustum'] - metas['post_trans'].view(B, N, 1, 1, 1, 3)
-        x, y, z = self._mat_vec(torch.inverse(metas['post_rots']), list(pts.unbind(-1)))
+        from .detector import small_inverse   # torch.inverse, or a closed form while a HIP graph is being captured
+        x, y, z = self._mat_vec(small_inverse(metas['post_rots']), list(pts.unbind(-1)))
         x, y = x * z, y * z
         rots = metas['k2s_sensor'][:, :, :3, :3].contiguous()
         trans = metas['k2s_sensor'][:, :, :3, 3].contiguous()
-        combine = rots.matmul(torch.inverse(metas['intrins']))
+        combine = rots.matmul(small_inverse(metas['intrins']))
         x, y, z = [v + trans[:, :, i, None, None, None] for i, v in enumerate(self._mat_vec(combine, [x, y, z]))]
         neg = z < 1e-3
         x, y, z = self._mat_vec(metas['intrins'], [x, y, z])

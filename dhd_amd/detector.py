@@ -455,6 +455,23 @@ def _affine_inverse(m):
     return torch.cat((top, bottom), dim=-2)
 
 
+def _inverse3(m):
+    """Inverse of (..., 3, 3) matrices by the adjugate (element-wise tensor ops only)."""
+    r0, r1, r2 = m[..., 0, :], m[..., 1, :], m[..., 2, :]
+    c0, c1, c2 = torch.cross(r1, r2, dim=-1), torch.cross(r2, r0, dim=-1), torch.cross(r0, r1, dim=-1)
+    det = (r0 * c0).sum(-1, keepdim=True)
+    return torch.stack((c0, c1, c2), dim=-1) / det.unsqueeze(-1)
+
+
+def small_inverse(m):
+    """torch.inverse, except while the current stream is being captured into a HIP graph (dhd_amd/graph.py): the solver
+    library behind torch.inverse allocates and synchronises, so 3x3 matrices and affine 4x4 matrices (last row 0,0,0,1:
+    every pose / calibration matrix of the detectors) are then inverted in closed form."""
+    if m.is_cuda and torch.cuda.is_current_stream_capturing():
+        return _inverse3(m) if m.shape[-1] == 3 else _affine_inverse(m)
+    return torch.inverse(m)
+
+
 @DETECTORS.register_module()
 class DHD(nn.Module):
     def __init__(self, img_backbone=None, img_neck=None, img_view_transformer=None, img_bev_encoder_backbone=None,
@@ -503,7 +520,7 @@ class DHD(nn.Module):
         # torch.inverse goes through the solver library (workspace allocation + synchronisation): not capturable.
         # While the step is being captured into a HIP graph (dhd_amd/graph.py) the ego pose, an affine matrix with last
         # row (0,0,0,1), is inverted in closed form instead (float64; equal to the LU inverse to ~1e-15 before the cast)
-        key_inv = _affine_inverse(key) if key.is_cuda and torch.cuda.is_current_stream_capturing() else torch.inverse(key)
+        key_inv = small_inverse(key)
         s2k = (key_inv @ e2g.double() @ s2e.double()).float()
         return [imgs, s2k, e2g, intrins, post_rots, post_trans, bda]
 
@@ -589,14 +606,14 @@ class DHD_stereo(DHD):
         imgs = [t.squeeze(2) for t in torch.split(imgs.view(B, N, F_, C, H, W), 1, 2)]
         s2e, e2g, intrins, post_rots, post_trans, bda = img_inputs[1:7]
         s2e, e2g = s2e.view(B, F_, N, 4, 4), e2g.view(B, F_, N, 4, 4)
-        key_inv = torch.inverse(e2g[:, 0, 0].double())[:, None, None]
+        key_inv = small_inverse(e2g[:, 0, 0].double())[:, None, None]
         s2k = (key_inv @ e2g.double() @ s2e.double()).float()
         curr2adj = None
         if stereo:
             t = self.temporal_frame
             cur = e2g[:, :t].double() @ s2e[:, :t].double()
             adj = e2g[:, 1:t + 1].double() @ s2e[:, 1:t + 1].double()
-            c2a = (torch.inverse(adj) @ cur).float()
+            c2a = (small_inverse(adj) @ cur).float()
             curr2adj = [p.squeeze(1) for p in torch.split(c2a, 1, 1)] + [None] * self.extra_ref_frames
             assert len(curr2adj) == F_
         per_frame = [[p.squeeze(1) for p in torch.split(v, 1, 1)] for v in
@@ -617,17 +634,21 @@ class DHD_stereo(DHD):
         bda_[:, :, 3, 3] = 1
         c02l0 = bda_.matmul(c02l0)
         c12l0 = (bda_ if bda_adj is None else bda_adj).matmul(c12l0)
-        l02l1 = c02l0.matmul(torch.inverse(c12l0))[:, 0].view(B, 1, 1, 4, 4)
+        l02l1 = c02l0.matmul(small_inverse(c12l0))[:, 0].view(B, 1, 1, 4, 4)
         l02l1 = l02l1[:, :, :, [True, True, False, True], :][:, :, :, :, [True, True, False, True]]
         vt = self.img_view_transformer
-        feat2bev = torch.zeros((3, 3), dtype=grid.dtype, device=grid.device)
-        feat2bev[0, 0], feat2bev[1, 1] = vt.grid_interval[0], vt.grid_interval[1]
-        feat2bev[0, 2], feat2bev[1, 2] = vt.grid_lower_bound[0], vt.grid_lower_bound[1]
-        feat2bev[2, 2] = 1
-        feat2bev = feat2bev.view(1, 3, 3)
-        tf = torch.inverse(feat2bev).matmul(l02l1).matmul(feat2bev)
+        key = (str(grid.device), grid.dtype, W, H, tuple(vt.grid_interval.tolist()), tuple(vt.grid_lower_bound.tolist()))
+        if getattr(self, '_f2b_key', None) != key:   # constants of the module: built (host -> device) once, not per step
+            feat2bev = torch.zeros((3, 3), dtype=grid.dtype)
+            feat2bev[0, 0], feat2bev[1, 1] = vt.grid_interval[0], vt.grid_interval[1]
+            feat2bev[0, 2], feat2bev[1, 2] = vt.grid_lower_bound[0], vt.grid_lower_bound[1]
+            feat2bev[2, 2] = 1
+            self._f2b = (feat2bev.view(1, 3, 3).to(grid.device), torch.inverse(feat2bev).view(1, 3, 3).to(grid.device),
+                         torch.tensor([W - 1.0, H - 1.0], dtype=inp.dtype).to(inp.device))
+            self._f2b_key = key
+        feat2bev, feat2bev_inv, norm = self._f2b
+        tf = feat2bev_inv.matmul(l02l1).matmul(feat2bev)
         grid = tf.matmul(grid)
-        norm = torch.tensor([W - 1.0, H - 1.0], dtype=inp.dtype, device=inp.device)
         return grid[:, :, :, :2, 0] / norm.view(1, 1, 1, 2) * 2.0 - 1.0
 
     def shift_feature(self, inp, sensor2keyegos, bda, bda_adj=None):
@@ -645,8 +666,11 @@ class DHD_stereo(DHD):
             return None, None, None, None, self.extract_stereo_ref_feat(img)
         x, stereo_feat = self.image_encoder(img, stereo=True)
         vt = self.img_view_transformer
+        cvf = getattr(self, '_cv_frustum_dev', None)   # device copy of the stereo frustum template, made once
+        if cvf is None or cvf.device != x.device or cvf.dtype != x.dtype:
+            cvf = self._cv_frustum_dev = vt.cv_frustum.to(x)
         metas = dict(k2s_sensor=k2s_sensor, intrins=intrin, post_rots=post_rot, post_trans=post_tran,
-                     frustum=vt.cv_frustum.to(x), cv_downsample=4, downsample=vt.downsample, grid_config=vt.grid_config,
+                     frustum=cvf, cv_downsample=4, downsample=vt.downsample, grid_config=vt.grid_config,
                      cv_feat_list=[feat_prev_iv, stereo_feat])
         bev_2d, bev_3d, depth, height = vt([x, sensor2keyego, ego2global, intrin, post_rot, post_tran, bda, mlp_input], metas)
         if self.pre_process and bev_3d.dim() == 5:

@@ -6,7 +6,7 @@ import torch
 import bench
 from dhd_amd.graph import GraphedStep
 dev = torch.device('cuda:0')
-job = bench.EndToEnd(dev, int(os.environ.get('B', 2)), 1000, 1, os.environ.get('AMP', 'fp16'), 'dhd-s', True, graph=True)
+job = bench.EndToEnd(dev, int(os.environ.get('B', 2)), 1000, 1, os.environ.get('AMP', 'fp16'), os.environ.get('MODEL', 'dhd-s'), True, graph=True)
 for _ in range(3):
     job._eager_step()
 torch.cuda.synchronize()
