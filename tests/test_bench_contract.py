@@ -1,0 +1,44 @@
+"""The driver's contract with bench.py (one JSON line, named fields), checked on the GPU with a short run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
+                          '--no-e2e', '--cpu-samples', '1'], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['unit'] == 'samples/s' and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 4 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']
+    for name in ('roofline', 'roofline_bwd', 'roofline_operator', 'roofline_sfa_stage'):
+        r = d[name]
+        assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+        assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.02 < r['frac'] < 1.0, (name, r['frac'])
+        assert r['traffic'] is None or r['traffic'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['unit'] == 'samples/s' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
+    assert d['value'] > 50 * c['value']            # sanity: the GPU path is not the CPU twin
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_ranks_than_gpus(gpu):
+    import torch
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')})
+    assert out.returncode != 0 and 'GPU(s) are visible' in (out.stderr + out.stdout)
