@@ -196,6 +196,117 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_fast_kernel(int c, int
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sub-wave forms for C = 4 L, L a power of two (C = 64: L = 16).  The operator is a gather over many short intervals
+// (DHD-S, B = 4: 81 k voxels of 7.8 points on average; 17 k pixels of 37 points): a whole wave per interval leaves the
+// kernel at the latency of its dependent chain index -> depth -> row -> store with ~10 rounds of resident waves.  Here L
+// lanes serve one interval (a lane = four channels, 16-byte accesses, a 4 C-byte row = one contiguous piece per group)
+// and a wave carries 64 / L intervals side by side: 4x fewer waves, 4x more gathers in flight per wave.
+// ---------------------------------------------------------------------------------------------------------------
+using pf4 = __attribute__((ext_vector_type(4))) float;
+
+template <int L>
+__global__ __launch_bounds__(kBlock) void bev_pool_v2_fwd_vec_kernel(int n_intervals, const float* __restrict__ depth,
+                                                                      const pf4* __restrict__ feat, const int* __restrict__ ranks_depth,
+                                                                      const int* __restrict__ ranks_feat,
+                                                                      const int* __restrict__ ranks_bev,
+                                                                      const int* __restrict__ interval_starts,
+                                                                      const int* __restrict__ interval_lengths, pf4* __restrict__ out) {
+  constexpr int G = DHD_WAVE / L;
+  const int lane = threadIdx.x & 63, grp = lane / L, cl = lane % L;
+  const int iv = (blockIdx.x * kWaves + (threadIdx.x >> 6)) * G + grp;
+  const bool valid = iv < n_intervals;
+  const int start = valid ? interval_starts[iv] : 0;
+  const int len = valid ? interval_lengths[iv] : 0;
+  const int vox = valid ? ranks_bev[start] : 0;     // requested with the first indices, not after the gathers
+  pf4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; __any(s0 < len); s0 += L) {
+    const int cnt = min(L, len - s0);              // group-uniform, <= 0 when this group is done
+    int rf = 0;
+    float dv = 0.f;
+    if (cl < cnt) {
+      rf = ranks_feat[start + s0 + cl];
+      dv = depth[ranks_depth[start + s0 + cl]];
+    }
+    constexpr int U = L < 8 ? L : 8;
+#pragma unroll
+    for (int k0 = 0; k0 < L; k0 += U) {
+      pf4 f[U];
+      float d[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u;
+        const int q = __shfl(rf, grp * L + k, DHD_WAVE);
+        d[u] = __shfl(dv, grp * L + k, DHD_WAVE);   // 0 beyond cnt
+        f[u] = k < cnt ? feat[(size_t)q * L + cl] : acc * 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += f[u] * d[u];
+    }
+  }
+  if (valid) out[(size_t)vox * L + cl] = acc;
+}
+
+template <int L>
+__global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_vec_kernel(int n_intervals, const pf4* __restrict__ out_grad,
+                                                                      const float* __restrict__ depth, const pf4* __restrict__ feat,
+                                                                      const int* __restrict__ ranks_depth,
+                                                                      const int* __restrict__ ranks_feat,
+                                                                      const int* __restrict__ ranks_bev,
+                                                                      const int* __restrict__ interval_starts,
+                                                                      const int* __restrict__ interval_lengths,
+                                                                      float* __restrict__ depth_grad, pf4* __restrict__ feat_grad) {
+  constexpr int G = DHD_WAVE / L;
+  const int lane = threadIdx.x & 63, grp = lane / L, cl = lane % L;
+  const int iv = (blockIdx.x * kWaves + (threadIdx.x >> 6)) * G + grp;
+  const bool valid = iv < n_intervals;
+  const int start = valid ? interval_starts[iv] : 0;
+  const int len = valid ? interval_lengths[iv] : 0;
+  const int pix = valid ? ranks_feat[start] : 0;   // every point of the interval shares the pixel (bev_pool.py:47-57)
+  const pf4 fv = valid ? feat[(size_t)pix * L + cl] : pf4{0.f, 0.f, 0.f, 0.f};
+  pf4 facc = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; __any(s0 < len); s0 += L) {
+    const int cnt = min(L, len - s0);
+    int rb = 0, rd = 0;
+    float dv = 0.f;
+    if (cl < cnt) {
+      rb = ranks_bev[start + s0 + cl];
+      rd = ranks_depth[start + s0 + cl];
+      dv = depth[rd];
+    }
+    float mine = 0.f;
+    constexpr int U = L < 8 ? L : 8;
+#pragma unroll
+    for (int k0 = 0; k0 < L; k0 += U) {
+      pf4 g[U];
+      float d[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u;
+        const int vox = __shfl(rb, grp * L + k, DHD_WAVE);
+        d[u] = __shfl(dv, grp * L + k, DHD_WAVE);
+        g[u] = k < cnt ? out_grad[(size_t)vox * L + cl] : facc * 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        facc += g[u] * d[u];
+        float part = (g[u].x * fv.x + g[u].y * fv.y) + (g[u].z * fv.z + g[u].w * fv.w);
+#pragma unroll
+        for (int m = 1; m < L; m <<= 1) part += __shfl_xor(part, m, DHD_WAVE);   // sum over the group's L lanes
+        if (cl == k0 + u) mine = part;
+      }
+    }
+    if (cl < cnt) depth_grad[rd] = mine;             // one writer per point (:104-106)
+  }
+  if (valid) feat_grad[(size_t)pix * L + cl] = facc;  // one writer per pixel (:120-121)
+}
+
+inline int vec_lanes(int c) {  // L = C / 4 when that is a power of two <= 64 and every row is 16-byte aligned, else 0
+  if (c % 4 != 0) return 0;
+  const int l = c / 4;
+  return (l >= 1 && l <= 64 && (l & (l - 1)) == 0) ? l : 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -207,8 +318,24 @@ int dhd_bev_pool_v2_forward(const float* depth, const float* feat, float* out, c
   if (n_intervals == 0) return DHD_OK;
   if (!depth || !feat || !out || !ranks_depth || !ranks_feat || !ranks_bev || !interval_lengths || !interval_starts)
     return DHD_EINVAL;
-  hipLaunchKernelGGL(bev_pool_v2_fwd_kernel, dim3(dhd_cdiv(n_intervals, kWaves)), dim3(kBlock), 0, dhd_stream(stream), c,
-                     n_intervals, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, out);
+  const int lv = (((uintptr_t)feat | (uintptr_t)out) & 15) == 0 ? vec_lanes(c) : 0;
+#define DHD_FWD_VEC(LL)                                                                                                       \
+  hipLaunchKernelGGL(bev_pool_v2_fwd_vec_kernel<LL>, dim3(dhd_cdiv(n_intervals, kWaves * (DHD_WAVE / LL))), dim3(kBlock), 0, \
+                     dhd_stream(stream), n_intervals, depth, reinterpret_cast<const pf4*>(feat), ranks_depth, ranks_feat,    \
+                     ranks_bev, interval_starts, interval_lengths, reinterpret_cast<pf4*>(out))
+  switch (lv) {
+    case 1: DHD_FWD_VEC(1); break;
+    case 2: DHD_FWD_VEC(2); break;
+    case 4: DHD_FWD_VEC(4); break;
+    case 8: DHD_FWD_VEC(8); break;
+    case 16: DHD_FWD_VEC(16); break;
+    case 32: DHD_FWD_VEC(32); break;
+    case 64: DHD_FWD_VEC(64); break;
+    default:
+      hipLaunchKernelGGL(bev_pool_v2_fwd_kernel, dim3(dhd_cdiv(n_intervals, kWaves)), dim3(kBlock), 0, dhd_stream(stream), c,
+                         n_intervals, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, out);
+  }
+#undef DHD_FWD_VEC
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
@@ -226,9 +353,26 @@ int dhd_bev_pool_v2_backward(const float* out_grad, float* depth_grad, float* fe
 #define DHD_BWD(KERN)                                                                                                    \
   hipLaunchKernelGGL(KERN, grid, dim3(kBlock), 0, dhd_stream(stream), c, n_intervals_bp, out_grad, depth, feat, ranks_depth, \
                      ranks_feat, ranks_bev, interval_starts_bp, interval_lengths_bp, depth_grad, feat_grad)
-  if (c <= 64) DHD_BWD(bev_pool_v2_bwd_fast_kernel<1>);
-  else if (c <= 128) DHD_BWD(bev_pool_v2_bwd_fast_kernel<2>);
-  else DHD_BWD(bev_pool_v2_bwd_kernel);
+  const int lv = (((uintptr_t)feat | (uintptr_t)out_grad | (uintptr_t)feat_grad) & 15) == 0 ? vec_lanes(c) : 0;
+#define DHD_BWD_VEC(LL)                                                                                                       \
+  hipLaunchKernelGGL(bev_pool_v2_bwd_vec_kernel<LL>, dim3(dhd_cdiv(n_intervals_bp, kWaves * (DHD_WAVE / LL))), dim3(kBlock), 0, \
+                     dhd_stream(stream), n_intervals_bp, reinterpret_cast<const pf4*>(out_grad), depth,                          \
+                     reinterpret_cast<const pf4*>(feat), ranks_depth, ranks_feat, ranks_bev, interval_starts_bp,                 \
+                     interval_lengths_bp, depth_grad, reinterpret_cast<pf4*>(feat_grad))
+  switch (lv) {
+    case 1: DHD_BWD_VEC(1); break;
+    case 2: DHD_BWD_VEC(2); break;
+    case 4: DHD_BWD_VEC(4); break;
+    case 8: DHD_BWD_VEC(8); break;
+    case 16: DHD_BWD_VEC(16); break;
+    case 32: DHD_BWD_VEC(32); break;
+    case 64: DHD_BWD_VEC(64); break;
+    default:
+      if (c <= 64) DHD_BWD(bev_pool_v2_bwd_fast_kernel<1>);
+      else if (c <= 128) DHD_BWD(bev_pool_v2_bwd_fast_kernel<2>);
+      else DHD_BWD(bev_pool_v2_bwd_kernel);
+  }
+#undef DHD_BWD_VEC
 #undef DHD_BWD
   DHD_LAUNCH_CHECK();
   return DHD_OK;
