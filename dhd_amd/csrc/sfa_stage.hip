@@ -1852,7 +1852,11 @@ inline int device_index() {
 //      product.  DEFAULT: measured against float64 at (2,512,200,200) the stage output is off by 2.2e-5 (bf16x6:
 //      1.2e-6, plain PyTorch fp32: 1.35e-6), well inside the 1e-3 bar of the path; the four forward / dgrad GEMMs
 //      take 118-131 us instead of 160-178 us at B = 4.  Modes 1 / 2 keep float32-level accuracy.
-int g_gemm_mode = 3;
+int g_gemm_mode = [] {  // default 3; the environment variable DHD_SFA_GEMM_MODE=0..4 overrides it at load time
+  const char* e = getenv("DHD_SFA_GEMM_MODE");
+  const int m = e ? atoi(e) : 3;
+  return (e && m >= 0 && m <= 4) ? m : 3;
+}();
 inline bool mode_streamed() { return g_gemm_mode == 2 || g_gemm_mode == 4; }
 inline bool mode_resident() { return g_gemm_mode == 1 || g_gemm_mode == 3; }
 inline int mode_terms() { return g_gemm_mode == 3 ? 2 : 3; }

@@ -283,7 +283,8 @@ int dhd_sfa_stage_supported(int c, int hw);
  *     with less than two rounds of tiles the tiles past the full round go to a second launch of 128-channel
  *     workgroups; 4: the same without that second launch.  Modes 1, 2 and 4 give bit-identical results;
  *   0 f32 MFMA (v_mfma_f32_32x32x2_f32), a plain float32 fma chain.
- * The weight-gradient GEMMs follow the same precision (bf16x3 in mode 3, bf16x6 in 1 / 2 / 4). */
+ * The weight-gradient GEMMs follow the same precision (bf16x3 in mode 3, bf16x6 in 1 / 2 / 4).
+ * The environment variable DHD_SFA_GEMM_MODE selects the initial mode when the library is loaded. */
 int dhd_sfa_set_gemm_mode(int mode);
 /* `saved` carries forward state to backward (a1, BatchNorm batch statistics, y1, y2);
  * `scratch` is reusable between calls on one stream.  0 if the shape is unsupported. */
