@@ -35,7 +35,6 @@ constexpr int kStreamWaves = kStreamBlock / DHD_WAVE;
 #define DHD_TABLE_FLOATS 8192
 #endif
 constexpr int kTableFloats = DHD_TABLE_FLOATS;  // LDS patch table: 128 voxels x 64 channels, or more voxels x fewer channels per pass
-constexpr int kGatherUnroll = 16;   // gradient rows in flight per wave (backward)
 
 #ifdef DHD_ABLATION
 // Experiment-only build (make ablate): phases can be switched off to price them.  Never in libdhd_amd.so.
@@ -342,10 +341,25 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
 //   feat_grad[q,:]    = sum over the pixel's entries of g * depth[p]         (register accumulation)
 // Every output element has exactly one writer: no atomics, no memset, deterministic.
 // ---------------------------------------------------------------------------------------
+// sum over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1): every lane of the row ends up with the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+  return v;
+}
+
+// Round 2 form: a table row (64 channels = 256 bytes) is read by 16 lanes x 16 bytes, so one load instruction gathers the
+// rows of FOUR candidates (lane = (candidate slot e = lane / 16, channel quad cq = lane % 16)), 32 rows in flight per wave
+// instead of 16, a quarter of the load instructions; <g, f> is a 16-lane DPP row sum.  Candidate i = 4 u + e of a batch
+// of 64 is handled in round u by slot e; lane (e, cq == u) keeps its point's total, so that the depth gradients of a
+// batch leave in one store instruction as before.
 __global__ __launch_bounds__(kBlock) void mghs_pixel_bwd(Layout L, const float* __restrict__ depth,
                                                           const float* __restrict__ feat, float* __restrict__ depth_grad,
                                                           float* __restrict__ feat_grad) {
   const int lane = threadIdx.x & 63;
+  const int es = lane >> 4, cq = lane & 15;
   // Workgroups go round-robin over the 8 XCDs: XCD x takes the x-th eighth of the pixels, so that the pixels
   // that share voxels (neighbours in the image, the same camera) gather their rows through one L2.
   const int per_xcd = gridDim.x >> 3;
@@ -354,11 +368,12 @@ __global__ __launch_bounds__(kBlock) void mghs_pixel_bwd(Layout L, const float* 
   if (q >= L.B * L.N * L.hw) return;
   const int bn = q / L.hw, pl = q % L.hw;
   const int p0 = bn * L.dhw + pl;  // point id of depth bin 0; bin d is p0 + d*hw
-  const float f = feat[(size_t)q * kTileC + lane];
-  const float* gc = L.vsum + lane;
-  float fg = 0.f;
-  // 2*D (depth bin, grid class) candidates, 64 at a time: lane e handles bin e/2, class e&1
+  const vfloat4 f = reinterpret_cast<const vfloat4*>(feat)[(size_t)q * (kTileC / 4) + cq];
+  const vfloat4* gc = reinterpret_cast<const vfloat4*>(L.vsum) + cq;
+  vfloat4 fg = {0.f, 0.f, 0.f, 0.f};
+  // 2*D (depth bin, grid class) candidates, 64 at a time: lane c loads the slot / depth of candidate e0 + c = (bin, class)
   const int n_cand = 2 * L.D;
+  constexpr int kRounds = DHD_WAVE / 4, kU = 8;   // 16 rounds of 4 candidates, 8 rounds (32 rows) in flight
   for (int e0 = 0; e0 < n_cand; e0 += DHD_WAVE) {
     const int nb = min(DHD_WAVE, n_cand - e0);
     int slot = -1;
@@ -369,48 +384,41 @@ __global__ __launch_bounds__(kBlock) void mghs_pixel_bwd(Layout L, const float* 
       slot = L.p_slot[(e & 1) * L.P + pid];
       dv = depth[pid];
     }
-    // v[i] = g_i[lane] * f[lane] for the 64 candidates of this batch (0 for dead ones); <g_i, f> for all of
-    // them at once by a transposing butterfly: at distance d the lanes with bit d set keep the upper half
-    // of their values and hand the lower half to their partner (and vice versa), so the number of values
-    // per lane halves at every stage: 32 + 16 + ... + 1 = 63 exchanges for 64 dot products, against seven
-    // DPP steps per dot product for separate wave reductions.  Lane i ends up with candidate i's total.
-    const unsigned long long live = __ballot(slot >= 0);
-    float v[DHD_WAVE];
+    float mine = 0.f;
 #pragma unroll
-    for (int i0 = 0; i0 < DHD_WAVE; i0 += kGatherUnroll) {
-      float g[kGatherUnroll];
-      if (i0 < nb) {  // wave-uniform
+    for (int u0 = 0; u0 < kRounds; u0 += kU) {
+      if (4 * u0 >= nb) break;  // wave-uniform
+      vfloat4 g[kU];
+      float d[kU];
 #pragma unroll
-        for (int j = 0; j < kGatherUnroll; ++j) {
-          const int i = i0 + j;
-          g[j] = ((live >> i) & 1ull) ? gc[(size_t)lane_i(slot, i) * kTileC] : 0.f;
-        }
+      for (int j = 0; j < kU; ++j) {
+        const int i = 4 * (u0 + j) + es;          // this slot's candidate in round u0 + j
+        const int sl = __shfl(slot, i, DHD_WAVE);
+        d[j] = __shfl(dv, i, DHD_WAVE);
+        g[j] = sl >= 0 ? gc[(size_t)sl * (kTileC / 4)] : fg * 0.f;   // dead candidates: g = 0
+      }
 #pragma unroll
-        for (int j = 0; j < kGatherUnroll; ++j) {
-          fg = fmaf(g[j], lane_f(dv, i0 + j), fg);  // dead candidates: g = 0
-          v[i0 + j] = g[j] * f;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < kGatherUnroll; ++j) v[i0 + j] = 0.f;
+      for (int j = 0; j < kU; ++j) {
+        fg += g[j] * d[j];
+        const float part = row16_sum((g[j].x * f.x + g[j].y * f.y) + (g[j].z * f.z + g[j].w * f.w));
+        // the two classes of a point are candidates 2 m, 2 m + 1 = slots (0, 1) or (2, 3) of one round
+        const float both = part + __shfl_xor(part, 16, DHD_WAVE);
+        if (cq == u0 + j) mine = both;
       }
     }
-#pragma unroll
-    for (int d = DHD_WAVE / 2; d >= 1; d >>= 1) {
-      const bool upper = (lane & d) != 0;
-#pragma unroll
-      for (int k = 0; k < d; ++k) {
-        const float keep = upper ? v[k + d] : v[k];
-        const float give = upper ? v[k] : v[k + d];
-        v[k] = keep + __shfl_xor(give, d, DHD_WAVE);
-      }
-    }
-    const float mine = v[0];  // <g, f> of the candidate this lane loaded
-    // the two classes of a point sit in adjacent lanes: add them and let the even lane write
-    const float other = __shfl_xor(mine, 1, DHD_WAVE);
-    if (lane < nb && !(lane & 1)) depth_grad[p0 + ((e0 + lane) >> 1) * L.hw] = mine + other;
+    // lane (es, cq) holds the total of candidate 4 cq + es; even slots write their point
+    const int cand = 4 * cq + es;
+    if (!(es & 1) && cand < nb) depth_grad[p0 + ((e0 + cand) >> 1) * L.hw] = mine;
   }
-  feat_grad[(size_t)q * kTileC + lane] = fg;
+  // feature gradient: sum of the four slots' accumulators
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float v = fg[c];
+    v += __shfl_xor(v, 16, DHD_WAVE);
+    v += __shfl_xor(v, 32, DHD_WAVE);
+    fg[c] = v;
+  }
+  if (es == 0) reinterpret_cast<vfloat4*>(feat_grad)[(size_t)q * (kTileC / 4) + cq] = fg;
 }
 
 // depth_grad = part(grid 0) + part(band grid)
