@@ -90,6 +90,10 @@ __device__ __forceinline__ int channels_per_pass(int nnz) {
 // accumulated before the first owned voxel goes to a scratch row, and a terminator bit makes the
 // run end on the scratch row as well, so nothing outside the owned voxels reaches a real slot.
 // ---------------------------------------------------------------------------------------
+// (Round 2, tried and reverted: 16 lanes x 16 bytes per feature row = four entries per load instruction with one partial
+// sum per entry slot, as mghs_pixel_bwd now does.  Every voxel boundary then needs a cross-slot reduction (8 lane
+// exchanges) where this form needs none, and voxels are short (8-17 entries): DHD-S 0.394 -> 0.440 ms per step, DHD-L
+// geometry 1.09 -> 1.28 ms.)
 template <int J>
 struct GatherStep {
   static __device__ __forceinline__ void load(float (&f)[DHD_WAVE], __amdgpu_buffer_rsrc_t feat_rsrc, int lane4, int pix,
