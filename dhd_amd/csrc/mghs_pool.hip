@@ -298,34 +298,43 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
   // voxel is never needed: a lane reads its 16 bytes only if one of its four voxels does.  The loads stay
   // unconditional instructions (lanes without work re-read one resident dummy line), so that the four of a channel
   // run are in flight together instead of each waiting behind a branch.
-  constexpr int kIter = kSegMaxVox / 4 / DHD_WAVE;  // float4 groups per lane and channel run
-  uint2 sl[kIter];
+  // As in the forward writer the cp channel runs of a pass form one flat (run, vector) index space (a wave per 200-vector
+  // run issued 4 loads of which the last served 8 lanes: 32 load instructions per wave for 25 loads' worth); five
+  // consecutive positions of a wave are requested together.
+  constexpr int kStride = kStreamWaves * DHD_WAVE, kBatch = 5;
+  const int q_step = kStride / nvec, r_step = kStride % nvec;
+  const float* gbase = og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)sg.y0 * sg.nx;
   __syncthreads();  // slot_of complete
-#pragma unroll
-  for (int k = 0; k < kIter; ++k) {
-    const int i = lane + k * DHD_WAVE;
-    sl[k] = make_uint2(0u, 0u);
-    if (i < nvec) sl[k] = *reinterpret_cast<const uint2*>(slot_of + 4 * i);
-  }
   for (int c_lo = 0; c_lo < kTileC; c_lo += cp) {
     __syncthreads();
-    for (int cc = wv; cc < cp; cc += kStreamWaves) {
-      const vfloat4* src = reinterpret_cast<const vfloat4*>(
-          og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)(c_lo + cc) * sc + (size_t)sg.y0 * sg.nx);
-      vfloat4 v[kIter];
+    const int total = cp * nvec;
+    int idx = wv * DHD_WAVE + lane;
+    int cc = idx / nvec, i = idx % nvec;
+    for (; idx - lane < total; ) {                 // wave-uniform condition
+      uint2 sl[kBatch];
+      vfloat4 v[kBatch];
+      int ccs[kBatch];
 #pragma unroll
-      for (int k = 0; k < kIter; ++k) {
-        const vfloat4* p = (sl[k].x | sl[k].y) ? src + lane + k * DHD_WAVE : reinterpret_cast<const vfloat4*>(L.vsum);
+      for (int k = 0; k < kBatch; ++k) {
+        const bool in = idx < total;
+        sl[k] = in ? *reinterpret_cast<const uint2*>(slot_of + 4 * i) : make_uint2(0u, 0u);
+        ccs[k] = cc;
+        const vfloat4* p = (sl[k].x | sl[k].y) ? reinterpret_cast<const vfloat4*>(gbase + (size_t)(c_lo + cc) * sc) + i
+                                               : reinterpret_cast<const vfloat4*>(L.vsum);
         v[k] = __builtin_nontemporal_load(p);
+        idx += kStride;
+        cc += q_step;
+        i += r_step;
+        if (i >= nvec) { i -= nvec; ++cc; }
       }
 #pragma unroll
-      for (int k = 0; k < kIter; ++k) {
+      for (int k = 0; k < kBatch; ++k) {
         if (sl[k].x | sl[k].y) {
           const unsigned s0 = sl[k].x & 0xffffu, s1 = sl[k].x >> 16, s2 = sl[k].y & 0xffffu, s3 = sl[k].y >> 16;
-          if (s0) table[(s0 - 1) * cp + cc] = v[k].x;
-          if (s1) table[(s1 - 1) * cp + cc] = v[k].y;
-          if (s2) table[(s2 - 1) * cp + cc] = v[k].z;
-          if (s3) table[(s3 - 1) * cp + cc] = v[k].w;
+          if (s0) table[(s0 - 1) * cp + ccs[k]] = v[k].x;
+          if (s1) table[(s1 - 1) * cp + ccs[k]] = v[k].y;
+          if (s2) table[(s2 - 1) * cp + ccs[k]] = v[k].z;
+          if (s3) table[(s3 - 1) * cp + ccs[k]] = v[k].w;
         }
       }
     }
