@@ -1001,6 +1001,10 @@ __global__ __launch_bounds__(kEwBlock) void pack_weight_res_kernel(const float* 
 }
 
 constexpr int kResTrPitch = 36;
+#ifndef RES_X5
+#define RES_X5 0  // experiment: with two weight parts keep three activation parts (five products, drops only ah*bl).
+                  // Measured: stage output error 2.2e-5 -> 8.6e-6, GEMMs 96-112 -> 125-139 us (stage 1.35 -> 1.56 ms): not taken
+#endif
 
 #ifndef RESABL
 #define RESABL 0  // timing experiments only (results wrong when non-zero): 1 no stores, 2 every tile reads the pixels of tile 0 (L2-resident), 4 no MFMA
@@ -1083,7 +1087,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
   auto step = [&](auto cset, auto first_tag, const Tile& cur, int kc, const Tile& pf, int kpf) {
     constexpr int CS = decltype(cset)::value;
     constexpr bool FIRST = decltype(first_tag)::value;   // first step of a tile: the accumulators start from zero
-    u32x4 at[NT];
+    constexpr int NTA = (NT == 2 && RES_X5) ? 3 : NT;   // parts of the activation operand
+    u32x4 at[NTA];
     {
       const int ci = 16 * kc + 8 * h;
       const float* cb = cf + (size_t)cur.b * 3 * c + ci;
@@ -1123,9 +1128,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
         unsigned hh, mm, ll;
-        if (NT == 3) {
+        if (NTA == 3) {
           split2(v[2 * jp], v[2 * jp + 1], hh, mm, ll);
-          at[NT - 1][jp] = ll;
+          at[NTA - 1][jp] = ll;
         } else {
           split2_hm(v[2 * jp], v[2 * jp + 1], hh, mm);
         }
@@ -1152,12 +1157,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
 #pragma unroll
         for (int m = 0; m < NT; ++m) bf[u][m] = img[((t0 + u) * NT + m) * 64];
       // product order (smallest first): NT = 3: l*h, h*l, m*m, m*h, h*m, h*h;  NT = 2: m*h, h*m, h*h
-      constexpr int kProd = NT == 3 ? 6 : 3;
+      //                               "x5" (three activation parts, two weight parts): l*h, m*m, m*h, h*m, h*h
+      constexpr int kProd = NT == 3 ? 6 : (NTA == 3 ? 5 : 3);
       constexpr int pa3[6] = {2, 0, 1, 1, 0, 0}, pb3[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int pa5[5] = {2, 1, 1, 0, 0}, pb5[5] = {0, 1, 0, 1, 0};
       constexpr int pa2[3] = {1, 0, 0}, pb2[3] = {0, 1, 0};
 #pragma unroll
       for (int q = 0; q < kProd; ++q) {
-        const int ia = NT == 3 ? pa3[q] : pa2[q], ib = NT == 3 ? pb3[q] : pb2[q];
+        const int ia = NT == 3 ? pa3[q] : (NTA == 3 ? pa5[q] : pa2[q]), ib = NT == 3 ? pb3[q] : (NTA == 3 ? pb5[q] : pb2[q]);
 #pragma unroll
         for (int u = 0; u < TP; ++u)
           if (!(RESABL & 4) || q == 0) acc[t0 + u] = mfma_bf16(at[ia], bf[u][ib], (FIRST && q == 0) ? zero : acc[t0 + u]);
