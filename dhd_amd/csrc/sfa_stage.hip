@@ -1436,9 +1436,15 @@ __global__ __launch_bounds__(kWgBlock, 2) void pw_wgrad6_kernel(const float* __r
   const long n_steps = (long)nb * sps;
   const int s0 = (int)(n_steps * blockIdx.x / n_workers), s1 = (int)(n_steps * (blockIdx.x + 1) / n_workers);
 
-  // this thread's items: (operand, row, half)
-  const int it_row = OT == 256 ? (tid >> 1) : ((tid & 255) >> 1);
-  const int it_h = tid & 1;
+  // this thread's items: (operand, row, half).  OT = 256 (round 2): line-coalesced loads as in pw_wgrad3_kernel -- load
+  // instruction j reads rows 128 j + 16 wv + (lane >> 2), four pixels 4 (lane & 3): 4 adjacent lanes = the row's 64 bytes of
+  // this step, 16 rows per instruction -- and the 8-pixel item of row 128 (lane & 1) + 16 wv + (lane >> 2), half
+  // (lane & 3) >> 1 is assembled with a lane-pair exchange.  The items and their arithmetic are the same as before
+  // (bit-identical results); OT = 128 keeps one thread = 32 contiguous bytes.
+  constexpr bool kCoal = OT == 256;
+  const int ld_row = 16 * wv + (lane >> 2), ld_px = 4 * (lane & 3), odd = lane & 1;
+  const int it_row = kCoal ? 128 * odd + ld_row : ((tid & 255) >> 1);
+  const int it_h = kCoal ? ((lane & 3) >> 1) : (tid & 1);
   const bool second_is_b = true;               // OT = 256: item 0 = A, item 1 = B
   const bool single_is_b = tid >= 256;         // OT = 128: waves 0-3 stage A, waves 4-7 stage B (wave-uniform)
   const int it_slot = (it_row >> 5) * 192 + (it_row & 31) + 32 * it_h;  // + term * 64
@@ -1462,7 +1468,25 @@ __global__ __launch_bounds__(kWgBlock, 2) void pw_wgrad6_kernel(const float* __r
     for (int q = 0; q < 3; ++q) { cfa[q] = ca[q * c]; cfb[q] = cb[q * c]; }
     cur_b = b;
   };
+  auto swap1 = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); };
   auto fetch = [&](int s) {
+    if (kCoal) {
+      const int b = s / sps, p = (s % sps) * 16 + ld_px;
+      const size_t off = p < hw ? p : 0;
+#pragma unroll
+      for (int it = 0; it < kItems; ++it) {
+        const float* src0 = it ? b0 : a0;
+        const float* src1 = it ? b1 : a1;
+        const bool two = it ? B_TWO : A_TWO;
+        const size_t base = (size_t)b * (it ? b_bstride : a_bstride) + (size_t)((it ? ob_ci : ob_co) + ld_row) * hw + off;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {   // q = load instruction: rows +0 / +128
+          raw[it][0][q] = *reinterpret_cast<const f32x4*>(src0 + base + (size_t)(128 * q) * hw);
+          if (two) raw[it][1][q] = *reinterpret_cast<const f32x4*>(src1 + base + (size_t)(128 * q) * hw);
+        }
+      }
+      return;
+    }
     const int b = s / sps, p = (s % sps) * 16 + 8 * it_h;
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
@@ -1488,6 +1512,24 @@ __global__ __launch_bounds__(kWgBlock, 2) void pw_wgrad6_kernel(const float* __r
       const bool is_b = OT == 256 ? (it == 1 && second_is_b) : single_is_b;
       const bool two = is_b ? B_TWO : A_TWO;
       const float k0 = is_b ? cfb[0] : cfa[0], k1 = is_b ? cfb[1] : cfa[1], k2 = is_b ? cfb[2] : cfa[2];
+      if (kCoal) {   // assemble [lower 4 pixels | upper 4 pixels] of this thread's row: the even lane keeps its piece of the
+                     // first instruction's row and takes its neighbour's, the odd lane the same for the second instruction's
+#pragma unroll
+        for (int in2 = 0; in2 < 2; ++in2) {
+          if (in2 == 1 && !two) continue;
+          const f32x4 r0 = raw[it][in2][0], r1 = raw[it][in2][1];
+          f32x4 lo, hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float keep = odd ? r1[e] : r0[e];
+            const float recv = swap1(odd ? r0[e] : r1[e]);
+            lo[e] = odd ? recv : keep;
+            hi[e] = odd ? keep : recv;
+          }
+          raw[it][in2][0] = lo;
+          raw[it][in2][1] = hi;
+        }
+      }
       float v[8];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
