@@ -1939,7 +1939,9 @@ inline bool res_supported(int c) {
   const int nt = mode_terms(), cob = res_cob(c, nt);
   if (c == 128) return cob == 4;
   if (c == 256) return nt == 2 ? (cob == 4 || cob == 2) : cob == 2;
-  return nt == 2 ? cob == 2 : cob == 1;
+  // C = 512: bf16x3 with teams of 8 still beats the streamed form (2.85 vs 3.43 ms per stage at B = 3); bf16x6 would need
+  // teams of 16 (4.23 ms) and stays on the streamed kernels (bit-identical results)
+  return nt == 2 && cob == 2;
 }
 
 int cu_count() {
