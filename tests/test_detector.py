@@ -274,7 +274,9 @@ def test_whole_step_hip_graph_replays_the_eager_step(gpu):
     x = torch.randn(1, 2, 16, 4, 11, device=gpu)
 
     def make(model):
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, eps=1e-2, fused=True, capturable=True)   # large eps: no 1/|g| amplification of rounding
+        # plain SGD: parameter differences stay proportional to gradient differences (library convolutions may pick another
+        # algorithm, i.e. another rounding, from one call to the next; Adam's 1/|g| would amplify that)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9)
         mlp = model['vt'].get_mlp_input(*calib)
 
         def step():
