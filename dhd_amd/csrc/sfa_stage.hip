@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -1007,16 +1008,43 @@ constexpr int kResTrPitch = 36;
 #endif
 
 #ifndef RESABL
-#define RESABL 0  // timing experiments only (results wrong when non-zero): 1 no stores, 2 every tile reads the pixels of tile 0 (L2-resident), 4 no MFMA
+#define RESABL 0  // timing experiments only (results wrong when non-zero): 1 no stores, 2 every tile reads the pixels of tile 0 (L2-resident), 4 no MFMA,
+                  // 8 per-wave phase clocks of the one-input kernel into g_res_tl (read back with dhd_debug_res_timeline)
+#endif
+#if RESABL & 8
+__device__ unsigned long long g_res_tl[4 * 256 * 8 * 8];   // [variant][block][wave][wait, prologue, loads+mfma, epilogue, total, steps, tiles, begin]
+#define RES_CLK() __builtin_readcyclecounter()
 #endif
 
-template <int NT, int COB, int KCN, bool TWO_IN, bool RELU, int EPI, int WAVES, int AUX>
+// word with lane L replaced by the wave-uniform value sval (v_writelane_b32: one VALU instruction).  gfx940+ needs two
+// wait states between a VALU write of an SGPR (the v_cmp that made sval) and a VALU read of it; the compiler inserts
+// them for its own instructions but cannot see into inline assembly (without them: stale pass bits, found by the
+// full-size parity test).
+template <int L>
+__device__ __forceinline__ int write_lane(int word, int sval) {
+  asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(sval), "n"(L));
+  return word;
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {   // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), straight-line
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int NT, int COB, int KCN, bool TWO_IN, bool RELU, int EPI, int WAVES, int AUX, int DPF>
 __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
                                                                     size_t in_bstride, unsigned in_bytes, const float* __restrict__ coef,
                                                                     const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                                     unsigned* __restrict__ relu_mask, float* __restrict__ stat_part,
                                                                     float* __restrict__ y, int c, int hw, int nb, int groups, int nteams) {
-  constexpr int D = 4;                 // prefetch distance in 16-channel steps
+  // prefetch distance in 16-channel steps (register sets of 8 loads per input in flight).  Measured with DPF = 8 (one-input
+  // kernel 193 VGPRs, two-input 240-256): 101.6 vs 99.3 us and 105-113 vs 108-113 us -- the loads are not what a wave
+  // waits for (phase clocks, experiments/res_timeline.py: 2 % of a wave's time), see DESIGN.md
+  constexpr int D = DPF;
   constexpr int kThreads = WAVES * 64;
   extern __shared__ u32x4 ldsr[];      // weight fragments (KCN * COB * NT KB) | coefficient tables [nb][3][c]
   static_assert(KCN % D == 0 && KCN >= 2 * D, "K steps: a multiple of the prefetch distance, at least two rounds");
@@ -1076,11 +1104,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
       if (TWO_IN) raw1[S][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(t.r1, t.voff, so + j * row_bytes, AUX));
     }
   };
-  using J0 = std::integral_constant<int, 0>;
-  using J1 = std::integral_constant<int, 1>;
-  using J2 = std::integral_constant<int, 2>;
-  using J3 = std::integral_constant<int, 3>;
-
+#if RESABL & 8
+  unsigned long long tl_wait = 0, tl_pro = 0, tl_mfma = 0, tl_epi = 0, tl_steps = 0, tl_tiles = 0;
+  const unsigned long long tl_begin = RES_CLK();
+#endif
   f32x16 acc[COB];
 
   // one 16-channel step: consume register set CS (loaded for (cur, kc)), refill it for (pf, kpf), then the MFMAs
@@ -1089,6 +1116,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
     constexpr bool FIRST = decltype(first_tag)::value;   // first step of a tile: the accumulators start from zero
     constexpr int NTA = (NT == 2 && RES_X5) ? 3 : NT;   // parts of the activation operand
     u32x4 at[NTA];
+#if RESABL & 8
+    const unsigned long long tl0 = RES_CLK();
+    if (!TWO_IN && D == 4) __builtin_amdgcn_s_waitcnt(0x4F78);   // vmcnt(24): this step's register set has landed
+    const unsigned long long tl1 = RES_CLK();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     {
       const int ci = 16 * kc + 8 * h;
       const float* cb = cf + (size_t)cur.b * 3 * c + ci;
@@ -1115,15 +1148,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
           v[4 * q + e + 1] = RELU ? fmaxf(t.y, 0.f) : t.y;
         }
       }
-      if (RELU && relu_mask != nullptr && g == 0) {  // wave-uniform: one team member records the pass bits
-        unsigned word = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
+      // the pass bits are recorded once per team: its members (same pixels, redundant prologues) take the steps in turn
+      if (RELU && relu_mask != nullptr && (kc % groups) == g) {  // wave-uniform
+        int word = 0;
+        static_for<8>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
           const unsigned long long bal = __ballot(v[j] > 0.f);
-          if (lane == j) word = (unsigned)bal;
-          if (lane == 8 + j) word = (unsigned)(bal >> 32);
-        }
-        if (lane < 16) relu_mask[((size_t)cur.b * nwt + cur.wt) * c + 16 * kc + lane] = word;   // [sample][wave tile][channel]
+          word = write_lane<j>(word, (int)(unsigned)bal);               // lane j: channel 16 kc + j
+          word = write_lane<8 + j>(word, (int)(unsigned)(bal >> 32));   // lane 8 + j: channel 16 kc + 8 + j
+        });
+        if (lane < 16) relu_mask[((size_t)cur.b * nwt + cur.wt) * c + 16 * kc + lane] = (unsigned)word;   // [sample][wave tile][channel]
       }
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
@@ -1142,6 +1176,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
     // four prologues to the top of the loop body -- i.e. consume every register set right after it was requested.
     // Scheduling barriers pin the order  prologue(kc) -> loads(kc + D) -> MFMAs(kc).
     __builtin_amdgcn_sched_barrier(0);
+#if RESABL & 8
+    const unsigned long long tl2 = RES_CLK();
+#endif
     issue(cset, pf, kpf);
     __builtin_amdgcn_sched_barrier(0);
     const u32x4* img = ldsr + kc * (COB * NT * 64) + lane;
@@ -1171,65 +1208,74 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+#if RESABL & 8
+    const unsigned long long tl3 = RES_CLK();
+    tl_wait += tl1 - tl0; tl_pro += tl2 - tl1; tl_mfma += tl3 - tl2; tl_steps += 1;
+#endif
   };
 
-  using T0 = std::integral_constant<bool, true>;
-  using F0 = std::integral_constant<bool, false>;
   int wtg = team * WAVES + wv;
   if (wtg >= total) return;                        // wave-uniform; no barrier follows
+  // epilogue operands are requested long before they are used: a load issued inside the epilogue is waited for at once,
+  // behind the stores of the previous half tiles (measured: 2.4 k clocks per 32-channel tile, a third of the wave's time)
+  float bias_r[COB];                               // this lane's output channels are the same for every tile
+#pragma unroll
+  for (int t = 0; t < COB; ++t) bias_r[t] = EPI == 0 ? bias[g * 32 * COB + 32 * t + r] : 0.f;
   Tile cur = make_tile(wtg);
-  issue(J0{}, cur, 0);
-  issue(J1{}, cur, 1);
-  issue(J2{}, cur, 2);
-  issue(J3{}, cur, 3);
+  static_for<D>([&](auto sc) { issue(sc, cur, decltype(sc)::value); });
   for (; wtg < total; wtg += stride) {
     const Tile nxt = make_tile(wtg + stride);
     // The K loop is fully unrolled (straight-line code per tile): with an inner loop the register allocator
     // copied every prefetch register and every accumulator at the loop header (and a copy of a loaded register
     // waits for its load: no lookahead left).  Steps kc >= KCN - D prefetch the first steps of the next tile.
-    step(J0{}, T0{}, cur, 0, cur, D);
-    step(J1{}, F0{}, cur, 1, cur, D + 1);
-    step(J2{}, F0{}, cur, 2, cur, D + 2);
-    step(J3{}, F0{}, cur, 3, cur, D + 3);
+    int mask_r[COB];                               // EPI 1: the ReLU pass bits of this tile, requested before the K loop
 #pragma unroll
-    for (int kc = D; kc < KCN - D; kc += D) {
-      step(J0{}, F0{}, cur, kc, cur, kc + D);
-      step(J1{}, F0{}, cur, kc + 1, cur, kc + 1 + D);
-      step(J2{}, F0{}, cur, kc + 2, cur, kc + 2 + D);
-      step(J3{}, F0{}, cur, kc + 3, cur, kc + 3 + D);
-    }
-    step(J0{}, F0{}, cur, KCN - D, nxt, 0);
-    step(J1{}, F0{}, cur, KCN - D + 1, nxt, 1);
-    step(J2{}, F0{}, cur, KCN - D + 2, nxt, 2);
-    step(J3{}, F0{}, cur, KCN - D + 3, nxt, 3);
+    for (int t = 0; t < COB; ++t)
+      mask_r[t] = EPI == 1 ? (int)relu_mask[((size_t)cur.b * nwt + cur.wt) * c + g * 32 * COB + 32 * t + r] : 0;
+    static_for<KCN>([&](auto kcc) {
+      constexpr int kc = decltype(kcc)::value;
+      step(std::integral_constant<int, kc % D>{}, std::integral_constant<bool, kc == 0>{}, cur, kc, kc + D < KCN ? cur : nxt,
+           (kc + D) % KCN);
+    });
 
     // acc[t][4q + e] = pixel p0 + 8q + 4h + e, channel g*32*COB + 32t + r.  Stored straight from this layout a
     // store instruction would write 64 separate 16-byte pieces (adjacent lanes = different channel rows): measured 40 us
     // of a 125 us GEMM.  Each half tile (16 channels x 32 pixels) goes through a wave-private LDS patch instead and is
     // written row-wise: 8 adjacent lanes = one whole 128-byte line, 8 lines per store instruction.
+#if RESABL & 8
+    const unsigned long long tl_e0 = RES_CLK();
+#endif
     const int p0 = cur.wt * 32;
     const int co0 = g * 32 * COB + r;
+    const bool full = p0 + 32 <= hw;               // wave-uniform; always true when hw % 32 == 0
+    // stores: one buffer resource per sample, the row of a store as a scalar byte offset, the lane's place inside a
+    // 16-row half tile as a 32-bit vector offset (was: a 64-bit multiply per lane and store)
+    const __amdgpu_buffer_rsrc_t ry =
+        __builtin_amdgcn_make_buffer_rsrc(y + (size_t)cur.b * c * hw, 0, (unsigned)((size_t)c * hw * sizeof(float)), 0x00020000);
+    const int pst = p0 + 4 * (lane & 7);
+    const int vst = ((lane >> 3) * hw + pst) * 4;
+    const bool st_ok = full || pst < hw;
 #pragma unroll
     for (int t = 0; t < COB; ++t) {
       const int co = co0 + 32 * t;
       float bs = 0.f, s1 = 0.f, s2 = 0.f;
-      unsigned word = 0;
-      if (EPI == 0) bs = bias[co];
-      if (EPI == 1) word = relu_mask[((size_t)cur.b * nwt + cur.wt) * c + co] >> (4 * h);
+      int word = 0;
+      if (EPI == 0) bs = bias_r[t];
+      if (EPI == 1) word = (int)((unsigned)mask_r[t] >> (4 * h));
       f32x4 vq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
         if (EPI == 0) {
-          if (p0 + 8 * q + 4 * h < hw) {   // hw % 4 == 0: a 4-pixel group is inside or outside as a whole
+          if (full || p0 + 8 * q + 4 * h < hw) {   // hw % 4 == 0: a 4-pixel group is inside or outside as a whole
             s1 += (v.x + v.y) + (v.z + v.w);
             s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
           }
           v.x += bs; v.y += bs; v.z += bs; v.w += bs;
         }
-        if (EPI == 1) {
+        if (EPI == 1) {   // pass bit -> all-ones / zero with one signed bit-field extract, then AND
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ((word >> (8 * q + e)) & 1u) ? v[e] : 0.f;
+          for (int e = 0; e < 4; ++e) v[e] = __int_as_float(__float_as_int(v[e]) & __builtin_amdgcn_sbfe(word, 8 * q + e, 1));
         }
         vq[q] = v;
       }
@@ -1241,11 +1287,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const int rr = (lane >> 3) + 8 * k, p = p0 + 4 * (lane & 7);
-          const f32x4 w = *reinterpret_cast<const f32x4*>(tr + rr * kTrPitch + 4 * (lane & 7));
-          const size_t row = ((size_t)cur.b * c + g * 32 * COB + 32 * t + 16 * ph + rr) * hw;
+          const f32x4 w = *reinterpret_cast<const f32x4*>(tr + ((lane >> 3) + 8 * k) * kTrPitch + 4 * (lane & 7));
+          const int srow = (g * 32 * COB + 32 * t + 16 * ph + 8 * k) * row_bytes;   // scalar
           if ((RESABL & 1) && w.x != 12345.678f) continue;
-          if (p < hw) *reinterpret_cast<f32x4*>(y + row + p) = w;
+          if (st_ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), ry, vst, srow, 0);
         }
       }
       if (EPI == 0 && stat_part != nullptr) {  // block-uniform
@@ -1259,7 +1304,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
       }
     }
     cur = nxt;
+#if RESABL & 8
+    tl_epi += RES_CLK() - tl_e0; tl_tiles += 1;
+#endif
   }
+#if RESABL & 8
+  if (lane == 0 && blockIdx.x < 256) {   // variant: 0 one-input forward, 1 two-input forward, 2 dgrad with mask, 3 dgrad plain
+    unsigned long long* q = g_res_tl + (((TWO_IN ? 1 + EPI : 0) * 256 + blockIdx.x) * 8 + wv) * 8;
+    q[0] = tl_wait; q[1] = tl_pro; q[2] = tl_mfma; q[3] = tl_epi; q[4] = RES_CLK() - tl_begin; q[5] = tl_steps; q[6] = tl_tiles;
+    q[7] = tl_begin;
+  }
+#endif
 }
 
 // partial rows [n][c2] -> kStatGroups rows: first level of the statistics reduction.  Thread =
@@ -1506,7 +1561,7 @@ __global__ __launch_bounds__(kWgBlock, 2) void pw_wgrad6_kernel(const float* __r
   };
   auto stage = [&](int s, int buf) {
     const int b = s / sps, p = (s % sps) * 16 + 8 * it_h;
-    if (b != cur_b) load_coefs(b);  // block-uniform, at most twice per worker
+    if (b != cur_b) load_coefs(b);  // block-uniform, a few times per worker
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
       const bool is_b = OT == 256 ? (it == 1 && second_is_b) : single_is_b;
@@ -1622,6 +1677,10 @@ __global__ __launch_bounds__(kWgBlock, 2) void pw_wgrad6_kernel(const float* __r
 //     touched per instruction, each line touched by four instructions).  An 8-pixel item is then assembled with one
 //     lane-pair exchange (DPP quad_perm): of the rows loaded by instructions 2a and 2a+1, the even lane keeps its piece
 //     of row 2a and takes its neighbour's, the odd lane does the same for row 2a+1.
+#ifndef WGABL
+#define WGABL 0  // timing experiments only (results wrong when non-zero): 1 loads only for the first step, 2 no MFMA, 4 no prologue / split,
+                 // 8 half the steps, 32 a quarter of the steps, 16 no partial stores
+#endif
 template <int OT, bool A_TWO, bool B_TWO, bool B_RELU>
 __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
                                                                 const float* __restrict__ acoef, size_t a_bstride,
@@ -1642,7 +1701,12 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
   const int wco = (wv >> 2) * (OT / 2), wci = (wv & 3) * (OT / 4);
   const int sps = (hw + 31) >> 5;                // steps per sample
   const long n_steps = (long)nb * sps;
-  const int s0 = (int)(n_steps * blockIdx.x / n_workers), s1 = (int)(n_steps * (blockIdx.x + 1) / n_workers);
+  // worker w takes the contiguous range [n_steps w / n_workers, n_steps (w + 1) / n_workers).  (Tried: steps w, w + n_workers,
+  // ... so that at any moment the workers together read one contiguous span of every channel row: 141 / 130 vs 133 / 128 us.)
+  const int w_id = blockIdx.x;
+  const int first = (int)(n_steps * w_id / n_workers);
+  const int count = ((int)(n_steps * (w_id + 1) / n_workers) - first) >> ((WGABL & 8) ? 1 : 0) >> ((WGABL & 32) ? 2 : 0);
+  auto step_of = [&](int k) { return first + min(k, count - 1); };   // past the end: the last step again
 
   // loads: instruction j reads rows 64 j + 8 wv + (lane >> 3), four pixels 4 (lane & 7) ..
   const int ld_row = 8 * wv + (lane >> 3), ld_px = 4 * (lane & 7);
@@ -1692,7 +1756,7 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
   auto swap1 = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); };
   auto stage = [&](int s, int buf) {
     const int b = s / sps, p = (s % sps) * 32 + 8 * chunk;
-    if (b != cur_b) load_coefs(b);  // block-uniform, at most twice per worker
+    if (b != cur_b) load_coefs(b);  // block-uniform, a few times per worker
     const bool in_lo = p < hw, in_hi = p + 4 < hw;
 #pragma unroll
     for (int op = 0; op < 2; ++op) {
@@ -1701,6 +1765,19 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
       for (int a = 0; a < NA; ++a) {
         const float k0 = op ? cfb[a][0] : cfa[a][0], k1 = op ? cfb[a][1] : cfa[a][1], k2 = op ? cfb[a][2] : cfa[a][2];
         const f32x2 k0v = {k0, k0}, k1v = {k1, k1}, k2v = {k2, k2};
+        if (WGABL & 4) {
+          const int row = 64 * (2 * a + odd) + ld_row;
+          u32x4* dst = ldsw + buf * kBuf + (it_ks * 2 + op) * kOp + (row >> 5) * 128 + (row & 31) + 32 * it_h;
+          u32x4 v0, v1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v0[e] = __float_as_uint(raw[op][0][2 * a][e]) ^ __float_as_uint(two ? raw[op][1][2 * a][e] : k0);
+            v1[e] = __float_as_uint(raw[op][0][2 * a + 1][e]) ^ __float_as_uint(two ? raw[op][1][2 * a + 1][e] : k1);
+          }
+          dst[0] = v0;
+          dst[64] = v1;
+          continue;
+        }
         // assemble the item: [lo 4 pixels | hi 4 pixels] of this thread's row, per input
         float x[2][8];
 #pragma unroll
@@ -1738,18 +1815,18 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
     }
   };
 
-  if (s0 < s1) {
-    fetch(s0);
-    stage(s0, 0);
-    fetch(min(s0 + 1, s1 - 1));
+  if (count > 0) {
+    fetch(step_of(0));
+    stage(step_of(0), 0);
+    fetch(step_of(1));
   }
   __syncthreads();
-  for (int s = s0; s < s1; ++s) {
-    const int buf = (s - s0) & 1;
+  for (int k = 0; k < count; ++k) {
+    const int buf = k & 1;
     // unconditional (indices clamped to the last step, whose re-staged copy nobody reads), see pw_wgrad6_kernel.
     // (tried: operand by operand -- stage A(s+1), request A(s+2), stage B(s+1), request B(s+2): no gain)
-    stage(min(s + 1, s1 - 1), buf ^ 1);
-    fetch(min(s + 2, s1 - 1));
+    stage(step_of(k + 1), buf ^ 1);
+    if (!(WGABL & 1)) fetch(step_of(k + 2));
     // keep the loads of step s + 2 ahead of this step's MFMAs (the scheduler sinks them to the end)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1767,6 +1844,11 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
 #pragma unroll
         for (int t = 0; t < 2; ++t) fa[t] = ta[(((wco >> 5) + i) * 2 + t) * 64];
         // terms: 0 = high, 1 = mid; smallest products first
+        if (WGABL & 2) {
+#pragma unroll
+          for (int j = 0; j < TB; ++j) acc[i][j][0] += __uint_as_float(fa[1][0] ^ fb[j][0][0] ^ fa[0][1] ^ fb[j][1][1]);
+          continue;
+        }
 #pragma unroll
         for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(fa[1], fb[j][0], acc[i][j]);
 #pragma unroll
@@ -1787,6 +1869,7 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
       for (int e = 0; e < 16; ++e) {
         const int co = ob_co + wco + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
         const int ci = ob_ci + wci + 32 * j + r;
+        if ((WGABL & 16) && acc[i][j][e] != 123.456f) continue;
         po[(size_t)co * c + ci] = acc[i][j][e];
       }
 }
@@ -2005,12 +2088,12 @@ int launch_pw_gemm_res(const float* in0, const float* in1, size_t in_bstride, in
 #define DHD_RES(NT, COB, KCN, TWO, RELU, EPI)                                                                            \
   do {                                                                                                                \
     if (res_aux() == 2) {                                                                                             \
-      auto kern = pw_gemm_res_kernel<NT, COB, KCN, TWO, RELU, EPI, kResWaves, 2>;                                     \
+      auto kern = pw_gemm_res_kernel<NT, COB, KCN, TWO, RELU, EPI, kResWaves, 2, 4>;                                  \
       DHD_LDS_ATTR_ONCE(kern, kLdsBytes);                                                                             \
       hipLaunchKernelGGL(kern, grid, dim3(kResWaves * 64), shmem, st, i0, i1, in_bstride, in_bytes, cf,               \
                          reinterpret_cast<const u32x4*>(wp), bias, rm, sp, yo, c, hw, nb, groups, nteams);            \
     } else {                                                                                                          \
-      auto kern = pw_gemm_res_kernel<NT, COB, KCN, TWO, RELU, EPI, kResWaves, 0>;                                     \
+      auto kern = pw_gemm_res_kernel<NT, COB, KCN, TWO, RELU, EPI, kResWaves, 0, 4>;                                  \
       DHD_LDS_ATTR_ONCE(kern, kLdsBytes);                                                                             \
       hipLaunchKernelGGL(kern, grid, dim3(kResWaves * 64), shmem, st, i0, i1, in_bstride, in_bytes, cf,               \
                          reinterpret_cast<const u32x4*>(wp), bias, rm, sp, yo, c, hw, nb, groups, nteams);            \
@@ -2185,6 +2268,12 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
 }  // namespace
 
 extern "C" {
+
+#if RESABL & 8
+int dhd_debug_res_timeline(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_res_tl), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int dhd_sfa_set_gemm_mode(int mode) {
   if (mode < 0 || mode > 4) return DHD_EINVAL;
