@@ -1956,7 +1956,10 @@ ScratchLayout scratch_layout(int b, int c, int hw, int r) {
 // output channels per block = 32 * cot
 inline int pw_cot(int c) { return (DHD_PW_COT_SEL == 8 && c % 256 == 0) ? 8 : 4; }
 
-inline bool stage_supported(int c, int hw) { return (c == 128 || (c > 0 && c % 256 == 0)) && hw > 0 && (hw & 3) == 0; }
+// (one sample of the input, 2 C hw floats, must stay below 4 GiB: the GEMMs address a sample through 32-bit buffer offsets)
+inline bool stage_supported(int c, int hw) {
+  return (c == 128 || (c > 0 && c % 256 == 0)) && hw > 0 && (hw & 3) == 0 && (size_t)2 * c * hw * sizeof(float) <= 0xFFFFFFFFull;
+}
 
 // hipFuncSetAttribute is not a stream operation: doing it on every launch breaks stream capture (HIP graphs),
 // so each kernel instantiation raises its dynamic-LDS limit once per device, on first use.

@@ -239,7 +239,7 @@ int dhd_sfa_mean_backward(const float* gs, float* gx, int b, int c2, int hw, voi
  *    conv1x1 -> BatchNorm -> sigmoid -> blend2, forward and backward, float32.  The two 1x1
  *    convolutions run on the f32 MFMA with the blends / BatchNorm / ReLU fused into their operand
  *    paths (csrc/sfa_stage.hip); only conv outputs y1, y2 are kept for backward.
- *    Supported: C == 128 or C % 256 == 0, hw % 4 == 0 (dhd_sfa_stage_supported); other shapes
+ *    Supported: C == 128 or C % 256 == 0, hw % 4 == 0, 2*C*hw*4 bytes < 4 GiB (dhd_sfa_stage_supported); other shapes
  *    return DHD_EUNSUPPORTED and callers use the section-3 kernels around library convolutions.
  * ------------------------------------------------------------------------------------ */
 

@@ -44,6 +44,8 @@ def test_sfa_stage_shape_support_and_validation():
     assert lib.dhd_sfa_stage_supported(256, 40000) == 1 and lib.dhd_sfa_stage_supported(128, 400) == 1
     assert lib.dhd_sfa_stage_supported(512, 40000) == 1
     assert lib.dhd_sfa_stage_supported(64, 40000) == 0 and lib.dhd_sfa_stage_supported(256, 402) == 0
+    # a sample is addressed through 32-bit buffer offsets: 2*C*hw*4 bytes must stay below 4 GiB
+    assert lib.dhd_sfa_stage_supported(512, 1 << 21) == 0 and lib.dhd_sfa_stage_supported(512, (1 << 20) - 4) == 1
     assert lib.dhd_sfa_stage_saved_bytes(4, 64, 40000, 8) == 0
     saved = lib.dhd_sfa_stage_saved_bytes(4, 256, 40000, 32)
     # y1 + y2 (2 x 164 MB) + one pass bit per activation (5 MB) + small tables
