@@ -48,7 +48,6 @@ constexpr int kPwStep = 16;       // input channels per weight image / pipeline 
 constexpr int kWgBlock = 512;     // pw_wgrad: 8 waves
 constexpr int kWgStride = 33;     // LDS row stride of a 32-pixel operand row (conflict-free column reads)
 constexpr int kWgWorkers = 256;   // total pw_wgrad blocks (one per CU)
-constexpr int kStatGroups = 64;   // rows left by the first level of the statistics reduction
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
@@ -1215,7 +1214,29 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
   };
 
   int wtg = team * WAVES + wv;
-  if (wtg >= total) return;                        // wave-uniform; no barrier follows
+  // BatchNorm statistics of the output (EPI 0): bf16x3 keeps them per lane over all of the wave's tiles and writes ONE row
+  // per wave, stat_part[team * WAVES + wave][2][c] (1024 rows instead of 5000 at B = 4, and no cross-lane exchange or store
+  // per tile); bf16x6 writes a row per (sample, wave tile) like the streamed kernels, whose results it reproduces bit for bit
+  constexpr bool kWaveStats = EPI == 0 && NT == 2;
+  float ws1[COB], ws2[COB];
+#pragma unroll
+  for (int t = 0; t < COB; ++t) ws1[t] = ws2[t] = 0.f;
+  auto flush_stats = [&]() {
+    if (!kWaveStats || stat_part == nullptr) return;
+    float* q = stat_part + ((size_t)(team * WAVES + wv) * 2) * c + g * 32 * COB + r;
+#pragma unroll
+    for (int t = 0; t < COB; ++t) {
+      const float s1 = ws1[t] + __shfl_xor(ws1[t], 32, DHD_WAVE), s2 = ws2[t] + __shfl_xor(ws2[t], 32, DHD_WAVE);
+      if (h == 0) {
+        q[32 * t] = s1;
+        q[c + 32 * t] = s2;
+      }
+    }
+  };
+  if (wtg >= total) {                              // wave-uniform; no barrier follows
+    flush_stats();                                 // zeros: every row of the table is written
+    return;
+  }
   // epilogue operands are requested long before they are used: a load issued inside the epilogue is waited for at once,
   // behind the stores of the previous half tiles (measured: 2.4 k clocks per 32-channel tile, a third of the wave's time)
   float bias_r[COB];                               // this lane's output channels are the same for every tile
@@ -1293,7 +1314,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
           if (st_ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), ry, vst, srow, 0);
         }
       }
-      if (EPI == 0 && stat_part != nullptr) {  // block-uniform
+      if (kWaveStats) {
+        ws1[t] += s1;
+        ws2[t] += s2;
+      } else if (EPI == 0 && stat_part != nullptr) {  // block-uniform
         s1 += __shfl_xor(s1, 32, DHD_WAVE);
         s2 += __shfl_xor(s2, 32, DHD_WAVE);
         if (h == 0) {
@@ -1308,6 +1332,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
     tl_epi += RES_CLK() - tl_e0; tl_tiles += 1;
 #endif
   }
+  flush_stats();
 #if RESABL & 8
   if (lane == 0 && blockIdx.x < 256) {   // variant: 0 one-input forward, 1 two-input forward, 2 dgrad with mask, 3 dgrad plain
     unsigned long long* q = g_res_tl + (((TWO_IN ? 1 + EPI : 0) * 256 + blockIdx.x) * 8 + wv) * 8;
@@ -1317,37 +1342,75 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
 #endif
 }
 
-// partial rows [n][c2] -> kStatGroups rows: first level of the statistics reduction.  Thread =
-// (float4 column, row phase); four independent accumulators keep 64 bytes per thread in flight.
-__global__ __launch_bounds__(kEwBlock) void stat_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int c2) {
-  __shared__ f32x4 sm[kEwBlock];
-  const int g = blockIdx.x, groups = gridDim.x;
-  const int lo = (int)((long)n * g / groups), hi = (int)((long)n * (g + 1) / groups);
-  const int ncol4 = c2 >> 2;
-  const int nsub = ncol4 < kEwBlock ? kEwBlock / ncol4 : 1;  // c2 is a multiple of 256: ncol4 divides or is divided by 256
-  for (int col0 = 0; col0 < ncol4; col0 += kEwBlock) {
-    const int col = col0 + threadIdx.x % (ncol4 < kEwBlock ? ncol4 : kEwBlock);
-    const int sub = ncol4 < kEwBlock ? threadIdx.x / ncol4 : 0;
-    const f32x4* src = reinterpret_cast<const f32x4*>(part) + col;
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-    int i = lo + sub;
-    for (; i + 3 * nsub < hi; i += 4 * nsub) {
-      a0 += src[(size_t)i * ncol4];
-      a1 += src[(size_t)(i + nsub) * ncol4];
-      a2 += src[(size_t)(i + 2 * nsub) * ncol4];
-      a3 += src[(size_t)(i + 3 * nsub) * ncol4];
+// The GEMM epilogues' statistics rows [n][2][c] (n = samples x wave tiles: 5000 rows, 10 MB at B = 4) -> batch statistics and
+// everything bn_train_finalize_kernel derives from them, in ONE launch (stat_reduce_kernel + bn_train_finalize_kernel took
+// 9 + 7 us as two dependent launches).  A workgroup owns four channels: thread t sums rows t, t + 256, ... with two 16-byte
+// loads per row (sum and sum of squares), the 256 partial sums meet in LDS as doubles, threads 0-3 finalize one channel each.
+// Workgroup -> channel group is XCD-aware: the workgroups on one XCD (ids = x mod 8) take neighbouring channel groups, so that
+// the 128-byte lines of a row are fetched into one L2 only.
+__global__ __launch_bounds__(kEwBlock) void bn_stats_finalize_kernel(const float* __restrict__ part, int n,
+                                                                     const float* __restrict__ shift, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                                     float* __restrict__ run_var, float momentum, float eps,
+                                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                                     float* __restrict__ scsh, float* __restrict__ tab, int nb, int c,
+                                                                     int hw) {
+  __shared__ double sm[kEwBlock][8];
+  const int nblk = gridDim.x, t = threadIdx.x;
+  const int cg = nblk >= 8 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;   // nblk is a multiple of 8 here
+  const int ch0 = 4 * cg;
+  const f32x4* p1 = reinterpret_cast<const f32x4*>(part + ch0);
+  const f32x4* p2 = reinterpret_cast<const f32x4*>(part + c + ch0);
+  const size_t row4 = (size_t)(2 * c) / 4;   // f32x4 units per row
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, b1 = a1, b2 = a1;
+  int i = t;
+  for (; i + kEwBlock < n; i += 2 * kEwBlock) {
+    a1 += p1[(size_t)i * row4];
+    a2 += p2[(size_t)i * row4];
+    b1 += p1[(size_t)(i + kEwBlock) * row4];
+    b2 += p2[(size_t)(i + kEwBlock) * row4];
+  }
+  if (i < n) {
+    a1 += p1[(size_t)i * row4];
+    a2 += p2[(size_t)i * row4];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sm[t][e] = (double)a1[e] + (double)b1[e];
+    sm[t][4 + e] = (double)a2[e] + (double)b2[e];
+  }
+  __syncthreads();
+  for (int s = kEwBlock / 2; s > 0; s >>= 1) {
+    if (t < s) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sm[t][e] += sm[t + s][e];
     }
-    for (; i < hi; i += nsub) a0 += src[(size_t)i * ncol4];
-    f32x4 t = (a0 + a1) + (a2 + a3);
-    if (nsub > 1) {
-      __syncthreads();
-      sm[threadIdx.x] = t;
-      __syncthreads();
-      if (sub == 0) {
-        for (int q = 1; q < nsub; ++q) t += sm[q * ncol4 + col];
-      }
-    }
-    if (sub == 0) reinterpret_cast<f32x4*>(out)[(size_t)g * ncol4 + col] = t;
+    __syncthreads();
+  }
+  if (t >= 4) return;
+  const int ch = ch0 + t;
+  const double s1 = sm[0][t], s2 = sm[0][4 + t];
+  const double cnt = (double)nb * (double)hw;
+  const double md = s1 / cnt;
+  double var = s2 / cnt - md * md;
+  if (var < 0.0) var = 0.0;
+  const double mu = (double)shift[ch] + md;
+  const float rs = (float)(1.0 / sqrt(var + (double)eps));
+  mean[ch] = (float)mu;
+  rstd[ch] = rs;
+  const float sc = gamma[ch] * rs, shf = beta[ch] - (float)mu * sc;
+  scsh[ch] = sc;
+  scsh[c + ch] = shf;
+  for (int b = 0; b < nb; ++b) {
+    float* q = tab + (size_t)b * 3 * c;
+    q[ch] = sc;
+    q[c + ch] = 0.f;
+    q[2 * c + ch] = shf;
+  }
+  if (run_mean) {
+    const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+    run_mean[ch] = (float)((1.0 - (double)momentum) * (double)run_mean[ch] + (double)momentum * mu);
+    run_var[ch] = (float)((1.0 - (double)momentum) * (double)run_var[ch] + (double)momentum * unb);
   }
 }
 
@@ -1937,8 +2000,8 @@ ScratchLayout scratch_layout(int b, int c, int hw, int r) {
   auto take = [&](size_t n) { size_t at = o; o += align_up(n); return at; };
   const size_t cc = (size_t)c * c, plane = (size_t)b * c * hw;
   L.wp1 = take(2 * cc); L.wp2 = take(2 * cc); L.wp1t = take(2 * cc); L.wp2t = take(2 * cc);  // f32 images: cc, bf16x6 images: 1.5 cc
-  L.part = take((size_t)(b * kPlaneChunks > kStatGroups ? b * kPlaneChunks : kStatGroups) * 2 * c);
-  L.stat_part = take((size_t)b * ((hw + 31) / 32) * 2 * c);
+  L.part = take((size_t)b * kPlaneChunks * 2 * c);
+  L.stat_part = take((size_t)b * ((hw + 31) / 32 + 64) * 2 * c);   // a row per (sample, wave tile), or per wave of every launch (<= tiles + 63 each)
   L.da1 = take((size_t)b * kPlaneChunks * c);
   L.da2 = take((size_t)b * kPlaneChunks * c);
   L.tab_g2 = take((size_t)b * 3 * c);
@@ -2062,7 +2125,9 @@ int launch_pack(const float* w, int transpose, float* packed, int c, hipStream_t
 
 // Resident-weights launcher: persistent workgroups, one per CU, teams of C / (32 COB) on one XCD.
 int launch_pw_gemm_res(const float* in0, const float* in1, size_t in_bstride, int in_channels, const float* coef, bool relu, const float* wp,
-                       const float* bias, unsigned* relu_mask, float* stat_part, float* y, int epi, int b, int c, int hw, hipStream_t st) {
+                       const float* bias, unsigned* relu_mask, float* stat_part, float* y, int epi, int b, int c, int hw, hipStream_t st,
+                       int* stat_rows) {
+  int rows_done = 0;   // statistics rows written so far (bf16x3: one per wave of every launch; bf16x6: one per (sample, wave tile))
   const int nt = mode_terms(), cob = res_cob(c, nt);
   const int groups = c / (32 * cob);
   const int kcn = c / 16, nwt = (hw + 31) / 32;
@@ -2086,7 +2151,8 @@ int launch_pw_gemm_res(const float* in0, const float* in1, size_t in_bstride, in
     const float* i1 = two ? in1 + (size_t)b0 * in_bstride : nullptr;
     const float* cf = coef + (size_t)b0 * 3 * c;
     unsigned* rm = relu_mask ? relu_mask + (size_t)b0 * nwt * c : nullptr;
-    float* sp = stat_part ? stat_part + (size_t)b0 * nwt * 2 * c : nullptr;
+    float* sp = stat_part ? stat_part + (size_t)rows_done * 2 * c : nullptr;
+    rows_done += nt == 2 ? nteams * kResWaves : (int)total;
     float* yo = y + (size_t)b0 * c * hw;
 #define DHD_RES(NT, COB, KCN, TWO, RELU, EPI)                                                                            \
   do {                                                                                                                \
@@ -2123,15 +2189,18 @@ int launch_pw_gemm_res(const float* in0, const float* in1, size_t in_bstride, in
 #undef DHD_RES
     DHD_LAUNCH_CHECK();
   }
+  if (stat_rows) *stat_rows = rows_done;
   return DHD_OK;
 }
 
 // in0/in1 prologue GEMM launcher.  epi: 0 forward (+bias), 1 dgrad with ReLU mask, 2 dgrad plain
 int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in_channels, const float* coef, bool relu, const float* wp,
                    const float* bias, const float* aux, const float* aux_scsh, unsigned* relu_mask, float* stat_part, float* y, int epi, int b,
-                   int c, int hw, hipStream_t st) {
+                   int c, int hw, hipStream_t st, int* stat_rows = nullptr) {
+  if (stat_rows) *stat_rows = b * ((hw + 31) / 32);   // the streamed kernels: a row per (sample, wave tile)
   if (res_supported(c))
-    return launch_pw_gemm_res(in0, in1, in_bstride, in_channels, coef, relu, wp, bias, relu_mask, stat_part, y, epi, b, c, hw, st);
+    return launch_pw_gemm_res(in0, in1, in_bstride, in_channels, coef, relu, wp, bias, relu_mask, stat_part, y, epi, b, c, hw, st,
+                              stat_rows);
   const int cot = pw_cot(c);
   const int tps = dhd_cdiv(hw, 32 * (kPwBlock / DHD_WAVE));  // 128-pixel tiles per sample
   const bool two = in1 != nullptr;
@@ -2313,7 +2382,7 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
   const dim3 planes2(kPlaneChunks, b * 2 * c), planes(kPlaneChunks, b * c);
   const dim3 per_ch(dhd_cdiv(c, kEwBlock));
   const bool fused_stats = w->training && g_gemm_mode >= 1;  // BatchNorm sums come out of the GEMM epilogue
-  const int nwt = (hw + 31) / 32;
+  int stat_rows = 0;
 
   hipLaunchKernelGGL(plane_mean_kernel, planes2, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw);
   hipLaunchKernelGGL(fc_forward_kernel, dim3(b), dim3(kFcBlock), (size_t)(2 * c + r) * sizeof(float), st, sc + T.mean_part,
@@ -2324,12 +2393,11 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
 
   // y1 = conv1(blend1(x))
   rc = launch_pw_gemm(x, x + (size_t)c * hw, (size_t)2 * c * hw, c, sv + S.tab_a, false, sc + T.wp1, w->conv1_b, nullptr, nullptr,
-                      nullptr, fused_stats ? sc + T.stat_part : nullptr, sv + S.y1, 0, b, c, hw, st);
+                      nullptr, fused_stats ? sc + T.stat_part : nullptr, sv + S.y1, 0, b, c, hw, st, &stat_rows);
   if (rc != DHD_OK) return rc;
   if (w->training) {
     if (fused_stats) {  // the GEMM epilogue left per-(sample, wave tile) sums shifted by the bias
-      hipLaunchKernelGGL(stat_reduce_kernel, dim3(kStatGroups), dim3(kEwBlock), 0, st, sc + T.stat_part, sc + T.part, b * nwt, 2 * c);
-      hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, kStatGroups, w->conv1_b, 1, w->bn1_w,
+      hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, sc + T.stat_part, stat_rows, w->conv1_b, w->bn1_w,
                          w->bn1_b, w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1,
                          sv + S.tab1, b, c, hw);
     } else {
@@ -2346,13 +2414,12 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
   // y2 = conv2(relu(bn1(y1)))
   rc = launch_pw_gemm(sv + S.y1, nullptr, (size_t)c * hw, c, sv + S.tab1, true, sc + T.wp2, w->conv2_b, nullptr, nullptr,
                       reinterpret_cast<unsigned*>(sv + S.mask), fused_stats ? sc + T.stat_part : nullptr, sv + S.y2, 0,
-                      b, c, hw, st);
+                      b, c, hw, st, &stat_rows);
   if (rc != DHD_OK) return rc;
   float* tab_unused = sc + T.tab_g2;  // bn2 has no consumer GEMM in forward; table slot reused as a sink
   if (w->training) {
     if (fused_stats) {  // the GEMM epilogue left per-(sample, wave tile) sums shifted by the bias
-      hipLaunchKernelGGL(stat_reduce_kernel, dim3(kStatGroups), dim3(kEwBlock), 0, st, sc + T.stat_part, sc + T.part, b * nwt, 2 * c);
-      hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, kStatGroups, w->conv2_b, 1, w->bn2_w,
+      hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, sc + T.stat_part, stat_rows, w->conv2_b, w->bn2_w,
                          w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, sv + S.mean2, sv + S.rstd2, sv + S.scsh2,
                          tab_unused, b, c, hw);
     } else {
