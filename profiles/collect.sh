@@ -3,7 +3,7 @@
 # from the repo root); copy the results into profiles/<round>/ afterwards.
 #   1. kernel stats of the default bench (MGHS + SFA stage) and of --no-sfa
 #   2. PMC passes (counters only, FETCH_SIZE and WRITE_SIZE separately) of the default bench
-#   3. a plain bench line outside the profiler
+#   3. a plain bench line outside the profiler (run last, after the PMC summary has been written)
 #   4. kernel stats + the two PMC passes of `bench.py --workload ema` (its kernel is merged into pmc_summary.json)
 # Usage: collect.sh [hotpath] [ema]   (default: both)
 set -u
@@ -24,7 +24,6 @@ cp $(find $OUT/mo -name 'mo_kernel_stats.csv') $OUT/mghs_only_kernel_stats.csv
 cp $(find $OUT/pf -name 'pf_counter_collection.csv') $OUT/pmc_fetch_size.csv
 cp $(find $OUT/pw -name 'pw_counter_collection.csv') $OUT/pmc_write_size.csv
 rm -rf $OUT/hp $OUT/mo $OUT/pf $OUT/pw
-cd $R && python bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err
 fi
 cd /tmp
 if [[ " $WHAT " == *" ema "* ]]; then
@@ -71,4 +70,9 @@ json.dump(dict(samples_per_gpu=4, source_sha256=kernel_source_sha256(),
                kernels=ks), open(out + '/pmc_summary.json', 'w'), indent=1)
 print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in ks.items()}, indent=0)[:3000])
 PY
+# the plain bench line last, with the fresh PMC summary in place (bench.py reports `traffic` only for a matching source hash)
+if [[ " $WHAT " == *" hotpath "* ]]; then
+cp $OUT/pmc_summary.json $R/profiles/r2/pmc_summary.json
+cd $R && python bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err
+fi
 ls -la $OUT
