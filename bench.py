@@ -72,14 +72,32 @@ def pmc_traffic(kernel, batch):
     return best
 
 
+def pmc_summary(batch):
+    """kernel -> HBM bytes per launch from the committed PMC summary that matches this batch and these kernel sources, or {}."""
+    prof = os.path.join(ROOT, 'profiles')
+    sha = kernel_source_sha256()
+    best = {}
+    for rnd in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        f = os.path.join(prof, rnd, 'pmc_summary.json')
+        if os.path.exists(f):
+            d = json.load(open(f))
+            if d.get('samples_per_gpu') == batch and d.get('source_sha256') == sha:
+                best = {k: v['hbm_bytes_per_launch'] for k, v in d.get('kernels', {}).items()}
+    return best
+
+
 def sfa_forward_traffic(batch):
-    """Sum of the committed PMC traffic of the kernels one dhd_sfa_stage_forward call launches, or None."""
-    calls = {'plane_mean_kernel': 1, 'fc_forward_kernel': 1, 'pack_weight_res_kernel': 2, 'pw_gemm_res_kernel<2,4,16,true,false,0,8,0>': 1,
-             'pw_gemm_res_kernel<2,4,16,false,true,0,8,0>': 1, 'stat_reduce_kernel': 2, 'bn_train_finalize_kernel': 2, 'blend2_bn_kernel': 1}
-    parts = [pmc_traffic(k, batch) for k in calls]
-    if any(p is None for p in parts):
+    """Sum of the committed PMC traffic of the kernels one dhd_sfa_stage_forward call launches (training mode, default GEMM
+    mode), or None.  The two GEMMs are found by their template arguments <terms, tiles, K steps, TWO_IN, RELU, EPI, ...>:
+    conv1 = two inputs / no ReLU / epilogue 0, conv2 = one input / ReLU / epilogue 0."""
+    k = pmc_summary(batch)
+    import re
+    conv1 = [v for n, v in k.items() if re.match(r'pw_gemm_res_kernel<\d+,\d+,\d+,true,false,0,', n)]
+    conv2 = [v for n, v in k.items() if re.match(r'pw_gemm_res_kernel<\d+,\d+,\d+,false,true,0,', n)]
+    calls = {'plane_mean_kernel': 1, 'fc_forward_kernel': 1, 'pack_weight_res_kernel': 1, 'bn_stats_finalize_kernel': 2, 'blend2_bn_kernel': 1}
+    if len(conv1) != 1 or len(conv2) != 1 or any(n not in k for n in calls):
         return None
-    return int(sum(p * n for p, n in zip(parts, calls.values())))
+    return int(conv1[0] + conv2[0] + sum(k[n] * m for n, m in calls.items()))
 
 
 def parse():
