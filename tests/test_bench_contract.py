@@ -42,3 +42,15 @@ def test_bench_refuses_more_ranks_than_gpus(gpu):
                          capture_output=True, text=True, timeout=300, cwd=ROOT,
                          env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')})
     assert out.returncode != 0 and 'GPU(s) are visible' in (out.stderr + out.stdout)
+
+
+def test_committed_pmc_summary_belongs_to_the_current_kernel_sources():
+    """bench.py reports `traffic` only while profiles/<round>/pmc_summary.json carries the hash of the kernel sources the
+    library is built from; a kernel edit without a fresh counter pass would silently turn the field into null."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.pmc_traffic('mghs_stream_fwd', 4) is not None, 'profiles/*/pmc_summary.json is stale: run profiles/collect.sh on the GPU box'
+    both = [bench.pmc_traffic(k, 4) for k in ('mghs_stream_bwd', 'mghs_pixel_bwd')]
+    assert None not in both
+    fwd = bench.sfa_forward_traffic(4)
+    assert fwd is not None and 4 * 328e6 < fwd < 2 * 4 * 328e6     # algorithmic 328 MB per sample (SURVEY 8d)
