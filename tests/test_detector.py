@@ -346,3 +346,98 @@ def test_config5_four_temporal_frames_with_swin_l_dimensions(gpu):
                  'img_voxel_encoder2.inc.double_conv.0.weight', 'mix.mysk_7.spacial_leanring.3.weight', 'occ_head.predicter.0.weight'):
         gr = dict(m.named_parameters())[name].grad
         assert gr is not None and torch.isfinite(gr).all() and gr.abs().sum() > 0, name
+
+
+@pytest.mark.gpu
+def test_config5_four_lifted_frames_full_size_pooled_tensors_vs_oracle(gpu):
+    """BASELINE.json configs[4] at its FULL geometry: DHD_stereo with `num_adj = 3` (five loaded frames, four lifted), Swin-L
+    widths and depths (embed 192, depths 2-2-18-2, heads 6/12/24/48), 6 cameras x 512x1408 images -> 32x88 feature maps,
+    D = 88, bf16 autocast.  Every lifted frame's call of MGHS_Stereo.view_transform is recorded (calibration, depth, context,
+    height distribution) and its two pooled tensors -- `bev_feat` (1,64,1,200,200) and the z-stacked `bev_feat_w_z`
+    (1,64,16,200,200) -- are compared with the CPU oracle run on those same inputs: voxel indices as the oracle computes them
+    from the raw calibration, values to 1e-4.  For the key frame (the only one with a graph, DHD_model.py:437-439) the
+    gradients that the pooling backward hands to depth / context are compared with the oracle's backward of the very
+    output gradients autograd delivered."""
+    import dhd_amd
+    from dhd_amd.detector import dhd_l_model_cfg
+    from oracle import mghs_oracle as O
+    torch.manual_seed(0)
+    H, W = 512, 1408
+    cfg = dhd_l_model_cfg(input_size=(H, W))
+    n, adj = 64, 3
+    cfg['num_adj'] = adj
+    cfg['img_backbone'].update(embed_dims=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48])
+    cfg['img_neck'].update(in_channels=768 + 1536)
+    cfg['img_bev_encoder_backbone'].update(numC_input=n * (adj + 1))
+    for k, nz in (('img_voxel_encoder0_backbone', 4), ('img_voxel_encoder1_backbone', 4), ('img_voxel_encoder2_backbone', 8)):
+        cfg[k].update(n_channels=n * nz * (adj + 1))
+    m = dhd_amd.build_detector(cfg).to(gpu).train()
+    m.img_backbone.init_weights()
+    vt = m.img_view_transformer
+    B, N, Fr = 1, 6, adj + 2
+    imgs = torch.randn(B, N * Fr, 3, H, W, device=gpu)
+    per = [syn.make_calibration(150 + f, B, N, (H, W)) for f in range(Fr)]
+    cat = lambda k: T(np.concatenate([p[k] for p in per], 1), gpu)
+    e2g = cat(1).clone()
+    for f in range(1, Fr):
+        e2g[:, f * N:(f + 1) * N, 0, 3] += 0.8 * f
+    calib = [cat(0), e2g, cat(2), cat(3), cat(4), T(per[0][5], gpu)]
+    sel = syn.hash_uniform(1, (B, N, H, W)) < 0.02
+    gt_d = T(np.where(sel, 1 + 40 * syn.hash_uniform(2, (B, N, H, W)), 0).astype(np.float32), gpu)
+    gt_h = T(np.where(sel, -1 + 6 * syn.hash_uniform(3, (B, N, H, W)), 0).astype(np.float32), gpu)
+    sem = torch.randint(0, 18, (B, 200, 200, 16), device=gpu)
+    cam = torch.rand(B, 200, 200, 16, device=gpu) < 0.3
+
+    calls = []
+    inner = vt.view_transform
+
+    def recording(inp, depth, tran_feat, height):
+        depth_in = depth
+        if torch.is_grad_enabled() and depth.requires_grad:
+            # copies whose .grad is what the pooling node alone hands back (`depth` itself also feeds loss_depth)
+            depth, tran_feat = depth.clone(), tran_feat.clone()
+        out = inner(inp, depth, tran_feat, height)
+        out = (out[0], out[1], depth_in, out[3])     # the caller's loss keeps using the original tensor
+        bev, bev_w_z = out[0], out[1]
+        if bev.requires_grad:
+            for t_ in (depth, tran_feat, bev, bev_w_z):
+                t_.retain_grad()
+        calls.append(dict(calib=[c.detach().float().cpu().numpy() for c in inp[1:7]], depth=depth, feat=tran_feat,
+                          height=height.detach(), bev=bev, bev_w_z=bev_w_z))
+        return out
+    vt.view_transform = recording
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        losses = m(return_loss=True, img_inputs=[imgs] + calib, gt_depth=gt_d, gt_height=gt_h, voxel_semantics=sem, mask_camera=cam)
+        total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    assert len(calls) == adj + 1 and [c['bev'].requires_grad for c in calls] == [False] * adj + [True]   # key frame last
+
+    ocfg = dict(grid_config=dict(depth=[1.0, 45.0, 0.5]), input_size=(H, W), downsample=16, height_range=vt.height_range,
+                mask_range=vt.mask_range, mask_1_grid=vt.mask_1_grid, mask_2_grid=vt.mask_2_grid, mask_3_grid=vt.mask_3_grid)
+    f32 = lambda t_: t_.detach().float().cpu().numpy()
+    for i, c in enumerate(calls):
+        assert tuple(c['depth'].shape) == (B * N, 88, 32, 88) and tuple(c['feat'].shape) == (B * N, 64, 32, 88)
+        assert tuple(c['bev'].shape) == (B, 64, 1, 200, 200) and tuple(c['bev_w_z'].shape) == (B, 64, 16, 200, 200)
+        depth, feat = f32(c['depth']), f32(c['feat'])
+        hidx = c['height'].float().argmax(dim=1).cpu().numpy().astype(np.uint8)
+        bev, bev_w_z = O.mghs_depth_view_transform(ocfg, c['calib'], depth, feat, hidx)
+        scale = max(1.0, float(np.abs(bev).max()))
+        assert np.count_nonzero(bev) > 100000, i
+        np.testing.assert_allclose(f32(c['bev']), bev, atol=1e-4 * scale, rtol=1e-4, err_msg=f'frame call {i}')
+        np.testing.assert_allclose(f32(c['bev_w_z']), bev_w_z, atol=1e-4 * scale, rtol=1e-4, err_msg=f'frame call {i}')
+    key = calls[-1]
+    g0, g1 = f32(key['bev'].grad), f32(key['bev_w_z'].grad)
+    flat = lambda a: np.ascontiguousarray(a.transpose(0, 2, 1, 3, 4)).reshape(a.shape[0], -1, 200, 200)
+    ws = [flat(g0), flat(g1[:, :, 0:4]), flat(g1[:, :, 4:8]), flat(g1[:, :, 8:16])]
+    hidx = key['height'].float().argmax(dim=1).cpu().numpy().astype(np.uint8)
+    dg, fg = O.view_transform_backward(ocfg, key['calib'], f32(key['depth']), f32(key['feat']), hidx, ws)
+    # the recorded tensors may be bf16 (autocast): autograd casts the float32 gradients of the pooling node back to it
+    for src, want, name in ((key['depth'], dg, 'depth'), (key['feat'], fg, 'context')):
+        got = f32(src.grad)
+        tol = (1e-2 if src.dtype != torch.float32 else 2e-4) * max(1e-12, float(np.abs(want).max()))
+        assert np.abs(want).max() > 0 and np.abs(got - want).max() <= tol, (name, float(np.abs(got - want).max()), tol)
+    for name in ('img_backbone.patch_embed.projection.weight', 'img_view_transformer.depth_net.cost_volumn_net.0.weight',
+                 'mix.mysk_7.spacial_leanring.3.weight', 'occ_head.predicter.0.weight'):
+        gr = dict(m.named_parameters())[name].grad
+        assert gr is not None and torch.isfinite(gr).all() and gr.abs().sum() > 0, name

@@ -187,6 +187,108 @@ def test_mghs_depth_view_transform_dhdm_size_vs_reference(gpu):
     np.testing.assert_allclose(ft.grad.cpu().numpy().reshape(-1)[g['feat_grad_pos']], g['feat_grad_val'], atol=2e-4, rtol=1e-5)
 
 
+def test_mghs_depth_view_transform_dhdl_size_b2_vs_reference(gpu):
+    """Golden G15 = the reference's MGHS_Depth.view_transform at the DHD-L geometry (configs[3]/[4]: 6 cameras 512x1408 ->
+    32x88 feature maps, D = 88, C = 64) with B = 2 (DHD-L.py samples_per_gpu), STACKED layout: `bev_feat` (2,64,1,200,200)
+    and `bev_feat_w_z` (2,64,16,200,200) written in place.  Index maps by SHA-256 (2.97 M points x 4 grids), sampled
+    voxels, sums, non-zero counts, sampled gradients, and the grid reset (:848-854)."""
+    from dhd_amd import MGHS_Depth, mghs_op
+    g = golden('g15_mghs_depth_dhdl_b2')
+    cfg = syn.dhd_s_config()
+    cfg['grid_config'] = dict(cfg['grid_config'], depth=[1.0, 45.0, 0.5])
+    cfg['input_size'] = (512, 1408)
+    cfg['collapse_z'] = False
+    _, s_in, s_w = (int(v) for v in g['seeds'])
+    B, N, fh, fw = 2, 6, 32, 88
+    depth, feat, hidx = syn.lift_inputs(s_in, B, N, 88, fh, fw, 64, 65)
+    plan, axes = make_plan(cfg, B, N)
+    calib_s, keep = device_calib(golden_calib(g), axes, gpu, g['ref_inv_post_rot'], g['ref_combine'])
+    for k in range(4):
+        rank, ego = mghs_op.voxel_index(plan, calib_s, k, want_ego=(k == 0))
+        if k == 0:
+            assert sha(ego.cpu().numpy()) == str(g['coor_sha'])
+        rank = rank.cpu().numpy()
+        assert sha(rank) == str(g[f'rank_map_sha{k}']), k
+        assert int((rank >= 0).sum()) == int(g[f'n_kept{k}'])
+    hn = dict(use_dcn=False, use_aspp=False)
+    m = MGHS_Depth(**dict(cfg, heightnet_cfg=hn, depthnet_cfg=hn)).to(gpu)
+    inject_reference_matrices(m, g, gpu)
+    calib = [T(a, gpu) for a in golden_calib(g)]
+    x = torch.zeros(B, N, 1, fh, fw, device=gpu)
+    dt, ft = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+    bev, bev_w_z, _, _ = m.view_transform([x] + calib, dt, ft, T(syn.height_probs_from_index(hidx, 65), gpu))
+    assert bev.shape == (B, 64, 1, 200, 200) and bev_w_z.shape == (B, 64, 16, 200, 200) and bev_w_z.is_contiguous()
+    assert list(m.grid_config['z']) == list(g['final_grid_z']) and m.grid_size.tolist() == g['final_grid_size'].tolist()
+    ((bev * T(syn.hash_signed(s_w, tuple(bev.shape)), gpu)).sum()
+     + (bev_w_z * T(syn.hash_signed(s_w + 1, tuple(bev_w_z.shape)), gpu)).sum()).backward()
+    for k, o in enumerate((bev, bev_w_z)):
+        o = o.detach().cpu().numpy()
+        np.testing.assert_allclose(o.reshape(-1)[g[f'out_pos{k}']], g[f'out_val{k}'], atol=1e-4, rtol=1e-5)
+        s = g[f'out_sum{k}']
+        assert abs(o.astype(np.float64).sum() - s[0]) < 1e-6 * s[1] + 1e-3
+        assert int(np.count_nonzero(o)) == int(s[2])
+    # sums of up to ~1100 terms (max_interval0 = 1114) in another order
+    np.testing.assert_allclose(dt.grad.cpu().numpy().reshape(-1)[g['depth_grad_pos']], g['depth_grad_val'], atol=3e-4, rtol=1e-5)
+    np.testing.assert_allclose(ft.grad.cpu().numpy().reshape(-1)[g['feat_grad_pos']], g['feat_grad_val'], atol=6e-4, rtol=1e-5)
+    for name, a in (('depth_grad', dt.grad), ('feat_grad', ft.grad)):
+        s = g[f'{name}_sum']
+        assert abs(a.double().sum().item() - s[0]) < 2e-6 * s[1] + 1e-3, name
+
+
+def test_stereo_cost_volume_dhdl_size_vs_reference(gpu):
+    """Golden G16 = the reference's DepthNet.calculate_cost_volumn (depthnet.py:307-361) at the DHD-L stereo size:
+    12 views (B = 2 x 6 cameras), 128-channel stereo features on 128 x 352 maps (MGHS_Stereo's cv_frustum, downsample 4),
+    D = 88 -> (12, 88, 128, 352).  gen_grid on the GPU + dhd_stereo_cost_volume: 16 384 sampled probabilities and two
+    per-view reductions over all 47.6 M of them.  A sample that lands within rounding of the adjacent image's border is
+    in on one side and zero-padded + biased on the other (grid positions differ by ~1e-6 between MKL's and the device's
+    matrix inverses): at most a handful of the samples may differ by more than the tolerance."""
+    from dhd_amd import MGHS_Stereo
+    from dhd_amd.depthnet import DepthNet
+    g = golden('g16_stereo_dhdl')
+    bn, d, h, w = (int(v) for v in g['shape'])
+    _, s_prev, s_curr = (int(v) for v in g['seeds'])
+    c = 128
+    cfg = syn.dhd_s_config()
+    cfg['grid_config'] = dict(cfg['grid_config'], depth=[1.0, 45.0, 0.5])
+    cfg['input_size'] = (512, 1408)
+    hn = dict(use_dcn=False, use_aspp=False)
+    vt = MGHS_Stereo(**dict(cfg, collapse_z=False, heightnet_cfg=hn, depthnet_cfg=dict(hn, stereo=True)))
+    assert tuple(vt.cv_frustum.shape) == (d, h, w, 3)
+    dn = DepthNet(32, 32, 16, d, use_dcn=False, aspp_mid_channels=16, stereo=True, bias=float(g['bias'])).to(gpu)
+    prev = T(0.5 * syn.hash_signed(s_prev, (bn, c, h, w)), gpu)
+    curr = T(0.5 * syn.hash_signed(s_curr, (bn, c, h, w)), gpu)
+    metas = dict(k2s_sensor=T(g['k2s_sensor'], gpu), intrins=T(g['intrins'], gpu), post_rots=T(g['post_rots'], gpu),
+                 post_trans=T(g['post_trans'], gpu), frustum=vt.cv_frustum.to(gpu), cv_feat_list=[prev, curr])
+    assert dn.use_hip_cost_volume
+    cv = dn.calculate_cost_volumn(metas)
+    assert tuple(cv.shape) == (bn, d, h, w)
+    got = cv.reshape(-1)[T(g['pos'], gpu)].cpu().numpy()
+    # Tolerance: the features are per-pixel hash noise (neighbouring pixels differ by O(1)), so a sampling position that
+    # moves by 1e-6 of the normalised range (1.7e-4 pixel of 352; MKL's vs the device's 3x3 inverses) moves each of the 128
+    # |difference| terms by ~1e-4 and the cost by ~1e-3, i.e. a probability by ~1e-3 of itself (measured: max 3.7e-5 absolute
+    # on probabilities of ~0.03).  Structural errors (channel order, padding, the bias flag, the softmax axis) are O(1).
+    bad = np.abs(got - g['val']) > 5e-3 * np.abs(g['val']) + 1e-6
+    assert bad.sum() <= 4, (int(bad.sum()), float(np.abs(got - g['val']).max()))
+    sq = (cv.double() ** 2).sum(dim=(1, 2, 3)).cpu().numpy()
+    mx = cv.max(dim=1).values.double().sum(dim=(1, 2)).cpu().numpy()
+    np.testing.assert_allclose(sq, g['view_sq_sum'], rtol=5e-4)
+    np.testing.assert_allclose(mx, g['view_max_sum'], rtol=5e-4)
+    np.testing.assert_allclose(cv.double().sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+def test_get_mlp_input_on_gpu_all_27_columns(gpu):
+    """Golden G4: MGHS.get_mlp_input (lss_heightmap.py:493-526) evaluated on CUDA tensors, every one of the 27 columns
+    bit-identical to the reference's (pure gathers of float32 calibration entries)."""
+    from dhd_amd import MGHS
+    g = golden('g4_loss')
+    cfg = syn.dhd_s_config()
+    cfg['input_size'] = (64, 176)
+    m = MGHS(**dict(cfg, heightnet_cfg=dict(use_dcn=False, use_aspp=False))).to(gpu)
+    mlp = m.get_mlp_input(*[T(a, gpu) for a in golden_calib(g)])
+    assert mlp.is_cuda and mlp.shape[-1] == 27
+    assert np.array_equal(mlp.cpu().numpy(), g['mlp_input'])
+
+
 # --------------------------------------------------------------------------- MGHS.forward as a whole (a11)
 
 class _HeightStandIn(torch.nn.Module):

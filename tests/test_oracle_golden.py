@@ -279,6 +279,36 @@ def test_mghs_depth_view_transform_vs_reference():
     np.testing.assert_allclose(fg, g['feat_grad'], atol=5e-6, rtol=0)
 
 
+def test_mghs_depth_view_transform_dhdl_size_b2_vs_reference():
+    """Golden G15: the reference's MGHS_Depth.view_transform at the DHD-L geometry (6 x 512x1408 -> 32x88 maps, D = 88,
+    C = 64, collapse_z=False) with B = 2 (DHD-L.py samples_per_gpu): 2.97 M frustum points.  Ego coordinates and every
+    grid's point -> voxel map by SHA-256, the pooled `bev_feat` / stacked `bev_feat_w_z` by samples, sums and counts."""
+    import hashlib
+    g = golden('g15_mghs_depth_dhdl_b2')
+    cfg = syn.dhd_s_config()
+    cfg['grid_config'] = dict(cfg['grid_config'], depth=[1.0, 45.0, 0.5])
+    cfg['input_size'] = (512, 1408)
+    cfg['collapse_z'] = False
+    calib = golden_calib(g)
+    _, s_in, _ = (int(v) for v in g['seeds'])
+    depth, feat, hidx = syn.lift_inputs(s_in, 2, 6, 88, 32, 88, 64, 65)
+    axes = O.frustum_axes(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    coor = O.ego_coor(axes, calib[0], calib[2], calib[3], calib[4], calib[5], g['ref_inv_post_rot'], g['ref_combine'])
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert coor.shape == (2, 6, 88, 32, 88, 3) and sha(coor) == str(g['coor_sha'])
+    for k, grid in enumerate(grids_of(cfg)):
+        rm = O.voxel_rank(coor, grid)
+        assert sha(rm) == str(g[f'rank_map_sha{k}'])
+        assert int((rm >= 0).sum()) == int(g[f'n_kept{k}'])
+    outs = O.mghs_depth_view_transform(cfg, calib, depth, feat, hidx, g['ref_inv_post_rot'], g['ref_combine'])
+    assert outs[0].shape == (2, 64, 1, 200, 200) and outs[1].shape == (2, 64, 16, 200, 200)
+    for k, o in enumerate(outs):
+        np.testing.assert_allclose(o.reshape(-1)[g[f'out_pos{k}']], g[f'out_val{k}'], atol=3e-5, rtol=1e-5)
+        s = g[f'out_sum{k}']
+        assert abs(o.astype(np.float64).sum() - s[0]) < 1e-6 * s[1] + 1e-3
+        assert int(np.count_nonzero(o)) == int(s[2])
+
+
 def test_dcn_oracle_vs_the_grid_sample_formulation():
     """oracle/dcn_oracle.py (explicit neighbour gathers, mmcv's published algorithm) against the package's CPU
     formulation (F.grid_sample, zero padding, align_corners) in float64, offsets far outside the image included."""
