@@ -123,6 +123,10 @@ def parse():
                    help="process-group backend; 'gloo' lets several ranks share one GPU (testing the N > 1 code path on a one-GPU box)")
     p.add_argument('--no-e2e', action='store_true', help='hotpath: leave out the end-to-end DHD-S sub-record')
     p.add_argument('--no-operator', action='store_true', help='hotpath: leave out the standalone bev_pool_v2 operator timing')
+    p.add_argument('--sfa-gemm', choices=['bf16x3', 'bf16x6', 'f32'], default=None,
+                   help="hotpath: precision of the SFA stage's C x C GEMMs in the main timed loop (default: the library default, bf16x3; "
+                        "the bf16x6 step time is reported beside it either way)")
+    p.add_argument('--bucket-mb', type=int, default=64, help='e2e under DDP: gradient bucket size (MB)')
     return p.parse_args()
 
 
@@ -131,7 +135,7 @@ class HotPath:
 
     GEOMETRY = {'dhd-s': ((256, 704), 1.0), 'dhd-m': ((256, 704), 0.5), 'dhd-l': ((512, 1408), 0.5)}  # input size, depth step
 
-    def __init__(self, dev, batch, seed, with_sfa, geometry='dhd-s'):
+    def __init__(self, dev, batch, seed, with_sfa, geometry='dhd-s', deterministic=False, sfa_gemm=None):
         self.dev, self.B = dev, batch
         cfg = self.cfg = syn.dhd_s_config()
         (ih, iw), dstep = self.GEOMETRY[geometry]
@@ -151,7 +155,8 @@ class HotPath:
                                                     (u.to(dev), v.to(dev), d.to(dev)))
         full = {'x': [-40, 40, 0.4], 'y': [-40, 40, 0.4], 'z': [-1, 5.4, 6.4]}
         grids = [mghs_op.grid_from_cfg(g) for g in (full, cfg['mask_1_grid'], cfg['mask_2_grid'], cfg['mask_3_grid'])]
-        self.plan = mghs_op.Plan(batch, N, D, fh, fw, C, grids)
+        # the context gradient comes back in tran_feat's own (B*N, C, fH, fW) layout (DHD_MGHS_FEAT_GRAD_NCHW)
+        self.plan = mghs_op.Plan(batch, N, D, fh, fw, C, grids, deterministic=deterministic, feat_grad_nchw=True)
         self.depth, self.feat = t(depth), t(feat)
         self.height = t(syn.height_probs_from_index(hidx, 65))
         self.ws = self.plan.new_workspace(dev)
@@ -161,6 +166,7 @@ class HotPath:
         if with_sfa:
             torch.manual_seed(seed)
             self.stage = channel_spatial_stage(512).to(dev).train()
+            self.stage.gemm = sfa_gemm     # None: the library default (bf16x3); 'bf16x6': float32-level products
             self.stage_params = list(self.stage.parameters())
             self.x = torch.randn(batch, 512, 200, 200, generator=g).to(dev).requires_grad_()
             self.gy = torch.randn(batch, 256, 200, 200, generator=g).to(dev)
@@ -176,9 +182,8 @@ class HotPath:
 
     def step(self, record):
         cfg = self.cfg
-        band = mghs_op.height_band(self.height, cfg['height_range'], cfg['mask_range'])
-        feat_nhwc = mghs_op._nchw_to_nhwc(self.feat)
-        mghs_op.prepare(self.plan, self.calib, band, self.ws)
+        # dhd_mghs_lift: height argmax -> band, context re-layout, geometry + grouping (4 launches)
+        _, feat_nhwc = mghs_op.lift(self.plan, self.calib, self.height, cfg['height_range'], cfg['mask_range'], self.feat, self.ws)
         if record:
             # HIP events on the launch stream, around the streaming kernel only
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -194,7 +199,7 @@ class HotPath:
         if record:
             b1.record()
             self.ev_bwd.append((b0, b1))
-        fg_nchw = mghs_op._nhwc_to_nchw(fg)
+        fg_nchw = fg   # already (B*N, C, fH, fW)
         if self.with_sfa:
             self.x.grad = None
             for prm in self.stage_params:  # optimizer.zero_grad(set_to_none=True), the PyTorch default
@@ -218,7 +223,7 @@ class EndToEnd:
     """DHD-S exactly as projects/configs/DHD/DHD-S.py:42-155 (random init, synthetic 6-camera batch,
     SURVEY.md 8d config 2): forward_train -> sum of the four losses -> backward -> grad clip 5 -> AdamW."""
 
-    def __init__(self, dev, batch, seed, world, amp, model='dhd-s', ema=True, graph=False):
+    def __init__(self, dev, batch, seed, world, amp, model='dhd-s', ema=True, graph=False, bucket_mb=64):
         import dhd_amd
         from dhd_amd.detector import dhd_l_model_cfg, dhd_m_model_cfg, dhd_s_model_cfg
         torch.manual_seed(seed)
@@ -235,7 +240,7 @@ class EndToEnd:
         self.n_params = sum(p.numel() for p in self.params)
         self.net = self.model
         if world > 1:
-            self.net = torch.nn.parallel.DistributedDataParallel(self.model, device_ids=[dev.index], bucket_cap_mb=64,
+            self.net = torch.nn.parallel.DistributedDataParallel(self.model, device_ids=[dev.index], bucket_cap_mb=bucket_mb,
                                                                  gradient_as_bucket_view=True)
         self.opt = torch.optim.AdamW(self.params, lr=2e-4, weight_decay=1e-2, fused=True, capturable=bool(graph))  # DHD-S.py:262
         # custom_hooks of all three configs (DHD-S.py:272-278): weight EMA after every iteration
@@ -300,7 +305,7 @@ class EndToEnd:
 
 
 def run_e2e(a, rank, world, dev):
-    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp, a.model, not a.no_ema, graph=not a.no_graph)
+    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp, a.model, not a.no_ema, graph=not a.no_graph, bucket_mb=a.bucket_mb)
     for _ in range(a.warmup):
         job.step(False)
     job.capture()
@@ -331,6 +336,32 @@ def run_e2e(a, rank, world, dev):
                         parallelism=f'DDP x{world} (RCCL bucketed all-reduce overlapped with backward)' if world > 1 else 'single GPU',
                         hip_graph=job.graphed is not None, hip_graph_error=job.graph_error, final_loss=float(loss)))), flush=True)
     ddist.shutdown()
+
+
+def hbm_calibration(dev, nbytes, reps=20, warmup=3):
+    """What this box's HBM does for the plain streams a kernel can be compared with, measured in THIS run with the same
+    timer as the kernel (HIP events on the launch stream around each launch): hipMemsetAsync, a linear grid-stride fill
+    with 16-byte non-temporal stores, and a linear read, each over `nbytes` (the dominant kernel's algorithmic bytes).
+    `roofline.frac` stays achieved / spec peak; `frac_of_fill` = fill_ms / launch_ms says how far the kernel is from the
+    fastest store stream of the same box, which is what round-over-round comparisons should use (boxes differ by +-8 %)."""
+    lib = _lib.load()
+    nbytes = int(nbytes) // 16 * 16
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    s = _lib.stream_ptr(dev)
+    out = {}
+    for name, pattern in (('memset', 0), ('fill', 1), ('read', 2)):
+        ev = []
+        for it in range(warmup + reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.dhd_hbm_calibrate(_lib.ptr(buf), nbytes, pattern, s), 'dhd_hbm_calibrate')
+            e1.record()
+            if it >= warmup:
+                ev.append((e0, e1))
+        torch.cuda.synchronize()
+        out[name] = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    del buf
+    return out, nbytes
 
 
 def operator_roofline(hp, steps, warmup):
@@ -529,7 +560,7 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
         return ddist.max_over_ranks(time.perf_counter() - t0, dev) / n
 
     for amp in ('off', 'fp16'):
-        job = EndToEnd(dev, a.batch, 1000 + rank, world, amp, 'dhd-s', True, graph=not a.no_graph)
+        job = EndToEnd(dev, a.batch, 1000 + rank, world, amp, 'dhd-s', True, graph=not a.no_graph, bucket_mb=a.bucket_mb)
         for _ in range(warmup):
             job.step(False)
         eager = timed(job, 2) if job.want_graph else None
@@ -705,9 +736,7 @@ def main():
         return run_ema(a, rank, world, dev)
     if a.workload == 'occ_loss':
         return run_occ_loss(a, rank, world, dev)
-    if a.deterministic:
-        mghs_op.set_deterministic(True)
-    hp = HotPath(dev, a.batch, 1000 + rank, not a.no_sfa, a.geometry)
+    hp = HotPath(dev, a.batch, 1000 + rank, not a.no_sfa, a.geometry, deterministic=a.deterministic, sfa_gemm=a.sfa_gemm)
 
     for _ in range(a.warmup):
         hp.step(False)
@@ -724,6 +753,21 @@ def main():
     fence()
     elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
 
+    # the same step with float32-level GEMM products in the SFA stage (bf16x6), W warm-ups + K timed steps
+    elapsed_x6 = None
+    if hp.with_sfa and (a.sfa_gemm or 'bf16x3') != 'bf16x6':
+        main_gemm, hp.stage.gemm = hp.stage.gemm, 'bf16x6'
+        for _ in range(a.warmup):
+            hp.step(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            hp.step(False)
+        fence()
+        elapsed_x6 = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+        hp.stage.gemm = main_gemm
+    cal_ms, cal_bytes = hbm_calibration(dev, hp.pool_fwd_bytes)   # every rank runs it, rank 0 reports
+
     line = None
     if rank == 0:
         kern_ms = float(np.mean([s.elapsed_time(e) for s, e in hp.ev]))
@@ -736,10 +780,21 @@ def main():
                                  + ('' if a.no_sfa else ' + SFA attention stage fwd+bwd') +
                                  f'; geometry {a.geometry}: 6 cams -> {hp.dims[2]}x{hp.dims[3]}, D={hp.dims[1]}, C=64, grids 200x200x{{1,4,4,8}}; dense backbone/encoder convs not in the step',
                         samples_per_gpu=a.batch, global_batch=a.batch * world, parallelism=f'sample-sharded x{world}, no data-path collective',
-                        deterministic_forward=bool(a.deterministic)),
+                        deterministic_forward=bool(a.deterministic),
+                        sfa_gemm=None if a.no_sfa else (a.sfa_gemm or 'bf16x3') +
+                        ' (float32 operands cut into bf16 parts for the bf16 MFMA, float32 accumulate; bf16x3 = 2 parts / 3 products per a*b, '
+                        'stage output within 2.2e-5 of float64; bf16x6 = 3 parts / 6 products, float32-level; storage, element-wise '
+                        'arithmetic and statistics are float32 in both)'),
             roofline=dict(bound='hbm', kernel='mghs_stream_fwd', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s',
                           frac=achieved / HBM_PEAK_GBPS, traffic=pmc_traffic('mghs_stream_fwd', a.batch), launch_ms=kern_ms,
-                          algorithmic_bytes=hp.pool_fwd_bytes))
+                          algorithmic_bytes=hp.pool_fwd_bytes,
+                          # same-run, same-timer calibration streams over the same number of bytes (hbm_calibration)
+                          memset_ms=cal_ms['memset'], fill_ms=cal_ms['fill'], read_ms=cal_ms['read'], calibration_bytes=cal_bytes,
+                          frac_of_fill=cal_ms['fill'] / kern_ms, frac_of_memset=cal_ms['memset'] / kern_ms,
+                          fill_GBps=cal_bytes / (cal_ms['fill'] * 1e-3) / 1e9, read_GBps=cal_bytes / (cal_ms['read'] * 1e-3) / 1e9))
+        if elapsed_x6 is not None:
+            line['ms_per_step_bf16x6'] = 1e3 * elapsed_x6 / a.steps
+            line['value_bf16x6'] = a.batch * world * a.steps / elapsed_x6
         bwd_ms = float(np.mean([s.elapsed_time(e) for s, e in hp.ev_bwd]))
         bwd_ach = hp.pool_bwd_bytes / (bwd_ms * 1e-3) / 1e9
         line['roofline_bwd'] = dict(bound='hbm', kernel='mghs_stream_bwd + mghs_pixel_bwd (dhd_mghs_backward)', achieved=bwd_ach,
@@ -760,8 +815,8 @@ def main():
                 frac=fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, traffic=sfa_forward_traffic(a.batch), launch_ms=fwd_ms,
                 algorithmic_bytes=fwd_bytes,
                 backward_ms=bwd_ms, gemm_tflops_fp32_equivalent=6 * gemm_flop / ((fwd_ms + bwd_ms) * 1e-3) / 1e12,
-                note='six C x C GEMMs per forward+backward; default GEMM mode bf16x3: float32 operands as two bf16 parts, three bf16 MFMA '
-                     'products per a*b (include/dhd_amd.h: dhd_sfa_set_gemm_mode); f32-MFMA peak is 157 TFLOP/s')
+                note='six C x C GEMMs per forward+backward; GEMM precision as config.sfa_gemm (include/dhd_amd.h: dhd_sfa_weights.gemm); '
+                     'f32-MFMA peak is 157 TFLOP/s')
     t_stage = time.perf_counter()
     if a.geometry == 'dhd-s' and not a.no_operator:
         op_roof = operator_roofline(hp, max(5, min(a.steps, 20)), 3)   # every rank runs it, rank 0 reports

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DHD_AMD_LIB', os.path.join(_HERE, 'csrc', 'libdhd_amd.so'))
 
 DHD_MAX_GRIDS = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _ERRORS = {-1: 'DHD_EINVAL (bad argument)', -2: 'DHD_ENOSPACE (workspace too small)',
            -3: 'DHD_EUNSUPPORTED (size outside supported range)'}
@@ -31,7 +31,15 @@ class Grid(C.Structure):
 class MghsDesc(C.Structure):
     _fields_ = [('batch', C.c_int32), ('n_cams', C.c_int32), ('n_depth', C.c_int32),
                 ('fh', C.c_int32), ('fw', C.c_int32), ('channels', C.c_int32), ('n_grids', C.c_int32),
-                ('grid', Grid * DHD_MAX_GRIDS)]
+                ('grid', Grid * DHD_MAX_GRIDS), ('flags', C.c_int32)]
+
+
+MGHS_DETERMINISTIC = 1     # dhd_mghs_desc.flags
+MGHS_FEAT_GRAD_NCHW = 2
+
+
+class MghsWorkspace(C.Structure):
+    _fields_ = [('state', C.c_void_p), ('state_bytes', C.c_size_t), ('scratch', C.c_void_p), ('scratch_bytes', C.c_size_t)]
 
 
 class TensorView(C.Structure):
@@ -49,7 +57,10 @@ class SfaWeights(C.Structure):
                  ('fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'conv1_w', 'conv1_b', 'bn1_w', 'bn1_b', 'bn1_mean', 'bn1_var',
                   'conv2_w', 'conv2_b', 'bn2_w', 'bn2_b', 'bn2_mean', 'bn2_var')] +
                 [('hidden', C.c_int32), ('training', C.c_int32), ('eps1', C.c_float), ('eps2', C.c_float),
-                 ('momentum1', C.c_float), ('momentum2', C.c_float)])
+                 ('momentum1', C.c_float), ('momentum2', C.c_float), ('gemm', C.c_int32)])
+
+
+SFA_GEMM = {'default': 0, 'bf16x6': 1, 'f32': 2, 'bf16x3': 3}   # dhd_sfa_weights.gemm
 
 
 class SfaGrads(C.Structure):
@@ -64,22 +75,25 @@ _PROTOTYPES = {
     'dhd_abi_version': ([], _I),
     'dhd_bev_pool_v2_forward': ([_P] * 8 + [_I, _I, _P], _I),
     'dhd_bev_pool_v2_backward': ([_P] * 10 + [_I, _I, _P], _I),
-    'dhd_mghs_workspace_bytes': ([C.POINTER(MghsDesc), C.POINTER(C.c_size_t)], _I),
+    'dhd_mghs_workspace_bytes': ([C.POINTER(MghsDesc), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], _I),
     'dhd_height_band': ([_P, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P], _I),
     'dhd_feat_nchw_to_nhwc': ([_P, _P, _I, _I, _I, _P], _I),
     'dhd_feat_nhwc_to_nchw': ([_P, _P, _I, _I, _I, _P], _I),
-    'dhd_mghs_prepare': ([C.POINTER(MghsDesc), C.POINTER(Calib), _P, _P, C.c_size_t, _P], _I),
-    'dhd_mghs_forward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P], _I),
-    'dhd_mghs_forward_gather': ([C.POINTER(MghsDesc), _P, _P, _P, _P], _I),
-    'dhd_mghs_forward_stream': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P], _I),
-    'dhd_mghs_forward_views': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(TensorView * DHD_MAX_GRIDS), _P, _P], _I),
-    'dhd_mghs_backward_views': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(TensorView * DHD_MAX_GRIDS), _P, _P, _P, _P], _I),
-    'dhd_mghs_backward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P, _P, _P], _I),
+    'dhd_mghs_prepare': ([C.POINTER(MghsDesc), C.POINTER(Calib), _P, C.POINTER(MghsWorkspace), _P], _I),
+    'dhd_mghs_lift': ([C.POINTER(MghsDesc), C.POINTER(Calib), _P, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _P,
+                       C.POINTER(MghsWorkspace), _P], _I),
+    'dhd_mghs_lift_static': ([C.POINTER(MghsDesc), C.POINTER(Calib), _P, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _P,
+                              C.POINTER(MghsWorkspace), _P], _I),
+    'dhd_mghs_forward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), C.POINTER(MghsWorkspace), _P], _I),
+    'dhd_mghs_forward_gather': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(MghsWorkspace), _P], _I),
+    'dhd_mghs_forward_stream': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), C.POINTER(MghsWorkspace), _P], _I),
+    'dhd_mghs_forward_views': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(TensorView * DHD_MAX_GRIDS), C.POINTER(MghsWorkspace), _P], _I),
+    'dhd_mghs_backward_views': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(TensorView * DHD_MAX_GRIDS), _P, _P, C.POINTER(MghsWorkspace), _P], _I),
+    'dhd_mghs_backward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P, C.POINTER(MghsWorkspace), _P], _I),
     'dhd_mghs_voxel_index': ([C.POINTER(MghsDesc), C.POINTER(Calib), _I, _P, _P, _P], _I),
-    'dhd_mghs_set_deterministic': ([_I], _I),
-    'dhd_mghs_get_deterministic': ([], _I),
-    'dhd_mghs_stats': ([C.POINTER(MghsDesc), _P, C.POINTER(C.c_int32 * DHD_MAX_GRIDS),
+    'dhd_mghs_stats': ([C.POINTER(MghsDesc), C.POINTER(MghsWorkspace), C.POINTER(C.c_int32 * DHD_MAX_GRIDS),
                         C.POINTER(C.c_int32 * DHD_MAX_GRIDS), _P], _I),
+    'dhd_hbm_calibrate': ([_P, C.c_size_t, _I, _P], _I),
     'dhd_sfa_channel_mean': ([_P, _P, _I, _I, _I, _P], _I),
     'dhd_sfa_blend1': ([_P, _P, _P, _I, _I, _I, _P], _I),
     'dhd_sfa_blend2': ([_P, _P, _P, _P, _I, _I, _I, _P], _I),
@@ -87,7 +101,6 @@ _PROTOTYPES = {
     'dhd_sfa_blend1_backward': ([_P] * 5 + [_I, _I, _I, _P], _I),
     'dhd_sfa_mean_backward': ([_P, _P, _I, _I, _I, _P], _I),
     'dhd_sfa_stage_supported': ([_I, _I], _I),
-    'dhd_sfa_set_gemm_mode': ([_I], _I),
     'dhd_sfa_stage_saved_bytes': ([_I, _I, _I, _I], C.c_size_t),
     'dhd_sfa_stage_scratch_bytes': ([_I, _I, _I, _I], C.c_size_t),
     'dhd_sfa_stage_forward': ([_P, C.POINTER(SfaWeights), _P, _P, _P, _I, _I, _I, _P], _I),

@@ -39,31 +39,41 @@ struct Layout {
   // generic dense-row path
   int nxc;                        // x chunks per row
   int sched_heavy, sched_ratio;   // grid-0 row groups front-loaded 1:ratio among the others
-  // workspace carve (device pointers)
-  int* count;      // [V]     entries per voxel
+  int flags;       // dhd_mghs_desc.flags
+  // scratch carve (device pointers): valid from prepare to the forward after it
+  int* count;      // [V]     entries per voxel                      } one contiguous, zero-filled range per prepare:
+  unsigned long long* scan_state;  // [n_chunks] look-back words       } count | scan_state | ticket
+  int* ticket;     // [64]    chunk ticket of the single-pass scan   }
   int* offset;     // [V+1]   exclusive prefix of count            (entry index space)
-  int* nzoff;      // [V+1]   exclusive prefix of (count > 0)      (non-empty voxel ordinal, "slot")
-  int* chunk_sum;  // [2*n_chunks]
   int* key;        // [2P]    voxel id of point p in grid 0 ([p]) and in its band grid ([P+p]); -1 = dropped
   int* rnk;        // [2P]    arrival rank of the point inside its voxel
   int* s_pid;      // [2P]    point id of every entry, entries grouped by voxel (index into depth)
   int* s_pix;      // [2P]    pixel id of every entry (row of feat_nhwc)
   int* s_slot;     // [2P]    slot (non-empty voxel ordinal) of every entry, non-decreasing
-  int* nzvox;      // [2P]    voxel id of every slot
-  int* p_slot;     // [2P]    slot of point p in grid 0 ([p]) and in its band grid ([P+p]); -1 = dropped
   float* cam;      // [B*N*kCamFloats] per-camera matrices
   float* dg_part;  // [2P]    backward scratch of the generic path: depth-gradient parts of grid 0 / band grid
-  float* vsum;     // [2P*kTileC] compact per-voxel rows: forward sums / backward extracted gradients
-                   //            (allocated for min(2P, V) slots, only when `compact`)
+  float* fg_stage; // [B*N*hw*C] generic path with DHD_MGHS_FEAT_GRAD_NCHW: the (B*N,fH,fW,C) gradient before its transposition
+  float* vsum;     // [(min(2P, V) + 1) * kTileC] compact per-voxel rows: forward sums / backward extracted gradients
+                   //            (only when `compact`)
+  // state carve: what the backward pass needs from prepare
+  int* nzoff;      // [V+1]   exclusive prefix of (count > 0)      (non-empty voxel ordinal, "slot")
+  int* nzvox;      // [min(2P, V)] voxel id of every slot
+  int* p_slot;     // [2P]    slot of point p in grid 0 ([p]) and in its band grid ([P+p]); -1 = dropped
+  size_t zero_bytes;  // bytes of the count | scan_state | ticket range
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-inline int make_layout(const dhd_mghs_desc* d, void* ws, Layout* L, size_t* bytes) {
+// Fills *L from the description; with `ws` also carves the device pointers and checks the sizes.  state_bytes /
+// scratch_bytes (optional) receive the sizes needed.
+inline int make_layout(const dhd_mghs_desc* d, const dhd_mghs_workspace* ws, Layout* L, size_t* state_bytes = nullptr,
+                       size_t* scratch_bytes = nullptr) {
   if (!d) return DHD_EINVAL;
   if (d->batch <= 0 || d->n_cams <= 0 || d->n_depth <= 0 || d->fh <= 0 || d->fw <= 0 || d->channels <= 0)
     return DHD_EINVAL;
   if (d->n_grids < 1 || d->n_grids > DHD_MAX_GRIDS) return DHD_EINVAL;
+  if (d->flags & ~(DHD_MGHS_DETERMINISTIC | DHD_MGHS_FEAT_GRAD_NCHW)) return DHD_EINVAL;
+  L->flags = d->flags;
   L->B = d->batch; L->N = d->n_cams; L->D = d->n_depth; L->fh = d->fh; L->fw = d->fw;
   L->C = d->channels; L->G = d->n_grids;
   L->hw = d->fh * d->fw;
@@ -108,28 +118,41 @@ inline int make_layout(const dhd_mghs_desc* d, void* ws, Layout* L, size_t* byte
     if (k == 1) k = 0;
     if (k >= 2) { L->sched_heavy = heavy; L->sched_ratio = k; }
   }
-  if (ws && (reinterpret_cast<uintptr_t>(ws) & 255)) return DHD_EINVAL;  // 16-byte vector access to the carved arrays
-  size_t off = 0;
-  char* base = static_cast<char*>(ws);
-  auto carve = [&](size_t n_words) { int* p = reinterpret_cast<int*>(base + off); off = align_up(off + n_words * 4, 256); return p; };
+  if (ws) {
+    if (!ws->state || !ws->scratch) return DHD_EINVAL;
+    // 16-byte vector access to the carved arrays
+    if ((reinterpret_cast<uintptr_t>(ws->state) | reinterpret_cast<uintptr_t>(ws->scratch)) & 255) return DHD_EINVAL;
+  }
   const size_t P2 = 2 * (size_t)L->P;
+  const size_t max_slots = P2 < (size_t)L->V ? P2 : (size_t)L->V;
+  L->n_slots_max = (int)max_slots;
+  size_t off = 0;
+  char* base = ws ? static_cast<char*>(ws->scratch) : nullptr;
+  auto carve = [&](size_t n_words) { int* p = reinterpret_cast<int*>(base + off); off = align_up(off + n_words * 4, 256); return p; };
   L->count = carve((size_t)L->V);
+  L->scan_state = reinterpret_cast<unsigned long long*>(carve(2 * (size_t)L->n_chunks));
+  L->ticket = carve(64);
+  L->zero_bytes = off;
   L->offset = carve((size_t)L->V + 1);
-  L->nzoff = carve((size_t)L->V + 1);
-  L->chunk_sum = carve(2 * (size_t)L->n_chunks);
   L->key = carve(P2);
   L->rnk = carve(P2);
   L->s_pid = carve(P2);
   L->s_pix = carve(P2);
   L->s_slot = carve(P2);
-  L->nzvox = carve(P2 < (size_t)L->V ? P2 : (size_t)L->V);
-  L->p_slot = carve(P2);
   L->cam = reinterpret_cast<float*>(carve((size_t)L->B * L->N * kCamFloats));
-  L->dg_part = reinterpret_cast<float*>(carve(P2));
-  const size_t max_slots = P2 < (size_t)L->V ? P2 : (size_t)L->V;
-  L->n_slots_max = (int)max_slots;
+  L->dg_part = reinterpret_cast<float*>(carve(compact ? 0 : P2));
+  L->fg_stage = reinterpret_cast<float*>(carve(compact ? 0 : (size_t)L->B * L->N * L->hw * L->C));
   L->vsum = reinterpret_cast<float*>(carve(compact ? (max_slots + 1) * kTileC : 0));  // +1: scratch row for discarded stores
-  if (bytes) *bytes = off;
+  const size_t scratch_need = off;
+  off = 0;
+  base = ws ? static_cast<char*>(ws->state) : nullptr;
+  L->nzoff = carve((size_t)L->V + 1);
+  L->nzvox = carve(max_slots);
+  L->p_slot = carve(P2);
+  const size_t state_need = off;
+  if (state_bytes) *state_bytes = state_need;
+  if (scratch_bytes) *scratch_bytes = scratch_need;
+  if (ws && (ws->state_bytes < state_need || ws->scratch_bytes < scratch_need)) return DHD_ENOSPACE;
   return DHD_OK;
 }
 

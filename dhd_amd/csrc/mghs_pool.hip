@@ -21,6 +21,7 @@
 // data-dependent loops: the latency-bound gather lives in the balanced per-entry kernels.
 // A generic dense-row path (any C, any grid shape) is kept for configurations the compact path does
 // not cover.
+#include "lift_device.h"
 #include "mghs_layout.h"
 
 namespace dhd {
@@ -35,14 +36,6 @@ constexpr int kStreamWaves = kStreamBlock / DHD_WAVE;
 #define DHD_TABLE_FLOATS 8192
 #endif
 constexpr int kTableFloats = DHD_TABLE_FLOATS;  // LDS patch table: 128 voxels x 64 channels, or more voxels x fewer channels per pass
-
-#ifdef DHD_ABLATION
-// Experiment-only build (make ablate): phases can be switched off to price them.  Never in libdhd_amd.so.
-__device__ int g_ablate = 0;
-#define ABL(bit) ((g_ablate & (bit)) != 0)
-#else
-#define ABL(bit) false
-#endif
 
 // ---------------------------------------------------------------------------------------
 // Segments
@@ -219,7 +212,7 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
   if (t == 1) ctl[1] = L.nzoff[sg.v0 + sg.nvox];
   for (int i = t; i < kSegMaxVox / 2; i += kStreamBlock) reinterpret_cast<unsigned*>(slot_of)[i] = 0u;
   __syncthreads();
-  const int k0 = rfl(ctl[0]), nnz = ABL(32) ? 0 : rfl(ctl[1]) - k0;   // ABL(32): a pure zero stream through the same code
+  const int k0 = rfl(ctl[0]), nnz = rfl(ctl[1]) - k0;
   for (int j = t; j < nnz; j += kStreamBlock) slot_of[L.nzvox[k0 + j] - sg.v0] = (unsigned short)(j + 1);
   const int cp = channels_per_pass(nnz);
   const int nvec = sg.nvox / 4;
@@ -227,15 +220,12 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
   const long sb = out.sb[sg.g], sz = out.sz[sg.g], sc = out.sc[sg.g];
   for (int c_lo = 0; c_lo < kTileC; c_lo += cp) {
     __syncthreads();  // slot_of complete / previous pass done with the table
-    if (!ABL(8)) {
-      // table[j*cp + cc] = vsum[(k0+j)*64 + c_lo + cc]: runs of cp floats, coalesced
-      for (int i = t; i < nnz * cp; i += kStreamBlock) {
-        const int j = i / cp, cc = i % cp;
-        table[i] = L.vsum[(size_t)(k0 + j) * kTileC + c_lo + cc];
-      }
+    // table[j*cp + cc] = vsum[(k0+j)*64 + c_lo + cc]: runs of cp floats, coalesced
+    for (int i = t; i < nnz * cp; i += kStreamBlock) {
+      const int j = i / cp, cc = i % cp;
+      table[i] = L.vsum[(size_t)(k0 + j) * kTileC + c_lo + cc];
     }
     __syncthreads();
-    if (ABL(16)) continue;
     // The cp channel runs of this pass (nvec 16-byte vectors each) are one flat index space: iteration `it` of wave
     // `wv` stores vectors [(it * waves + wv) * 64, + 64).  With a wave per channel run, 200 vectors were 3 full
     // stores + one 8-lane store (32 store instructions per wave and pass for 25 stores' worth of bytes); flat, every
@@ -257,12 +247,8 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
         if (s3) v.w = table[(s3 - 1) * cp + cc];
       }
       vfloat4* dst = reinterpret_cast<vfloat4*>(base + (size_t)cc * sc) + i;
-#ifdef DHD_PLAIN_STORES
-      *dst = v;
-#else
       // streamed once, not re-read here: non-temporal, so the output stream does not evict vsum from L2
       __builtin_nontemporal_store(v, dst);
-#endif
       cc += q_step;
       i += r_step;
       if (i >= nvec) { i -= nvec; ++cc; }
@@ -431,7 +417,23 @@ __global__ __launch_bounds__(kBlock) void mghs_pixel_bwd(Layout L, const float* 
     v += __shfl_xor(v, 32, DHD_WAVE);
     fg[c] = v;
   }
-  if (es == 0) reinterpret_cast<vfloat4*>(feat_grad)[(size_t)q * (kTileC / 4) + cq] = fg;
+  if (es == 0) {
+    if (L.flags & DHD_MGHS_FEAT_GRAD_NCHW) {
+      // (B*N, C, fH, fW): channel 4 cq + c of pixel pl; the 64 four-byte stores of a pixel meet those of its row
+      // neighbours (the next waves of this XCD's pixel range) in L2 before the lines leave it
+      float* dst = feat_grad + ((size_t)bn * kTileC + 4 * cq) * L.hw + pl;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dst[(size_t)c * L.hw] = fg[c];
+    } else {
+      reinterpret_cast<vfloat4*>(feat_grad)[(size_t)q * (kTileC / 4) + cq] = fg;
+    }
+  }
+}
+
+// generic path with DHD_MGHS_FEAT_GRAD_NCHW: (bn, hw, C) -> (bn, C, hw)
+__global__ __launch_bounds__(kLiftBlock) void mghs_fg_to_nchw(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  __shared__ float tile[64][65];
+  transpose_tile(tile, src, dst, rows, cols, blockIdx.z, blockIdx.y * 64, blockIdx.x * 64);
 }
 
 // depth_grad = part(grid 0) + part(band grid)
@@ -661,14 +663,10 @@ using namespace dhd;
 
 extern "C" {
 
-#ifdef DHD_ABLATION
-int dhd_debug_set_ablation(int mask) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &mask, sizeof(int)); }
-#endif
-
-int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc, void* workspace,
+int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc, const dhd_mghs_workspace* workspace,
                             void* stream) {
   Layout L;
-  int rc = make_layout(desc, workspace, &L, nullptr);
+  int rc = make_layout(desc, workspace, &L);
   if (rc) return rc;
   if (!workspace || !depth || !feat_nhwc) return DHD_EINVAL;
   if (!L.compact) return DHD_OK;  // the generic path gathers inside its row kernel
@@ -680,10 +678,10 @@ int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const
 }
 
 static int forward_stream_impl(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                               float* const out[DHD_MAX_GRIDS], const dhd_tensor_view* views, void* workspace,
+                               float* const out[DHD_MAX_GRIDS], const dhd_tensor_view* views, const dhd_mghs_workspace* workspace,
                                void* stream) {
   Layout L;
-  int rc = make_layout(desc, workspace, &L, nullptr);
+  int rc = make_layout(desc, workspace, &L);
   if (rc) return rc;
   if (!workspace || !depth || !feat_nhwc || (!out && !views)) return DHD_EINVAL;
   OutPtrs o;
@@ -702,19 +700,19 @@ static int forward_stream_impl(const dhd_mghs_desc* desc, const float* depth, co
 }
 
 int dhd_mghs_forward_stream(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                            float* const out[DHD_MAX_GRIDS], void* workspace, void* stream) {
+                            float* const out[DHD_MAX_GRIDS], const dhd_mghs_workspace* workspace, void* stream) {
   return forward_stream_impl(desc, depth, feat_nhwc, out, nullptr, workspace, stream);
 }
 
 int dhd_mghs_forward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                     float* const out[DHD_MAX_GRIDS], void* workspace, void* stream) {
+                     float* const out[DHD_MAX_GRIDS], const dhd_mghs_workspace* workspace, void* stream) {
   int rc = dhd_mghs_forward_gather(desc, depth, feat_nhwc, workspace, stream);
   if (rc) return rc;
   return forward_stream_impl(desc, depth, feat_nhwc, out, nullptr, workspace, stream);
 }
 
 int dhd_mghs_forward_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                           const dhd_tensor_view out[DHD_MAX_GRIDS], void* workspace, void* stream) {
+                           const dhd_tensor_view out[DHD_MAX_GRIDS], const dhd_mghs_workspace* workspace, void* stream) {
   if (!out) return DHD_EINVAL;
   int rc = dhd_mghs_forward_gather(desc, depth, feat_nhwc, workspace, stream);
   if (rc) return rc;
@@ -723,9 +721,9 @@ int dhd_mghs_forward_views(const dhd_mghs_desc* desc, const float* depth, const 
 
 static int backward_impl(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                          const float* const out_grad[DHD_MAX_GRIDS], const dhd_tensor_view* views, float* depth_grad,
-                         float* feat_grad_nhwc, void* workspace, void* stream) {
+                         float* feat_grad_nhwc, const dhd_mghs_workspace* workspace, void* stream) {
   Layout L;
-  int rc = make_layout(desc, workspace, &L, nullptr);
+  int rc = make_layout(desc, workspace, &L);
   if (rc) return rc;
   if (!workspace || !depth || !feat_nhwc || (!out_grad && !views) || !depth_grad || !feat_grad_nhwc) return DHD_EINVAL;
   InPtrs in;
@@ -739,12 +737,19 @@ static int backward_impl(const dhd_mghs_desc* desc, const float* depth, const fl
     DHD_LAUNCH_CHECK();
     return DHD_OK;
   }
+  const bool to_nchw = (L.flags & DHD_MGHS_FEAT_GRAD_NCHW) != 0;
+  float* fg = to_nchw ? L.fg_stage : feat_grad_nhwc;
   DHD_HIP(hipMemsetAsync(L.dg_part, 0, 2 * (size_t)L.P * 4, st));
-  DHD_HIP(hipMemsetAsync(feat_grad_nhwc, 0, (size_t)L.B * L.N * L.hw * L.C * 4, st));
+  DHD_HIP(hipMemsetAsync(fg, 0, (size_t)L.B * L.N * L.hw * L.C * 4, st));
   int stride; size_t smem; dim3 grid;
   rows_launch_shape(L, &stride, &smem, &grid);
-  hipLaunchKernelGGL(mghs_rows_bwd, grid, dim3(kRowBlock), smem, st, L, depth, feat_nhwc, in, feat_grad_nhwc, stride);
+  hipLaunchKernelGGL(mghs_rows_bwd, grid, dim3(kRowBlock), smem, st, L, depth, feat_nhwc, in, fg, stride);
   DHD_LAUNCH_CHECK();
+  if (to_nchw) {
+    hipLaunchKernelGGL(mghs_fg_to_nchw, dim3(dhd_cdiv(L.C, 64), dhd_cdiv(L.hw, 64), L.B * L.N), dim3(kLiftBlock), 0, st, fg,
+                       feat_grad_nhwc, L.hw, L.C);
+    DHD_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(mghs_sum_parts, dim3(dhd_cdiv(L.P, kBlock)), dim3(kBlock), 0, st, L.dg_part, L.P, depth_grad);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
@@ -752,13 +757,13 @@ static int backward_impl(const dhd_mghs_desc* desc, const float* depth, const fl
 
 int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                       const float* const out_grad[DHD_MAX_GRIDS], float* depth_grad, float* feat_grad_nhwc,
-                      void* workspace, void* stream) {
+                      const dhd_mghs_workspace* workspace, void* stream) {
   return backward_impl(desc, depth, feat_nhwc, out_grad, nullptr, depth_grad, feat_grad_nhwc, workspace, stream);
 }
 
 int dhd_mghs_backward_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                             const dhd_tensor_view out_grad[DHD_MAX_GRIDS], float* depth_grad, float* feat_grad_nhwc,
-                            void* workspace, void* stream) {
+                            const dhd_mghs_workspace* workspace, void* stream) {
   if (!out_grad) return DHD_EINVAL;
   return backward_impl(desc, depth, feat_nhwc, nullptr, out_grad, depth_grad, feat_grad_nhwc, workspace, stream);
 }

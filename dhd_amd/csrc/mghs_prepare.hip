@@ -10,17 +10,11 @@
 // File:line citations are into /root/reference/projects/mmdet3d_plugin/.
 #include <stdlib.h>
 
+#include "lift_device.h"
 #include "mghs_layout.h"
 
 namespace dhd {
 namespace {
-
-#ifdef DHD_ABLATION
-__device__ int g_prep_ablate = 0;  // experiment-only build: 1 = skip the counting atomics
-#define PABL(bit) ((g_prep_ablate & (bit)) != 0)
-#else
-#define PABL(bit) false
-#endif
 
 // ---------------------------------------------------------------------------------------
 // Geometry.  The operation order, the absence of FMA contraction and the IEEE division are
@@ -143,14 +137,62 @@ __device__ __forceinline__ int voxel_of(const dhd_grid& g, const float* e, int b
 
 // One thread per camera: the two 3x3 inverses are ~25 serial IEEE divisions, far too slow to
 // repeat in the prologue of every geometry workgroup.
-__global__ __launch_bounds__(64) void mghs_camera(Layout L, dhd_calib cal) {
-  const int bn = blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void camera_block(const Layout& L, const dhd_calib& cal, int block) {
+  const int bn = block * kLiftBlock + threadIdx.x;
   if (bn >= L.B * L.N) return;
   CamMats m;
   load_camera(cal, bn, bn / L.N, &m);
   float* dst = L.cam + (size_t)bn * kCamFloats;
   const float* src = reinterpret_cast<const float*>(&m);
   for (int i = 0; i < (int)(sizeof(CamMats) / 4); ++i) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// Prologue: everything of a lift that depends on nothing computed before it, as the roles of ONE launch (a block
+// takes the role its index falls into): zero-fill of the counters and of the scan's look-back words, the per-camera
+// matrices, height argmax -> band id, NCHW -> NHWC of the context features.  (Round 2 issued them as a memset and
+// four kernels of 5-8 us each, none of which fills the chip.)
+// ---------------------------------------------------------------------------------------
+struct PrologueArgs {
+  int n_zero, n_cam, n_band, n_tr;   // blocks per role
+  // zero-fill: [zero_ptr, zero_ptr + zero_bytes), 256-byte aligned
+  char* zero_ptr;
+  size_t zero_bytes;
+  // band
+  const float* height;
+  int n_height;
+  uint8_t* band;
+  BandLut lut;
+  // transposition (bn, C, hw) -> (bn, hw, C)
+  const float* feat_nchw;
+  float* feat_nhwc;
+  int tr_cols_tiles, tr_rows_tiles, tr_vec;
+};
+constexpr int kZeroBytesPerBlock = kLiftBlock * 16 * 8;   // 32 KB per block: eight 16-byte stores per thread
+
+__global__ __launch_bounds__(kLiftBlock) void mghs_prologue(Layout L, dhd_calib cal, PrologueArgs a) {
+  __shared__ float tile[64][65];
+  int blk = blockIdx.x;
+  if (blk < a.n_zero) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i z = {0, 0, 0, 0};
+    const size_t lo = (size_t)blk * kZeroBytesPerBlock;
+    const size_t hi = lo + kZeroBytesPerBlock < a.zero_bytes ? lo + kZeroBytesPerBlock : a.zero_bytes;
+    for (size_t o = lo + (size_t)threadIdx.x * 16; o < hi; o += (size_t)kLiftBlock * 16) *reinterpret_cast<v4i*>(a.zero_ptr + o) = z;
+    return;
+  }
+  blk -= a.n_zero;
+  if (blk < a.n_cam) { camera_block(L, cal, blk); return; }
+  blk -= a.n_cam;
+  if (blk < a.n_band) { height_band_block(blk, a.height, L.B * L.N * L.hw, a.n_height, L.hw, a.lut, a.band); return; }
+  blk -= a.n_band;
+  if (blk < a.n_tr) {
+    const int per_b = a.tr_cols_tiles * a.tr_rows_tiles;
+    const int b = blk / per_b, rem = blk % per_b;
+    const int r0 = (rem / a.tr_cols_tiles) * 64, c0 = (rem % a.tr_cols_tiles) * 64;
+    if (a.tr_vec) transpose4_tile(tile, a.feat_nchw, a.feat_nhwc, L.C, L.hw, b, r0, c0);
+    else transpose_tile(tile, a.feat_nchw, a.feat_nhwc, L.C, L.hw, b, r0, c0);
+  }
 }
 
 // Counting with run aggregation.  A wave holds whole pixel COLUMNS of one depth plane: lane =
@@ -180,6 +222,9 @@ __device__ __forceinline__ int count_runs(int* __restrict__ count, int key, int 
   return valid ? base + (lane - leader) : 0;
 }
 
+// BAND_ONLY (static rig, dhd_mghs_lift_static): grid 0's keys, ranks and counters are those of the earlier full prepare
+// and are left alone; only the band grid's entry of every point is recomputed and counted.
+template <bool BAND_ONLY>
 __global__ __launch_bounds__(kBlock) void mghs_geom_count(Layout L, dhd_calib cal, const uint8_t* __restrict__ band) {
   __shared__ CamMats cam;
   const int bn = blockIdx.y;
@@ -200,8 +245,10 @@ __global__ __launch_bounds__(kBlock) void mghs_geom_count(Layout L, dhd_calib ca
   const int pid = bn * L.dhw + i;
   int k0 = -1, k1 = -1;
   if (in_range) {
-    const int v0 = voxel_of(L.grid[0], e, b);
-    if (v0 >= 0) k0 = L.vox_base[0] + v0;
+    if (!BAND_ONLY) {
+      const int v0 = voxel_of(L.grid[0], e, b);
+      if (v0 >= 0) k0 = L.vox_base[0] + v0;
+    }
     if (L.G > 1) {
       const int g = (int)band[bn * L.hw + h * L.fw + w] + 1;
       if (g < L.G) {
@@ -211,12 +258,10 @@ __global__ __launch_bounds__(kBlock) void mghs_geom_count(Layout L, dhd_calib ca
     }
   }
   int r0 = 0, r1 = 0;
-  if (!PABL(1)) {
-    r0 = count_runs(L.count, k0, hh, lane);
-    if (L.G > 1) r1 = count_runs(L.count, k1, hh, lane);
-  }
+  if (!BAND_ONLY) r0 = count_runs(L.count, k0, hh, lane);
+  if (L.G > 1) r1 = count_runs(L.count, k1, hh, lane);
   if (in_range) {
-    L.key[pid] = k0; L.rnk[pid] = r0;
+    if (!BAND_ONLY) { L.key[pid] = k0; L.rnk[pid] = r0; }
     L.key[L.P + pid] = k1; L.rnk[L.P + pid] = r1;
   }
 }
@@ -242,41 +287,28 @@ __global__ __launch_bounds__(kBlock) void mghs_voxel_index_kernel(Layout L, dhd_
 }
 
 // ---------------------------------------------------------------------------------------
-// Exclusive scans over the per-voxel counters (two launches: block sums, then scan + carry-in):
-// `offset` = prefix of count (entry index), `nzoff` = prefix of (count > 0) (slot index).
+// Exclusive scans over the per-voxel counters in ONE pass (decoupled look-back): `offset` = prefix of count (entry
+// index), `nzoff` = prefix of (count > 0) (slot index).  A block takes the next chunk of kChunk counters by ticket (so
+// every predecessor chunk has started), publishes its chunk aggregate, adds up its predecessors' published words
+// (64 at a time, one per lane of wave 0) until it meets one that already carries an inclusive prefix, and publishes its
+// own inclusive prefix.  A look-back word is one 64-bit value [status:2 | entries:31 | slots:31] (status 1 = chunk
+// aggregate, 2 = inclusive prefix), written and read with single relaxed device-scope atomics: value and flag cannot
+// tear, so no fences are needed.  (Round 2: a chunk-sum pass over count + a scan pass whose blocks re-added all earlier
+// chunk sums: 6 + 11 us at B = 4.)
 // ---------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(kBlock) void mghs_chunk_sum(const int* __restrict__ count, int V, int n_chunks,
-                                                          int* __restrict__ chunk_sum) {
-  __shared__ int ws[2][kBlock / DHD_WAVE];
-  const int base = blockIdx.x * kChunk;
-  int s = 0, z = 0;
-#pragma unroll
-  for (int k = 0; k < kScanItems; ++k) {
-    int i = base + k * kBlock + threadIdx.x;
-    if (i < V) { int c = count[i]; s += c; z += c > 0; }
-  }
-  s = wave_sum_i(s);
-  z = wave_sum_i(z);
-  if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = s; ws[1][threadIdx.x >> 6] = z; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    chunk_sum[blockIdx.x] = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
-    chunk_sum[n_chunks + blockIdx.x] = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
-  }
+__device__ __forceinline__ unsigned long long scan_word(int status, int entries, int slots) {
+  return ((unsigned long long)status << 62) | ((unsigned long long)(unsigned)entries << 31) | (unsigned long long)(unsigned)slots;
 }
 
 __global__ __launch_bounds__(kBlock) void mghs_scan(Layout L) {
-  __shared__ int ws[2][kBlock / DHD_WAVE];
   __shared__ int ws2[2][kBlock / DHD_WAVE];
+  __shared__ int s_chunk, s_excl[2];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int V = L.V;
-  int part = 0, partz = 0;
-  for (int j = t; j < (int)blockIdx.x; j += kBlock) { part += L.chunk_sum[j]; partz += L.chunk_sum[L.n_chunks + j]; }
-  part = wave_sum_i(part);
-  partz = wave_sum_i(partz);
-  if (lane == 0) { ws[0][wv] = part; ws[1][wv] = partz; }
-  const int first = blockIdx.x * kChunk + t * kScanItems;
+  if (t == 0) s_chunk = atomicAdd(L.ticket, 1);
+  __syncthreads();
+  const int chunk = s_chunk;
+  const int first = chunk * kChunk + t * kScanItems;
   int v[kScanItems];
   int tsum = 0, tz = 0;
   // a thread owns kScanItems = 8 consecutive counters: two 16-byte loads when the chunk lies inside [0, V)
@@ -301,8 +333,32 @@ __global__ __launch_bounds__(kBlock) void mghs_scan(Layout L) {
   }
   if (lane == 63) { ws2[0][wv] = incl; ws2[1][wv] = inclz; }
   __syncthreads();
-  int run = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
-  int runz = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
+  if (wv == 0) {
+    const int agg = ws2[0][0] + ws2[0][1] + ws2[0][2] + ws2[0][3];
+    const int aggz = ws2[1][0] + ws2[1][1] + ws2[1][2] + ws2[1][3];
+    if (lane == 0 && chunk > 0)
+      __hip_atomic_store(L.scan_state + chunk, scan_word(1, agg, aggz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ex = 0, exz = 0;
+    for (int j = chunk - 1; j >= 0; j -= DHD_WAVE) {
+      const int idx = j - lane;
+      unsigned long long w = scan_word(2, 0, 0);          // before chunk 0: an inclusive prefix of nothing
+      if (idx >= 0) {
+        do { w = __hip_atomic_load(L.scan_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 62) == 0);
+      }
+      const unsigned long long done = __ballot((w >> 62) == 2);
+      const int stop = done ? __builtin_ctzll(done) : DHD_WAVE;   // nearest predecessor that carries an inclusive prefix
+      const int e = lane <= stop ? (int)((w >> 31) & 0x7fffffffu) : 0, z = lane <= stop ? (int)(w & 0x7fffffffu) : 0;
+      ex += wave_sum_i(e);
+      exz += wave_sum_i(z);
+      if (done) break;
+    }
+    if (lane == 0) {
+      __hip_atomic_store(L.scan_state + chunk, scan_word(2, ex + agg, exz + aggz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_excl[0] = ex; s_excl[1] = exz;
+    }
+  }
+  __syncthreads();
+  int run = s_excl[0], runz = s_excl[1];
   for (int k = 0; k < wv; ++k) { run += ws2[0][k]; runz += ws2[1][k]; }
   run += incl - tsum;
   runz += inclz - tz;
@@ -328,6 +384,8 @@ __global__ __launch_bounds__(kBlock) void mghs_scan(Layout L) {
   }
 }
 
+// J0 = 1: only the band grid's entries (static rig: grid 0's part of the sorted lists is already in place)
+template <int J0>
 __global__ __launch_bounds__(kBlock) void mghs_scatter(Layout L, int blocks_per_bn) {
   // workgroups go round-robin over the XCDs: XCD x takes the x-th eighth of the points, so that the 4-byte
   // scatters into one cache line of the sorted arrays mostly come from one L2
@@ -340,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void mghs_scatter(Layout L, int blocks_per_
   const int pid = bn * L.dhw + i;
   const int pix = bn * L.hw + (i % L.hw);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = J0; j < 2; ++j) {
     int k = L.key[j * L.P + pid];
     int slot = -1;
     if (k >= 0) {
@@ -359,8 +417,8 @@ __global__ __launch_bounds__(kBlock) void mghs_scatter(Layout L, int blocks_per_
 // entry list of its voxel -- 6 to 17 entries on average, at most a few hundred -- and rewrites its rank; the scatter
 // then runs a second time.  The per-voxel sums of the forward are then accumulated in ascending point order and two
 // runs are bit-identical.
-__global__ __launch_bounds__(kBlock) void mghs_rank_by_pid(Layout L) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kBlock) void mghs_rank_by_pid(Layout L, int t0) {
+  const int t = t0 + blockIdx.x * kBlock + threadIdx.x;
   if (t >= 2 * L.P) return;
   const int k = L.key[t];
   if (k < 0) return;
@@ -371,41 +429,14 @@ __global__ __launch_bounds__(kBlock) void mghs_rank_by_pid(Layout L) {
   L.rnk[t] = r;
 }
 
-int g_deterministic = -1;  // -1: not set yet (environment DHD_MGHS_DETERMINISTIC decides at first use)
-
 }  // namespace
 }  // namespace dhd
 
 using namespace dhd;
 
-extern "C" {
+namespace {
 
-#ifdef DHD_ABLATION
-int dhd_debug_set_prepare_ablation(int mask) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prep_ablate), &mask, sizeof(int)); }
-#endif
-
-int dhd_abi_version(void) { return DHD_ABI_VERSION; }
-
-int dhd_mghs_set_deterministic(int on) {
-  g_deterministic = on ? 1 : 0;
-  return DHD_OK;
-}
-
-int dhd_mghs_get_deterministic(void) {
-  if (g_deterministic < 0) {
-    const char* e = getenv("DHD_MGHS_DETERMINISTIC");
-    g_deterministic = (e && e[0] && e[0] != '0') ? 1 : 0;
-  }
-  return g_deterministic;
-}
-
-int dhd_mghs_workspace_bytes(const dhd_mghs_desc* desc, size_t* bytes) {
-  if (!bytes) return DHD_EINVAL;
-  Layout L;
-  return make_layout(desc, nullptr, &L, bytes);
-}
-
-static int check_calib(const dhd_calib* c) {
+int check_calib(const dhd_calib* c) {
   if (!c || !c->sensor2ego || !c->post_tran || !c->bda || !c->frustum_u || !c->frustum_v || !c->frustum_d)
     return DHD_EINVAL;
   if (!c->inv_post_rot && !c->post_rot) return DHD_EINVAL;
@@ -413,48 +444,105 @@ static int check_calib(const dhd_calib* c) {
   return DHD_OK;
 }
 
-int dhd_mghs_prepare(const dhd_mghs_desc* desc, const dhd_calib* calib, const uint8_t* band, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+// prologue (zero-fill [+ cameras] [+ band + transposition]) -> geometry + counting -> scan -> scatter [-> ranking -> scatter]
+int lift_impl(const dhd_mghs_desc* desc, const dhd_calib* calib, const float* height, int n_height, const float* height_range,
+              const float* mask_range, const float* feat_nchw, uint8_t* band, float* feat_nhwc, const dhd_mghs_workspace* ws,
+              bool fused_lift, bool static_rig, void* stream) {
   Layout L;
-  size_t need = 0;
-  int rc = make_layout(desc, workspace, &L, &need);
+  if (!ws) return DHD_EINVAL;
+  int rc = make_layout(desc, ws, &L);
   if (rc) return rc;
-  if (!workspace) return DHD_EINVAL;
-  if (workspace_bytes < need) return DHD_ENOSPACE;
   if ((rc = check_calib(calib))) return rc;
   if (L.G > 1 && !band) return DHD_EINVAL;
-  hipStream_t st = dhd_stream(stream);
-  DHD_HIP(hipMemsetAsync(L.count, 0, (size_t)L.V * 4, st));
-  hipLaunchKernelGGL(mghs_camera, dim3(dhd_cdiv(L.B * L.N, 64)), dim3(64), 0, st, L, *calib);
-  DHD_LAUNCH_CHECK();
-  dim3 gp(dhd_cdiv(L.dhw, kBlock), L.B * L.N);
-  {
-    int hp = 1;
-    while (hp < L.fh) hp <<= 1;
-    if (hp > DHD_WAVE) return DHD_EUNSUPPORTED;  // feature maps taller than 64 rows
-    const long cols_per_block = (long)(kBlock / DHD_WAVE) * (DHD_WAVE / hp);
-    dim3 gc(dhd_cdiv((long)L.D * L.fw, cols_per_block), L.B * L.N);
-    hipLaunchKernelGGL(mghs_geom_count, gc, dim3(kBlock), 0, st, L, *calib, band);
+  int hp = 1;
+  while (hp < L.fh) hp <<= 1;
+  if (hp > DHD_WAVE) return DHD_EUNSUPPORTED;  // feature maps taller than 64 rows
+  PrologueArgs a = {};
+  if (fused_lift) {
+    if (!feat_nchw || !feat_nhwc) return DHD_EINVAL;
+    if (L.G > 1) {
+      if (!height || !height_range || !mask_range) return DHD_EINVAL;
+      if (n_height <= 0 || n_height > kMaxHeightBins) return DHD_EUNSUPPORTED;
+      make_band_lut(height_range, n_height, mask_range, &a.lut);
+      a.height = height; a.n_height = n_height; a.band = band;
+      a.n_band = dhd_cdiv((long)L.B * L.N * L.hw * kBandLanes, kLiftBlock);
+    }
+    a.feat_nchw = feat_nchw; a.feat_nhwc = feat_nhwc;
+    a.tr_cols_tiles = dhd_cdiv(L.hw, 64); a.tr_rows_tiles = dhd_cdiv(L.C, 64);
+    a.tr_vec = transpose_vectorisable(feat_nchw, feat_nhwc, L.C, L.hw) ? 1 : 0;
+    a.n_tr = a.tr_cols_tiles * a.tr_rows_tiles * L.B * L.N;
   }
+  // static rig: grid 0's counters stay (up to the last whole 256-byte block of them: the few counters of grid 0 in the
+  // block shared with grid 1 are re-counted... they are not -- so the boundary must be aligned); the band grids'
+  // counters, the look-back words and the ticket are cleared
+  size_t keep = 0;
+  if (static_rig) {
+    keep = (size_t)L.vox_base[1] * 4;
+    if (keep & 255) return DHD_EUNSUPPORTED;   // B * nz0 * ny0 * nx0 counters of grid 0 must end on a 256-byte boundary
+  }
+  a.zero_ptr = reinterpret_cast<char*>(L.count) + keep;
+  a.zero_bytes = L.zero_bytes - keep;
+  a.n_zero = dhd_cdiv((long)a.zero_bytes, kZeroBytesPerBlock);
+  a.n_cam = static_rig ? 0 : dhd_cdiv(L.B * L.N, kLiftBlock);
+  hipStream_t st = dhd_stream(stream);
+  hipLaunchKernelGGL(mghs_prologue, dim3(a.n_zero + a.n_cam + a.n_band + a.n_tr), dim3(kLiftBlock), 0, st, L, *calib, a);
   DHD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(mghs_chunk_sum, dim3(L.n_chunks), dim3(kBlock), 0, st, L.count, L.V, L.n_chunks, L.chunk_sum);
+  const dim3 gp(dhd_cdiv(L.dhw, kBlock), L.B * L.N);
+  const long cols_per_block = (long)(kBlock / DHD_WAVE) * (DHD_WAVE / hp);
+  const dim3 gc(dhd_cdiv((long)L.D * L.fw, cols_per_block), L.B * L.N);
+  if (static_rig) hipLaunchKernelGGL(mghs_geom_count<true>, gc, dim3(kBlock), 0, st, L, *calib, band);
+  else hipLaunchKernelGGL(mghs_geom_count<false>, gc, dim3(kBlock), 0, st, L, *calib, band);
   DHD_LAUNCH_CHECK();
   hipLaunchKernelGGL(mghs_scan, dim3(L.n_chunks), dim3(kBlock), 0, st, L);
   DHD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(mghs_scatter, dim3(dhd_cdiv((long)gp.x * gp.y, 8) * 8), dim3(kBlock), 0, st, L, (int)gp.x);
+  const dim3 gs(dhd_cdiv((long)gp.x * gp.y, 8) * 8);
+  if (static_rig) hipLaunchKernelGGL(mghs_scatter<1>, gs, dim3(kBlock), 0, st, L, (int)gp.x);
+  else hipLaunchKernelGGL(mghs_scatter<0>, gs, dim3(kBlock), 0, st, L, (int)gp.x);
   DHD_LAUNCH_CHECK();
-  if (dhd_mghs_get_deterministic()) {
-    hipLaunchKernelGGL(mghs_rank_by_pid, dim3(dhd_cdiv(2L * L.P, kBlock)), dim3(kBlock), 0, st, L);
-    hipLaunchKernelGGL(mghs_scatter, dim3(dhd_cdiv((long)gp.x * gp.y, 8) * 8), dim3(kBlock), 0, st, L, (int)gp.x);
+  if (L.flags & DHD_MGHS_DETERMINISTIC) {
+    const int t0 = static_rig ? L.P : 0;
+    hipLaunchKernelGGL(mghs_rank_by_pid, dim3(dhd_cdiv(2L * L.P - t0, kBlock)), dim3(kBlock), 0, st, L, t0);
+    if (static_rig) hipLaunchKernelGGL(mghs_scatter<1>, gs, dim3(kBlock), 0, st, L, (int)gp.x);
+    else hipLaunchKernelGGL(mghs_scatter<0>, gs, dim3(kBlock), 0, st, L, (int)gp.x);
     DHD_LAUNCH_CHECK();
   }
   return DHD_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int dhd_abi_version(void) { return DHD_ABI_VERSION; }
+
+int dhd_mghs_workspace_bytes(const dhd_mghs_desc* desc, size_t* state_bytes, size_t* scratch_bytes) {
+  if (!state_bytes || !scratch_bytes) return DHD_EINVAL;
+  Layout L;
+  return make_layout(desc, nullptr, &L, state_bytes, scratch_bytes);
+}
+
+int dhd_mghs_prepare(const dhd_mghs_desc* desc, const dhd_calib* calib, const uint8_t* band, const dhd_mghs_workspace* ws,
+                     void* stream) {
+  return lift_impl(desc, calib, nullptr, 0, nullptr, nullptr, nullptr, const_cast<uint8_t*>(band), nullptr, ws, false, false, stream);
+}
+
+int dhd_mghs_lift(const dhd_mghs_desc* desc, const dhd_calib* calib, const float* height, int n_height, const float* height_range,
+                  const float* mask_range, const float* feat_nchw, uint8_t* band, float* feat_nhwc, const dhd_mghs_workspace* ws,
+                  void* stream) {
+  return lift_impl(desc, calib, height, n_height, height_range, mask_range, feat_nchw, band, feat_nhwc, ws, true, false, stream);
+}
+
+int dhd_mghs_lift_static(const dhd_mghs_desc* desc, const dhd_calib* calib, const float* height, int n_height,
+                         const float* height_range, const float* mask_range, const float* feat_nchw, uint8_t* band,
+                         float* feat_nhwc, const dhd_mghs_workspace* ws, void* stream) {
+  if (!desc || desc->n_grids < 2) return DHD_EINVAL;   // with one grid nothing changes from frame to frame: reuse the workspace
+  return lift_impl(desc, calib, height, n_height, height_range, mask_range, feat_nchw, band, feat_nhwc, ws, true, true, stream);
+}
+
 int dhd_mghs_voxel_index(const dhd_mghs_desc* desc, const dhd_calib* calib, int grid_index, int32_t* rank_map,
                          float* ego, void* stream) {
   Layout L;
-  int rc = make_layout(desc, nullptr, &L, nullptr);
+  int rc = make_layout(desc, nullptr, &L);
   if (rc) return rc;
   if ((rc = check_calib(calib))) return rc;
   if (!rank_map || grid_index < 0 || grid_index >= L.G) return DHD_EINVAL;
@@ -465,12 +553,12 @@ int dhd_mghs_voxel_index(const dhd_mghs_desc* desc, const dhd_calib* calib, int 
   return DHD_OK;
 }
 
-int dhd_mghs_stats(const dhd_mghs_desc* desc, const void* workspace, int32_t n_kept[DHD_MAX_GRIDS],
+int dhd_mghs_stats(const dhd_mghs_desc* desc, const dhd_mghs_workspace* ws, int32_t n_kept[DHD_MAX_GRIDS],
                    int32_t n_intervals[DHD_MAX_GRIDS], void* stream) {
   Layout L;
-  int rc = make_layout(desc, const_cast<void*>(workspace), &L, nullptr);
+  if (!ws || !n_kept || !n_intervals) return DHD_EINVAL;
+  int rc = make_layout(desc, ws, &L);
   if (rc) return rc;
-  if (!workspace || !n_kept || !n_intervals) return DHD_EINVAL;
   hipStream_t st = dhd_stream(stream);
   DHD_HIP(hipStreamSynchronize(st));
   // not a hot path: read the two prefix arrays at the grid boundaries

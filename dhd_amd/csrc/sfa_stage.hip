@@ -2042,19 +2042,23 @@ inline int device_index() {
     }                                                                                                               \
   } while (0)
 
-// GEMM modes (dhd_sfa_set_gemm_mode):
-//   0  f32 MFMA (pw_gemm / pw_wgrad)
-//   1  bf16x6, weights resident in LDS (pw_gemm_res<3>): bit-identical to mode 2
-//   2  bf16x6, weights streamed per tile (pw_gemm6, with the 128-channel tail launch);  4: the same, single launch
+// GEMM precision of the current call (dhd_sfa_weights.gemm), carried in a thread-local for the duration of the entry
+// point -- per call, nothing process-wide.  Internal numbering:
+//   0  f32 MFMA (pw_gemm / pw_wgrad)                                                    DHD_SFA_GEMM_F32
+//   1  bf16x6: weights resident in LDS (pw_gemm_res<3>) where that form covers the channel count, else streamed per
+//      pixel tile (pw_gemm6, with the 128-channel tail launch); bit-identical results      DHD_SFA_GEMM_BF16X6
 //   3  bf16x3, weights resident in LDS (pw_gemm_res<2>): three products per a*b, relative error <= 3 * 2^-18 per
 //      product.  DEFAULT: measured against float64 at (2,512,200,200) the stage output is off by 2.2e-5 (bf16x6:
-//      1.2e-6, plain PyTorch fp32: 1.35e-6), well inside the 1e-3 bar of the path; the four forward / dgrad GEMMs
-//      take 118-131 us instead of 160-178 us at B = 4.  Modes 1 / 2 keep float32-level accuracy.
-int g_gemm_mode = [] {  // default 3; the environment variable DHD_SFA_GEMM_MODE=0..4 overrides it at load time
-  const char* e = getenv("DHD_SFA_GEMM_MODE");
-  const int m = e ? atoi(e) : 3;
-  return (e && m >= 0 && m <= 4) ? m : 3;
-}();
+//      1.2e-6, plain PyTorch fp32: 1.35e-6), well inside the 1e-3 bar of the path.         DHD_SFA_GEMM_BF16X3
+thread_local int g_gemm_mode = 3;
+inline int set_call_mode(int gemm) {
+  switch (gemm) {
+    case DHD_SFA_GEMM_DEFAULT: case DHD_SFA_GEMM_BF16X3: g_gemm_mode = 3; return DHD_OK;
+    case DHD_SFA_GEMM_BF16X6: g_gemm_mode = 1; return DHD_OK;
+    case DHD_SFA_GEMM_F32: g_gemm_mode = 0; return DHD_OK;
+    default: return DHD_EINVAL;
+  }
+}
 inline bool mode_streamed() { return g_gemm_mode == 2 || g_gemm_mode == 4; }
 inline bool mode_resident() { return g_gemm_mode == 1 || g_gemm_mode == 3; }
 inline int mode_terms() { return g_gemm_mode == 3 ? 2 : 3; }
@@ -2347,12 +2351,6 @@ int dhd_debug_res_timeline(unsigned long long* host, int n) {
 }
 #endif
 
-int dhd_sfa_set_gemm_mode(int mode) {
-  if (mode < 0 || mode > 4) return DHD_EINVAL;
-  g_gemm_mode = mode;
-  return DHD_OK;
-}
-
 int dhd_sfa_stage_supported(int c, int hw) { return stage_supported(c, hw) ? 1 : 0; }
 
 size_t dhd_sfa_stage_saved_bytes(int b, int c, int hw, int hidden) {
@@ -2373,6 +2371,7 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
       !w->conv2_b || !w->bn2_w || !w->bn2_b)
     return DHD_EINVAL;
   if (!w->training && (!w->bn1_mean || !w->bn1_var || !w->bn2_mean || !w->bn2_var)) return DHD_EINVAL;
+  if (set_call_mode(w->gemm) != DHD_OK) return DHD_EINVAL;
   hipStream_t st = dhd_stream(stream);
   const int r = w->hidden;
   const SavedLayout S = saved_layout(b, c, hw, r);
@@ -2444,6 +2443,7 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
   if (!grads->fc1_w || !grads->fc1_b || !grads->fc2_w || !grads->fc2_b || !grads->conv1_w || !grads->conv1_b || !grads->bn1_w ||
       !grads->bn1_b || !grads->conv2_w || !grads->conv2_b || !grads->bn2_w || !grads->bn2_b)
     return DHD_EINVAL;
+  if (set_call_mode(w->gemm) != DHD_OK) return DHD_EINVAL;
   hipStream_t st = dhd_stream(stream);
   const int r = w->hidden;
   const SavedLayout S = saved_layout(b, c, hw, r);

@@ -32,10 +32,67 @@ def grid_from_cfg(cfg):
     return grid_struct(lower.tolist(), interval.tolist(), size.tolist())
 
 
-class Plan:
-    """Static description of one view transform: sizes + grids (no device state)."""
+_default_deterministic = None   # module default of Plan(deterministic=None); None = environment DHD_MGHS_DETERMINISTIC
 
-    def __init__(self, batch, n_cams, n_depth, fh, fw, channels, grids):
+
+def set_deterministic(on=True):
+    """Default for plans built afterwards without an explicit `deterministic=` (Plan, MGHS modules): reproducible forward
+    sums, i.e. prepare orders the entries of every voxel by point id (include/dhd_amd.h: DHD_MGHS_DETERMINISTIC; one
+    ranking pass + a second scatter per prepare).  A Python-side default only: the C ABI takes the flag per call
+    (dhd_mghs_desc.flags), so two models in one process can differ by passing `deterministic=` themselves."""
+    global _default_deterministic
+    _default_deterministic = bool(on)
+
+
+def is_deterministic():
+    if _default_deterministic is None:
+        import os
+        return os.environ.get('DHD_MGHS_DETERMINISTIC', '0') not in ('', '0')
+    return _default_deterministic
+
+
+class _ScratchPool:
+    """Grow-only device scratch, one buffer per (device, stream, tag).  A larger request allocates a new buffer and
+    keeps the old ones alive: a captured HIP graph (or a kernel still in flight) may hold their raw pointers, and
+    memory handed back to the allocator could be given to someone else while they run.  Calls that share a buffer are
+    ordered by their stream, which is what scratch needs."""
+
+    def __init__(self):
+        self._cur = {}
+        self._retired = []
+
+    def get(self, device, nbytes, tag=''):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+        buf = self._cur.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                self._retired.append(buf)
+            buf = self._cur[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return buf
+
+    def bytes_held(self):
+        return sum(b.numel() for b in self._cur.values()) + sum(b.numel() for b in self._retired)
+
+
+scratch_pool = _ScratchPool()
+
+
+class Workspace:
+    """Device memory of one view transform (include/dhd_amd.h: dhd_mghs_workspace): `state` is what the backward pass
+    needs from prepare (held by the autograd graph), `scratch` everything else (shared per stream by default)."""
+
+    def __init__(self, state, scratch):
+        self.state, self.scratch = state, scratch
+        self.device = state.device
+        c = self.c = _lib.MghsWorkspace()
+        c.state, c.state_bytes = state.data_ptr(), state.numel()
+        c.scratch, c.scratch_bytes = scratch.data_ptr(), scratch.numel()
+
+
+class Plan:
+    """Static description of one view transform: sizes + grids + flags (no device state)."""
+
+    def __init__(self, batch, n_cams, n_depth, fh, fw, channels, grids, deterministic=None, feat_grad_nchw=False):
         if not 1 <= len(grids) <= _lib.DHD_MAX_GRIDS:
             raise ValueError('1..4 grids')
         d = _lib.MghsDesc()
@@ -43,18 +100,27 @@ class Plan:
         d.n_grids = len(grids)
         for i in range(_lib.DHD_MAX_GRIDS):
             d.grid[i] = grids[min(i, len(grids) - 1)]
+        self.deterministic = is_deterministic() if deterministic is None else bool(deterministic)
+        self.feat_grad_nchw = bool(feat_grad_nchw)
+        d.flags = (_lib.MGHS_DETERMINISTIC if self.deterministic else 0) | (_lib.MGHS_FEAT_GRAD_NCHW if feat_grad_nchw else 0)
         self.desc = d
         self.grids = list(grids)
-        nbytes = C.c_size_t(0)
-        _lib.check(_lib.load().dhd_mghs_workspace_bytes(C.byref(d), C.byref(nbytes)), 'dhd_mghs_workspace_bytes')
-        self.workspace_bytes = int(nbytes.value)
+        st, sc = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(_lib.load().dhd_mghs_workspace_bytes(C.byref(d), C.byref(st), C.byref(sc)), 'dhd_mghs_workspace_bytes')
+        self.state_bytes, self.scratch_bytes = int(st.value), int(sc.value)
 
     def out_shapes(self):
         d = self.desc
         return [(d.batch, g.n[2] * d.channels, g.n[1], g.n[0]) for g in self.grids]
 
-    def new_workspace(self, device):
-        return torch.empty(self.workspace_bytes, dtype=torch.uint8, device=device)
+    def new_workspace(self, device, private_scratch=False):
+        """A fresh state + the stream's shared scratch (or, `private_scratch`, one of its own: needed when the prepared
+        grouping must survive other view transforms on the stream, e.g. a static-rig cache)."""
+        device = torch.device(device)
+        state = torch.empty(self.state_bytes, dtype=torch.uint8, device=device)
+        scratch = (torch.empty(self.scratch_bytes, dtype=torch.uint8, device=device) if private_scratch
+                   else scratch_pool.get(device, self.scratch_bytes, 'mghs'))
+        return Workspace(state, scratch)
 
 
 def _f32(t, name):
@@ -91,9 +157,7 @@ def height_band(height, height_range, mask_range):
     bn, nh, fh, fw = h.shape
     if nh != len(height_range):
         raise ValueError('height has %d bins, height_range %d' % (nh, len(height_range)))
-    # float32 values exactly as torch.tensor(height_range) and the python-scalar comparisons see them
-    hr = (C.c_float * nh)(*torch.tensor(height_range, dtype=torch.float32).tolist())
-    mr = (C.c_float * 4)(*torch.tensor(list(mask_range), dtype=torch.float32).tolist())
+    hr, mr = _range_arrays(height_range, mask_range)
     band = torch.empty((bn, fh, fw), dtype=torch.uint8, device=h.device)
     with torch.cuda.device(h.device):
         rc = lib.dhd_height_band(_lib.ptr(h), bn, nh, fh, fw, hr, mr, _lib.ptr(band), _lib.stream_ptr(h.device))
@@ -121,25 +185,48 @@ def _nhwc_to_nchw(x):
     return out
 
 
-def set_deterministic(on=True):
-    """Reproducible forward sums: prepare orders the entries of every voxel by point id (include/dhd_amd.h:
-    dhd_mghs_set_deterministic); costs one ranking pass + a second scatter per prepare.  Process-wide."""
-    _lib.check(_lib.load().dhd_mghs_set_deterministic(int(bool(on))), 'dhd_mghs_set_deterministic')
-
-
-def is_deterministic():
-    return bool(_lib.load().dhd_mghs_get_deterministic())
-
-
 def prepare(plan, calib, band, workspace):
     lib = _lib.load()
     dev = workspace.device
     if band is not None:
         _lib.require_gpu_tensor(band, torch.uint8, 'band')
     with torch.cuda.device(dev):
-        rc = lib.dhd_mghs_prepare(C.byref(plan.desc), C.byref(calib), _lib.ptr(band), _lib.ptr(workspace),
-                                  workspace.numel(), _lib.stream_ptr(dev))
+        rc = lib.dhd_mghs_prepare(C.byref(plan.desc), C.byref(calib), _lib.ptr(band), C.byref(workspace.c), _lib.stream_ptr(dev))
     _lib.check(rc, 'dhd_mghs_prepare')
+
+
+def _range_arrays(height_range, mask_range):
+    # float32 values exactly as torch.tensor(height_range) and the python-scalar comparisons see them
+    hr = (C.c_float * len(height_range))(*torch.tensor(list(height_range), dtype=torch.float32).tolist())
+    mr = (C.c_float * 4)(*torch.tensor(list(mask_range), dtype=torch.float32).tolist())
+    return hr, mr
+
+
+def lift(plan, calib, height, height_range, mask_range, tran_feat, workspace, static=False):
+    """The lift side of MGHS.view_transform in one C call (dhd_mghs_lift: band ids from the height distribution, the
+    context re-laid out to (B*N,fH,fW,C), geometry + grouping).  height may be None for a single-grid plan.  `static`:
+    dhd_mghs_lift_static -- `workspace` holds an earlier lift of the same plan and calibration.
+    Returns (band or None, feat_nhwc)."""
+    lib = _lib.load()
+    tf = _lib.require_gpu_tensor(tran_feat, torch.float32, 'tran_feat')
+    bn, c, fh, fw = tf.shape
+    dev = tf.device
+    band, hptr, nh, hr, mr = None, None, 0, None, None
+    if plan.desc.n_grids > 1:
+        h = _f32(height.float().contiguous(), 'height')
+        nh = h.shape[1]
+        if nh != len(height_range):
+            raise ValueError('height has %d bins, height_range %d' % (nh, len(height_range)))
+        hr, mr = _range_arrays(height_range, mask_range)
+        band = torch.empty((bn, fh, fw), dtype=torch.uint8, device=dev)
+        hptr = _lib.ptr(h)
+    feat_nhwc = torch.empty((bn, fh, fw, c), dtype=torch.float32, device=dev)
+    fn = lib.dhd_mghs_lift_static if static else lib.dhd_mghs_lift
+    with torch.cuda.device(dev):
+        rc = fn(C.byref(plan.desc), C.byref(calib), hptr, nh, hr, mr, _lib.ptr(tf), _lib.ptr(band), _lib.ptr(feat_nhwc),
+                C.byref(workspace.c), _lib.stream_ptr(dev))
+    _lib.check(rc, 'dhd_mghs_lift_static' if static else 'dhd_mghs_lift')
+    return band, feat_nhwc
 
 
 def _ptr_array(tensors):
@@ -156,7 +243,7 @@ def pool_forward(plan, depth, feat_nhwc, workspace):
     arr = _ptr_array(outs)
     with torch.cuda.device(dev):
         rc = lib.dhd_mghs_forward(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
-                                  _lib.ptr(workspace), _lib.stream_ptr(dev))
+                                  C.byref(workspace.c), _lib.stream_ptr(dev))
     _lib.check(rc, 'dhd_mghs_forward')
     return outs
 
@@ -171,11 +258,11 @@ def pool_forward_phases(plan, depth, feat_nhwc, workspace, between=None):
     with torch.cuda.device(dev):
         st = _lib.stream_ptr(dev)
         _lib.check(lib.dhd_mghs_forward_gather(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc),
-                                               _lib.ptr(workspace), st), 'dhd_mghs_forward_gather')
+                                               C.byref(workspace.c), st), 'dhd_mghs_forward_gather')
         if between is not None:
             between()
         _lib.check(lib.dhd_mghs_forward_stream(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
-                                               _lib.ptr(workspace), st), 'dhd_mghs_forward_stream')
+                                               C.byref(workspace.c), st), 'dhd_mghs_forward_stream')
     return outs
 
 
@@ -183,11 +270,12 @@ def pool_backward(plan, depth, feat_nhwc, out_grads, workspace):
     lib = _lib.load()
     dev = depth.device
     depth_grad = torch.empty_like(depth)
-    feat_grad = torch.empty_like(feat_nhwc)
+    bn, fh, fw, c = feat_nhwc.shape
+    feat_grad = torch.empty((bn, c, fh, fw) if plan.feat_grad_nchw else (bn, fh, fw, c), dtype=torch.float32, device=dev)
     arr = _ptr_array(out_grads)
     with torch.cuda.device(dev):
         rc = lib.dhd_mghs_backward(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
-                                   _lib.ptr(depth_grad), _lib.ptr(feat_grad), _lib.ptr(workspace),
+                                   _lib.ptr(depth_grad), _lib.ptr(feat_grad), C.byref(workspace.c),
                                    _lib.stream_ptr(dev))
     _lib.check(rc, 'dhd_mghs_backward')
     return depth_grad, feat_grad
@@ -241,30 +329,29 @@ def _views(plan, layout, tensors):
 
 
 class _MGHSPool(torch.autograd.Function):
-    """depth (B*N,D,fH,fW), tran_feat (B*N,C,fH,fW) -> pooled tensors in the requested layout."""
+    """depth (B*N,D,fH,fW), tran_feat (B*N,C,fH,fW) -> pooled tensors in the requested layout.  `feat_nhwc` is the
+    re-laid-out context the lift produced for `workspace` (mghs_op.lift); tran_feat itself only carries the gradient."""
 
     @staticmethod
-    def forward(ctx, depth, tran_feat, plan, workspace, layout='collapsed'):
+    def forward(ctx, depth, tran_feat, plan, workspace, feat_nhwc, layout='collapsed'):
         # float32 only: callers cast outside the node (see mghs_pool) so that autograd casts the
         # gradients back to whatever dtype an autocast region produced
         depth = _lib.require_gpu_tensor(depth.contiguous(), torch.float32, 'depth')
-        tran_feat = _lib.require_gpu_tensor(tran_feat.contiguous(), torch.float32, 'tran_feat')
-        feat_nhwc = _nchw_to_nhwc(tran_feat)
         lib = _lib.load()
         dev = depth.device
         outs = _alloc_outputs(plan, layout, dev)
         arr = _views(plan, layout, outs)
         with torch.cuda.device(dev):
             rc = lib.dhd_mghs_forward_views(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
-                                            _lib.ptr(workspace), _lib.stream_ptr(dev))
+                                            C.byref(workspace.c), _lib.stream_ptr(dev))
         _lib.check(rc, 'dhd_mghs_forward_views')
         ctx.plan, ctx.layout = plan, layout
-        ctx.save_for_backward(depth, feat_nhwc, workspace)
+        ctx.save_for_backward(depth, feat_nhwc, workspace.state)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
-        depth, feat_nhwc, workspace = ctx.saved_tensors
+        depth, feat_nhwc, state = ctx.saved_tensors
         plan, layout = ctx.plan, ctx.layout
         lib = _lib.load()
         dev = depth.device
@@ -272,14 +359,16 @@ class _MGHSPool(torch.autograd.Function):
         gs = [torch.zeros(s, dtype=torch.float32, device=dev) if g is None else g.float().contiguous()
               for g, s in zip(grads, shapes)]
         arr = _views(plan, layout, gs)
-        depth_grad = torch.empty_like(depth)
-        feat_grad = torch.empty_like(feat_nhwc)
+        bn, fh, fw, c = feat_nhwc.shape
         with torch.cuda.device(dev):
+            # the scratch of the stream the backward runs on (autograd replays the forward's stream)
+            ws = Workspace(state, scratch_pool.get(dev, plan.scratch_bytes, 'mghs'))
+            depth_grad = torch.empty_like(depth)
+            feat_grad = torch.empty((bn, c, fh, fw) if plan.feat_grad_nchw else (bn, fh, fw, c), dtype=torch.float32, device=dev)
             rc = lib.dhd_mghs_backward_views(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
-                                             _lib.ptr(depth_grad), _lib.ptr(feat_grad), _lib.ptr(workspace),
-                                             _lib.stream_ptr(dev))
+                                             _lib.ptr(depth_grad), _lib.ptr(feat_grad), C.byref(ws.c), _lib.stream_ptr(dev))
         _lib.check(rc, 'dhd_mghs_backward_views')
-        return depth_grad, _nhwc_to_nchw(feat_grad), None, None, None
+        return depth_grad, (feat_grad if plan.feat_grad_nchw else _nhwc_to_nchw(feat_grad)), None, None, None, None
 
 
 class _Shape:
@@ -299,12 +388,24 @@ def _alloc_shapes(plan, layout):
 
 
 def mghs_pool(plan, calib, band, depth, tran_feat, workspace=None, layout='collapsed'):
-    """Prepare (geometry + grouping) and pool.  `workspace` may be passed to reuse memory in
-    inference; under autograd a fresh one is held by the graph until backward has run."""
+    """Prepare (geometry + grouping) from a given band map and pool.  `workspace` may be passed to reuse memory in
+    inference; under autograd a fresh state is held by the graph until backward has run."""
     if workspace is None:
         workspace = plan.new_workspace(depth.device)
     prepare(plan, calib, band, workspace)
-    return _MGHSPool.apply(depth.float(), tran_feat.float(), plan, workspace, layout)
+    tf = _lib.require_gpu_tensor(tran_feat.float().contiguous(), torch.float32, 'tran_feat')
+    return _MGHSPool.apply(depth.float(), tf, plan, workspace, _nchw_to_nhwc(tf.detach()), layout)
+
+
+def mghs_lift_pool(plan, calib, height, height_range, mask_range, depth, tran_feat, workspace=None, layout='collapsed',
+                   static=False):
+    """MGHS.view_transform's whole device side: dhd_mghs_lift (band ids, context re-layout, geometry + grouping: four
+    launches) and the pooling node.  height: (B*N, H, fH, fW) distribution or logits (only its argmax matters)."""
+    if workspace is None:
+        workspace = plan.new_workspace(depth.device)
+    tf = tran_feat.float().contiguous()
+    _, feat_nhwc = lift(plan, calib, height, height_range, mask_range, tf.detach(), workspace, static=static)
+    return _MGHSPool.apply(depth.float(), tf, plan, workspace, feat_nhwc, layout)
 
 
 def voxel_index(plan, calib, grid_index, want_ego=False):
@@ -328,7 +429,7 @@ def stats(plan, workspace):
     kept = (C.c_int32 * _lib.DHD_MAX_GRIDS)()
     ivs = (C.c_int32 * _lib.DHD_MAX_GRIDS)()
     with torch.cuda.device(workspace.device):
-        rc = lib.dhd_mghs_stats(C.byref(plan.desc), _lib.ptr(workspace), C.byref(kept), C.byref(ivs),
+        rc = lib.dhd_mghs_stats(C.byref(plan.desc), C.byref(workspace.c), C.byref(kept), C.byref(ivs),
                                 _lib.stream_ptr(workspace.device))
     _lib.check(rc, 'dhd_mghs_stats')
     n = plan.desc.n_grids

@@ -89,17 +89,23 @@ class _AttentionStage(torch.autograd.Function):
         return (gx, None) + (None,) * len(ctx.needs_input_grad[2:])
 
 
-_scratch = {}  # (device, bytes) -> reusable scratch buffer of the fused stage (stream-ordered use)
-
-
 def _stage_scratch(dev, nbytes):
-    key = (dev.index, nbytes)
-    buf = _scratch.get(key)
-    if buf is None:
-        for k in [k for k in _scratch if k[0] == dev.index]:
-            del _scratch[k]
-        buf = _scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    return buf
+    """Reusable scratch of the fused stage: grow-only, one buffer per (device, stream); outgrown buffers stay alive
+    (a captured HIP graph may hold their address) -- mghs_op.scratch_pool."""
+    from .mghs_op import scratch_pool
+    return scratch_pool.get(dev, nbytes, 'sfa')
+
+
+_GEMM_ENV = {'0': 'f32', '1': 'bf16x6', '3': 'bf16x3'}   # DHD_SFA_GEMM_MODE also accepts round 2's numbers
+
+
+def default_gemm():
+    """GEMM precision of stages built without an explicit `gemm`: the environment variable DHD_SFA_GEMM_MODE
+    (bf16x3 | bf16x6 | f32), else the library default (bf16x3: include/dhd_amd.h, dhd_sfa_weights.gemm)."""
+    import os
+    e = os.environ.get('DHD_SFA_GEMM_MODE', '').strip().lower()
+    e = _GEMM_ENV.get(e, e)
+    return e if e in _lib.SFA_GEMM else 'default'
 
 
 def _bn_momentum(bn, training):
@@ -150,6 +156,7 @@ class _FusedStage(torch.autograd.Function):
             setattr(wts, tag + '_mean', bn.running_mean.data_ptr() if track else None)
             setattr(wts, tag + '_var', bn.running_var.data_ptr() if track else None)
         wts.hidden, wts.training = hidden, training
+        wts.gemm = _lib.SFA_GEMM[stage.gemm or default_gemm()]   # per call; backward reuses this struct
         wts.eps1, wts.eps2 = bn1.eps, bn2.eps
         wts.momentum1, wts.momentum2 = _bn_momentum(bn1, training), _bn_momentum(bn2, training)
         if training and not bn1.training:
@@ -230,6 +237,7 @@ class channel_spatial_stage(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     fused = True  # set False to force the generic path (library convolutions between the blend kernels)
+    gemm = None   # 'bf16x3' | 'bf16x6' | 'f32': precision of the fused stage's C x C GEMMs; None = default_gemm()
 
     def forward(self, x):
         if self.fused and fused_stage_supported(self, x):

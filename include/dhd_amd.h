@@ -31,7 +31,7 @@ extern "C" {
 #define DHD_ENOSPACE (-2)   /* workspace too small */
 #define DHD_EUNSUPPORTED (-3)
 
-#define DHD_ABI_VERSION 1
+#define DHD_ABI_VERSION 2
 int dhd_abi_version(void);
 
 /* ------------------------------------------------------------------------------------ *
@@ -89,7 +89,20 @@ typedef struct dhd_mghs_desc {
   int32_t channels; /* C  (context channels)               */
   int32_t n_grids;  /* 1..4; grid 0 pools every pixel, grid k>=1 pools pixels of band k-1 */
   dhd_grid grid[DHD_MAX_GRIDS];
+  int32_t flags;    /* DHD_MGHS_* bits below; per call, nothing about them is process-wide */
 } dhd_mghs_desc;
+
+/* dhd_mghs_desc.flags
+ *   DHD_MGHS_DETERMINISTIC   reproducible forward sums.  By default the order of the entries inside a voxel is the
+ *       arrival order of the counting atomics of dhd_mghs_prepare, so the float32 sum of a voxel differs in its last bits
+ *       from run to run (the reference's order is unspecified as well: unstable argsort, lss_heightmap.py:355).  With the
+ *       bit set, prepare orders the entries of every voxel by point id (one extra ranking pass + a second scatter):
+ *       dhd_mghs_forward is then bit-identical from run to run, and equal to a sum in ascending ranks_depth order.  The
+ *       backward is deterministic either way.
+ *   DHD_MGHS_FEAT_GRAD_NCHW  dhd_mghs_backward* write the context gradient as (B*N, C, fH, fW) -- the layout of the
+ *       reference's tran_feat -- instead of (B*N, fH, fW, C), so that the caller needs no transposition pass. */
+#define DHD_MGHS_DETERMINISTIC 1
+#define DHD_MGHS_FEAT_GRAD_NCHW 2
 
 /* Camera calibration, all [dev] float32, laid out as the reference's input list
  * (lss_heightmap.py:384-390).  inv_post_rot / combine are OPTIONAL (may be NULL): when given they
@@ -110,9 +123,20 @@ typedef struct dhd_calib {
   const float* frustum_d;    /* (D)  */
 } dhd_calib;
 
-/* Bytes of workspace needed by dhd_mghs_prepare/forward/backward for `desc`.  The workspace pointer
- * must be 256-byte aligned (DHD_EINVAL otherwise): its arrays are read and written as 16-byte vectors. */
-int dhd_mghs_workspace_bytes(const dhd_mghs_desc* desc, size_t* bytes);
+/* Device memory of a view transform, in two caller-owned parts (both 256-byte aligned, DHD_EINVAL otherwise):
+ *   state   : what dhd_mghs_backward needs from dhd_mghs_prepare -- per-voxel slot prefix, voxel id of every slot, per-point
+ *             slots (about 28 MB at DHD-S, B = 4).  One per prepare whose backward is still to come.
+ *   scratch : everything else (counters, sort keys, the grouped entry lists, the compact per-voxel table: about 0.45 GB at
+ *             DHD-S, B = 4).  Valid from a prepare to the forward that follows it; dhd_mghs_backward uses it as plain scratch.
+ *             Calls that share a scratch must be ordered on one stream; any number of states may share it. */
+int dhd_mghs_workspace_bytes(const dhd_mghs_desc* desc, size_t* state_bytes, size_t* scratch_bytes);
+
+typedef struct dhd_mghs_workspace {
+  void* state;
+  size_t state_bytes;
+  void* scratch;
+  size_t scratch_bytes;
+} dhd_mghs_workspace;
 
 /* Height argmax -> band id per pixel (height_feature_to_height_map + create_mask_3,
  * lss_heightmap.py:528-564).  height is (B*N, H, fH, fW) (probabilities or logits: only the
@@ -134,28 +158,46 @@ int dhd_feat_nhwc_to_nchw(const float* src, float* dst, int bn, int c, int hw, v
  * groups the kept points by voxel (device counting sort; order inside a voxel is unspecified,
  * as with the reference's unstable argsort, :355).  `band` is the per-pixel band id from
  * dhd_height_band (ignored when n_grids == 1; may then be NULL).  The result stays in
- * `workspace` and is consumed by dhd_mghs_forward / dhd_mghs_backward until the next prepare. */
+ * `ws` and is consumed by dhd_mghs_forward / dhd_mghs_backward until the next prepare. */
 int dhd_mghs_prepare(const dhd_mghs_desc* desc, const dhd_calib* calib, const uint8_t* band,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     const dhd_mghs_workspace* ws, void* stream);
+
+/* The lift side of MGHS.view_transform in one call and four launches (lss_heightmap.py:434-442 + :290 + the
+ * preparation above): dhd_height_band (height, height_range, mask_range -> band), dhd_feat_nchw_to_nhwc (tran_feat
+ * (B*N,C,fH,fW) -> feat_nhwc) and dhd_mghs_prepare.  band (B*N,fH,fW) and feat_nhwc (B*N,fH,fW,C) are outputs the
+ * caller owns (feat_nhwc is an input of dhd_mghs_forward / backward).  n_grids == 1: height / band may be NULL. */
+int dhd_mghs_lift(const dhd_mghs_desc* desc, const dhd_calib* calib, const float* height, int n_height,
+                  const float* height_range /*host*/, const float* mask_range /*host*/, const float* feat_nchw,
+                  uint8_t* band, float* feat_nhwc, const dhd_mghs_workspace* ws, void* stream);
+
+/* Static rig (the reference's dormant accelerate / pre_compute idea, lss_heightmap.py:234-258,374-378): with the same
+ * calibration from frame to frame only the height bands change, and the full-height grid 0 pools every pixel whatever
+ * its band, so its whole grouping is frame-independent.  dhd_mghs_lift_static is dhd_mghs_lift for a `ws` that holds
+ * the result of an earlier dhd_mghs_prepare / dhd_mghs_lift / dhd_mghs_lift_static of the SAME desc and calibration
+ * (the caller guarantees that): camera matrices and the grid-0 part of the grouping are reused, only the band grids'
+ * entries are counted, scanned and scattered again.  Results are identical to a full dhd_mghs_lift. */
+int dhd_mghs_lift_static(const dhd_mghs_desc* desc, const dhd_calib* calib, const float* height, int n_height,
+                         const float* height_range /*host*/, const float* mask_range /*host*/, const float* feat_nchw,
+                         uint8_t* band, float* feat_nhwc, const dhd_mghs_workspace* ws, void* stream);
 
 /* Pooling forward for all grids.  depth (B*N,D,fH,fW); feat_nhwc (B*N,fH,fW,C).
  * out[g] is the FINAL reference layout (B, nz_g*C, ny_g, nx_g) with channel = z*C + c, i.e. the
  * result of bev_pool.py:105 (permute) followed by lss_heightmap.py:298-299 (collapse_z); the same
  * memory viewed as (B, nz_g, C, ny_g, nx_g) serves collapse_z=False.  Every element is written
- * (zeros included); no pre-zeroing needed.  Uses the workspace's scratch region (per-voxel sums). */
+ * (zeros included); no pre-zeroing needed.  Uses the scratch part of `ws` (per-voxel sums). */
 int dhd_mghs_forward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                     float* const out[DHD_MAX_GRIDS], void* workspace, void* stream);
+                     float* const out[DHD_MAX_GRIDS], const dhd_mghs_workspace* ws, void* stream);
 
 /* The two phases of dhd_mghs_forward, for callers that want to time or overlap them:
- *   gather : per-voxel sums of depth * context into the workspace's compact table (balanced over the
+ *   gather : per-voxel sums of depth * context into the scratch's compact table (balanced over the
  *            grouped entries; instruction-bound)
  *   stream : the dense writer -- every output tensor once, zero-filled, with the table rows patched in
  *            (HBM-bound; the dominant kernel of the forward pass)
  * dhd_mghs_forward == gather then stream on the same stream. */
 int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                            void* workspace, void* stream);
+                            const dhd_mghs_workspace* ws, void* stream);
 int dhd_mghs_forward_stream(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                            float* const out[DHD_MAX_GRIDS], void* workspace, void* stream);
+                            float* const out[DHD_MAX_GRIDS], const dhd_mghs_workspace* ws, void* stream);
 
 /* Strided placement of one grid's dense tensor: element (b, z, c, y, x) lives at
  *   ptr + b*batch_stride + z*z_stride + c*channel_stride + y*nx + x      (strides in floats, multiples of 4).
@@ -169,18 +211,18 @@ typedef struct dhd_tensor_view {
 } dhd_tensor_view;
 
 int dhd_mghs_forward_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
-                           const dhd_tensor_view out[DHD_MAX_GRIDS], void* workspace, void* stream);
+                           const dhd_tensor_view out[DHD_MAX_GRIDS], const dhd_mghs_workspace* ws, void* stream);
 int dhd_mghs_backward_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                             const dhd_tensor_view out_grad[DHD_MAX_GRIDS], float* depth_grad,
-                            float* feat_grad_nhwc, void* workspace, void* stream);
+                            float* feat_grad, const dhd_mghs_workspace* ws, void* stream);
 
 /* Pooling backward.  out_grad[g] has the layout of out[g].  depth_grad (B*N,D,fH,fW) and
- * feat_grad_nhwc (B*N,fH,fW,C) are fully overwritten (zero-filled internally).  Pixels outside
+ * feat_grad ((B*N,fH,fW,C), or (B*N,C,fH,fW) with DHD_MGHS_FEAT_GRAD_NCHW) are fully overwritten.  Pixels outside
  * a band contribute nothing to that band's grid, matching d(tran_feat * mask), :436-442.
- * The workspace's scratch region is written (the grouping produced by prepare is not). */
+ * Reads the state part of `ws`, uses its scratch part as scratch (the state is not modified). */
 int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                       const float* const out_grad[DHD_MAX_GRIDS], float* depth_grad,
-                      float* feat_grad_nhwc, void* workspace, void* stream);
+                      float* feat_grad, const dhd_mghs_workspace* ws, void* stream);
 
 /* Introspection for parity tests and for the voxel_pooling_prepare_v2 mirror: per-point voxel
  * rank of ONE grid for every frustum point, -1 if dropped (band-independent), i.e. the map
@@ -189,19 +231,16 @@ int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float
 int dhd_mghs_voxel_index(const dhd_mghs_desc* desc, const dhd_calib* calib, int grid_index,
                          int32_t* rank_map, float* ego, void* stream);
 
-/* Reproducible forward sums (process-wide switch; default off, or the environment variable DHD_MGHS_DETERMINISTIC=1 at
- * first use).  By default the order of the entries inside a voxel is the arrival order of the counting atomics of
- * dhd_mghs_prepare, so the float32 sum of a voxel differs in its last bits from run to run (the reference's order is
- * unspecified as well: unstable argsort, lss_heightmap.py:355).  With the switch on, prepare orders the entries of
- * every voxel by point id (one extra ranking pass + a second scatter): dhd_mghs_forward is then bit-identical from
- * run to run, and equal to a sum in ascending ranks_depth order.  The backward is deterministic either way. */
-int dhd_mghs_set_deterministic(int on);
-int dhd_mghs_get_deterministic(void);
-
 /* Number of pooled (point, grid) pairs of the last prepare, per grid: n_kept[g] points,
- * n_intervals[g] non-empty voxels.  Reads back from the workspace: synchronises `stream`. */
-int dhd_mghs_stats(const dhd_mghs_desc* desc, const void* workspace, int32_t n_kept[DHD_MAX_GRIDS],
+ * n_intervals[g] non-empty voxels.  Reads back from `ws` right after a prepare: synchronises `stream`. */
+int dhd_mghs_stats(const dhd_mghs_desc* desc, const dhd_mghs_workspace* ws, int32_t n_kept[DHD_MAX_GRIDS],
                    int32_t n_intervals[DHD_MAX_GRIDS], void* stream);
+
+/* HBM calibration streams for roofline reporting (bench.py): move `bytes` (a multiple of 16, buf 16-byte aligned)
+ * once with   pattern 0: hipMemsetAsync,   1: a linear grid-stride fill with 16-byte non-temporal stores,
+ * 2: a linear grid-stride read with 16-byte non-temporal loads (one float per workgroup is written to buf's first
+ * page so that the loads stay live).  The rate a measured kernel is compared against on the SAME box and run. */
+int dhd_hbm_calibrate(void* buf /*[dev]*/, size_t bytes, int pattern, void* stream);
 
 /* ------------------------------------------------------------------------------------ *
  * 3. SFA channel/spatial attention stage (models/necks/mix.py:37-59), memory-bound parts.
@@ -264,6 +303,7 @@ typedef struct dhd_sfa_weights { /* [dev] float32 */
   int32_t training;     /* 1: batch statistics (nn.Module.train()), 0: running statistics */
   float eps1, eps2;
   float momentum1, momentum2; /* update factor of the running statistics */
+  int32_t gemm;         /* DHD_SFA_GEMM_* below */
 } dhd_sfa_weights;
 
 typedef struct dhd_sfa_grads { /* [dev] float32 outputs, shapes as in dhd_sfa_weights, overwritten */
@@ -273,19 +313,21 @@ typedef struct dhd_sfa_grads { /* [dev] float32 outputs, shapes as in dhd_sfa_we
 } dhd_sfa_grads;
 
 int dhd_sfa_stage_supported(int c, int hw);
-/* How the stage's C x C GEMMs are computed (process-wide, not thread-safe against running calls).  Every float32
- * operand is cut into bfloat16 parts (round-to-nearest-even, exact: h + m + l == x) for the bf16 MFMA:
- *   3 (default) "bf16x3": two parts per operand, three products ah*bh + ah*bm + am*bh per a*b (error <= 3 * 2^-18
- *     |ab| per product; stage output within ~2e-5 of float64 at full size, inside the path's 1e-3 bar); persistent
- *     workgroups keep their output channels' weight fragments resident in LDS (C in {128, 256, 512});
- *   1 "bf16x6", resident weights: three parts, six products -- float32-level accuracy (dropped terms < 2^-25 |ab|);
- *   2 "bf16x6", weights streamed through LDS per 128-pixel tile (round 1's kernels, any C % 256 == 0 or C == 128);
- *     with less than two rounds of tiles the tiles past the full round go to a second launch of 128-channel
- *     workgroups; 4: the same without that second launch.  Modes 1, 2 and 4 give bit-identical results;
- *   0 f32 MFMA (v_mfma_f32_32x32x2_f32), a plain float32 fma chain.
- * The weight-gradient GEMMs follow the same precision (bf16x3 in mode 3, bf16x6 in 1 / 2 / 4).
- * The environment variable DHD_SFA_GEMM_MODE selects the initial mode when the library is loaded. */
-int dhd_sfa_set_gemm_mode(int mode);
+/* dhd_sfa_weights.gemm: how the stage's C x C GEMMs are computed in THIS call (forward and backward of one stage must
+ * pass the same value; nothing is process-wide).  Every float32 operand is cut into bfloat16 parts (round-to-nearest-even,
+ * exact: h + m + l == x) for the bf16 MFMA:
+ *   DHD_SFA_GEMM_DEFAULT (0)  = DHD_SFA_GEMM_BF16X3
+ *   DHD_SFA_GEMM_BF16X6 (1)   three parts, six products -- float32-level accuracy (dropped terms < 2^-25 |ab|)
+ *   DHD_SFA_GEMM_F32 (2)      f32 MFMA (v_mfma_f32_32x32x2_f32), a plain float32 fma chain
+ *   DHD_SFA_GEMM_BF16X3 (3)   two parts per operand, three products ah*bh + ah*bm + am*bh per a*b (error <= 3 * 2^-18
+ *                             |ab| per product; stage output within ~2e-5 of float64 at full size, inside the path's 1e-3 bar)
+ * Kernel forms (resident weights in LDS, or weights streamed through LDS per pixel tile for channel counts the resident form
+ * does not cover) are chosen by the library and do not change results within a mode.  The weight-gradient GEMMs follow the
+ * same precision. */
+#define DHD_SFA_GEMM_DEFAULT 0
+#define DHD_SFA_GEMM_BF16X6 1
+#define DHD_SFA_GEMM_F32 2
+#define DHD_SFA_GEMM_BF16X3 3
 /* `saved` carries forward state to backward (a1, BatchNorm batch statistics, y1, y2);
  * `scratch` is reusable between calls on one stream.  0 if the shape is unsupported. */
 size_t dhd_sfa_stage_saved_bytes(int b, int c, int hw, int hidden);

@@ -58,8 +58,9 @@ def test_sfa_stage_shape_support_and_validation():
     w.hidden = 32
     assert lib.dhd_sfa_stage_forward(one, C.byref(w), one, one, one, 4, 256, 40000, None) == -1  # null weights
     assert lib.dhd_sfa_stage_backward(one, C.byref(w), one, one, one, C.byref(g), one, 4, 256, 40000, None) == -1
-    assert lib.dhd_sfa_set_gemm_mode(5) == -1 and lib.dhd_sfa_set_gemm_mode(-1) == -1
-    assert all(lib.dhd_sfa_set_gemm_mode(m) == 0 for m in (0, 2, 3, 4, 1))
+    # the GEMM precision is a per-call field (dhd_sfa_weights.gemm), not a process-wide switch
+    assert not hasattr(lib, 'dhd_sfa_set_gemm_mode') and not hasattr(lib, 'dhd_mghs_set_deterministic')
+    assert _lib.SFA_GEMM == {'default': 0, 'bf16x6': 1, 'f32': 2, 'bf16x3': 3}
 
 
 def test_library_is_a_gfx950_code_object():
@@ -71,22 +72,32 @@ def test_library_is_a_gfx950_code_object():
 def test_argument_validation_happens_on_the_host():
     from dhd_amd import _lib
     lib = _lib.load()
-    n = C.c_size_t(0)
+    n, m = C.c_size_t(0), C.c_size_t(0)
     d = _lib.MghsDesc()
-    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == -1  # all-zero desc
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n), C.byref(m)) == -1  # all-zero desc
     d.batch, d.n_cams, d.n_depth, d.fh, d.fw, d.channels, d.n_grids = 1, 6, 44, 16, 44, 64, 4
     for g, nz in zip(range(4), (1, 4, 4, 8)):
         d.grid[g].n[0], d.grid[g].n[1], d.grid[g].n[2] = 200, 200, nz
-    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == 0
-    per_sample = n.value
-    # index arrays (~3V + 12P words = 17 MB) + the worst-case compact table (2P slots x 256 B = 95 MB)
-    assert 1.0e8 < per_sample < 1.3e8
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n), C.byref(m)) == 0
+    state, scratch = n.value, m.value
+    # state (what backward needs, held by autograd): slot prefix (V words) + slot -> voxel (2P) + per-point slots (2P) = 5.7 MB
+    assert 5.0e6 < state < 6.5e6
+    # scratch (shared per stream): counters / keys / sorted lists (~2V + 10P words = 13 MB) + the worst-case compact table
+    # (2P slots x 256 B = 95 MB)
+    assert 1.0e8 < scratch < 1.2e8
     d.batch = 4
-    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == 0 and 3.9 * per_sample < n.value < 4.1 * per_sample
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n), C.byref(m)) == 0
+    assert 3.9 * state < n.value < 4.1 * state and 3.9 * scratch < m.value < 4.1 * scratch
     d.n_grids = 5
-    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == -1
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n), C.byref(m)) == -1
     d.n_grids = 4
-    assert lib.dhd_mghs_prepare(C.byref(d), None, None, None, 0, None) == -1
+    d.flags = 4                                                                     # unknown flag bit
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n), C.byref(m)) == -1
+    d.flags = _lib.MGHS_DETERMINISTIC | _lib.MGHS_FEAT_GRAD_NCHW
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n), C.byref(m)) == 0
+    assert lib.dhd_mghs_prepare(C.byref(d), None, None, None, None) == -1
+    assert lib.dhd_mghs_lift(C.byref(d), None, None, 65, None, None, None, None, None, None, None) == -1
+    assert lib.dhd_hbm_calibrate(None, 1024, 0, None) == -1 and lib.dhd_hbm_calibrate(C.c_void_p(4096), 1000, 1, None) == -1
     assert lib.dhd_bev_pool_v2_forward(None, None, None, None, None, None, None, None, 64, 10, None) == -1
     assert lib.dhd_bev_pool_v2_forward(None, None, None, None, None, None, None, None, 64, 0, None) == 0  # nothing to do
     assert lib.dhd_sfa_channel_mean(None, None, 1, 512, 40000, None) == -1
@@ -97,7 +108,7 @@ def test_argument_validation_happens_on_the_host():
     assert lib.dhd_bn_train_forward(None, 0, 2, 8, 64, None, None, None, None, 0.1, 1e-5, None, None, None, None, None) == -1
     assert lib.dhd_ema_update(None, None, None, 0, 0.5, 0.5, None) == 0  # empty state
     d.batch = 1 << 20
-    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == -3  # beyond the int32 index space
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n), C.byref(m)) == -3  # beyond the int32 index space
 
 
 def test_no_silent_fallback_without_gpu_or_library():
@@ -144,6 +155,13 @@ def test_workspace_alignment_is_checked_on_the_host():
     d = _lib.MghsDesc()
     d.batch, d.n_cams, d.n_depth, d.fh, d.fw, d.channels, d.n_grids = 1, 1, 4, 4, 11, 64, 1
     d.grid[0].n[0], d.grid[0].n[1], d.grid[0].n[2] = 8, 8, 1
-    n = C.c_size_t(0)
-    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n)) == 0 and n.value > 0
-    assert lib.dhd_mghs_prepare(C.byref(d), None, None, C.c_void_p(0x10004), n.value, None) == -1
+    n, m = C.c_size_t(0), C.c_size_t(0)
+    assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n), C.byref(m)) == 0 and n.value > 0 and m.value > 0
+    cal = _lib.Calib()
+    for f, _ in _lib.Calib._fields_:
+        setattr(cal, f, 0x20000)
+    for state, scratch, rc in ((0x10004, 0x40000, -1), (0x10000, 0x40004, -1)):
+        ws = _lib.MghsWorkspace(state, n.value, scratch, m.value)
+        assert lib.dhd_mghs_prepare(C.byref(d), C.byref(cal), None, C.byref(ws), None) == rc
+    ws = _lib.MghsWorkspace(0x10000, n.value - 1, 0x40000, m.value)       # too small
+    assert lib.dhd_mghs_prepare(C.byref(d), C.byref(cal), None, C.byref(ws), None) == -2

@@ -162,16 +162,19 @@ def test_feature_relayout_round_trip(gpu):
 
 # --------------------------------------------------------------------------- fused view transform
 
-def run_fused(gpu, cfg, calib_np, depth, feat, hidx, inv=None, comb=None, weights_seed=None):
+def run_fused(gpu, cfg, calib_np, depth, feat, hidx, inv=None, comb=None, weights_seed=None, separate=False):
     from dhd_amd import mghs_op
     B, N = calib_np[0].shape[:2]
     plan, axes = make_plan(cfg, B, N, channels=feat.shape[1])
     calib, keep = device_calib(calib_np, axes, gpu, inv, comb)
     height = T(syn.height_probs_from_index(hidx, len(cfg['height_range'])), gpu)
-    band = mghs_op.height_band(height, cfg['height_range'], cfg['mask_range'])
     dt, ft = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
     ws = plan.new_workspace(gpu)
-    outs = mghs_op.mghs_pool(plan, calib, band, dt, ft, ws)
+    if separate:   # the stand-alone entry points: dhd_height_band, dhd_feat_nchw_to_nhwc, dhd_mghs_prepare
+        band = mghs_op.height_band(height, cfg['height_range'], cfg['mask_range'])
+        outs = mghs_op.mghs_pool(plan, calib, band, dt, ft, ws)
+    else:          # dhd_mghs_lift: the same three steps as four launches
+        outs = mghs_op.mghs_lift_pool(plan, calib, height, cfg['height_range'], cfg['mask_range'], dt, ft, ws)
     grads = None
     if weights_seed is not None:
         loss = sum((o * T(syn.hash_signed(weights_seed + k, tuple(o.shape)), gpu)).sum() for k, o in enumerate(outs))
@@ -313,7 +316,7 @@ def test_full_size_properties_batch4(gpu):
 
 
 def test_deterministic_mode_makes_the_forward_bit_reproducible(gpu):
-    """dhd_mghs_set_deterministic(1): the entries of a voxel are ordered by point id instead of by the arrival order of
+    """DHD_MGHS_DETERMINISTIC (dhd_mghs_desc.flags): the entries of a voxel are ordered by point id instead of by the arrival order of
     the counting atomics, so the per-voxel float32 sums -- hence every output -- are bit-identical from run to run, at
     the full DHD-S size and B = 4; the results still agree with the default mode to rounding; gradients too."""
     from dhd_amd import mghs_op
@@ -332,6 +335,16 @@ def test_deterministic_mode_makes_the_forward_bit_reproducible(gpu):
         for a, b in zip(runs[0][0], outs):
             assert np.array_equal(a, b)
         assert np.array_equal(runs[0][1][0], grads[0]) and np.array_equal(runs[0][1][1], grads[1])
+    # the stand-alone entry points (dhd_height_band + dhd_feat_nchw_to_nhwc + dhd_mghs_prepare) and the fused dhd_mghs_lift
+    # produce the same grouping: in deterministic mode the results are bit-identical
+    mghs_op.set_deterministic(True)
+    try:
+        sep_outs, sep_grads, _ = run_fused(gpu, cfg, calib_np, depth, feat, hidx, weights_seed=700, separate=True)
+    finally:
+        mghs_op.set_deterministic(False)
+    for a, b in zip(runs[0][0], sep_outs):
+        assert np.array_equal(a, b)
+    assert np.array_equal(runs[0][1][0], sep_grads[0]) and np.array_equal(runs[0][1][1], sep_grads[1])
     for a, b in zip(runs[0][0], ref_outs):
         assert np.array_equal(a != 0, b != 0)
         np.testing.assert_allclose(a, b, atol=1e-4, rtol=1e-4)
@@ -453,26 +466,27 @@ def _plain_stage(st, x, margin=0.0):
 
 _TIE = 2e-6
 
-# GEMM modes of the stage operator (include/dhd_amd.h: dhd_sfa_set_gemm_mode) and the tolerance factor the tests grant
-# them relative to the float32-level modes: bf16x3 (the default) drops product terms of relative size <= 3 * 2^-18, the
-# path's bar is 1e-3 (BASELINE.json north_star)
-GEMM_MODES = {'x3_resident': (3, 20.0), 'x6_resident': (1, 1.0), 'x6_streamed': (2, 1.0)}
+# GEMM precisions of the stage operator (include/dhd_amd.h: dhd_sfa_weights.gemm, per call) and the tolerance factor the
+# tests grant them relative to the float32-level one: bf16x3 (the default) drops product terms of relative size
+# <= 3 * 2^-18, the path's bar on outputs is 1e-3 (BASELINE.json north_star)
+GEMM_MODES = {'bf16x3': 20.0, 'bf16x6': 1.0}
 
 
 class gemm_mode:
-    """with gemm_mode('x6_resident') as tol_factor: ...  -- restores the default mode afterwards."""
+    """with gemm_mode('bf16x6') as tol_factor: ...  -- every channel_spatial_stage called inside uses that precision
+    (class-level default of the `gemm` attribute; an instance can still set its own)."""
 
     def __init__(self, name):
-        self.mode, self.factor = GEMM_MODES[name]
+        self.name, self.factor = name, GEMM_MODES.get(name, 1.0)
 
     def __enter__(self):
-        from dhd_amd import _lib
-        _lib.check(_lib.load().dhd_sfa_set_gemm_mode(self.mode), 'mode')
+        from dhd_amd.mix import channel_spatial_stage
+        channel_spatial_stage.gemm = self.name
         return self.factor
 
     def __exit__(self, *exc):
-        from dhd_amd import _lib
-        _lib.check(_lib.load().dhd_sfa_set_gemm_mode(3), 'mode')
+        from dhd_amd.mix import channel_spatial_stage
+        channel_spatial_stage.gemm = None
         return False
 
 
@@ -550,45 +564,41 @@ def test_sfa_stage_vs_torch(gpu, c, b, h, w, train, gemm):
 
 @pytest.mark.parametrize('c,b,h,w', [(128, 2, 20, 28), (256, 2, 36, 40), (512, 1, 24, 40)])
 def test_sfa_stage_f32_mfma_mode_vs_torch(gpu, c, b, h, w):
-    """GEMM mode 0 (dhd_sfa_set_gemm_mode: plain float32 MFMA kernels) through the same comparison."""
-    from dhd_amd import _lib
+    """gemm = 'f32' (DHD_SFA_GEMM_F32: plain float32 MFMA kernels) through the same comparison."""
     from dhd_amd.mix import channel_spatial_stage
     torch.manual_seed(c + w)
     st = channel_spatial_stage(2 * c).to(gpu).train()
+    st.gemm = 'f32'          # per instance: other stages of the process keep their own precision
     x = (torch.randn(b, 2 * c, h, w, device=gpu) * 0.7 + 0.1).requires_grad_()
-    lib = _lib.load()
-    _lib.check(lib.dhd_sfa_set_gemm_mode(0), 'mode')
-    try:
-        _check_stage_against_torch(st, x)
-    finally:
-        _lib.check(lib.dhd_sfa_set_gemm_mode(3), 'mode')
+    _check_stage_against_torch(st, x)
 
 
 @pytest.mark.parametrize('c,b,h,w', [(256, 2, 200, 200), (512, 1, 200, 200), (256, 1, 64, 72), (128, 3, 36, 40)])
-def test_sfa_stage_x6_modes_are_bit_identical(gpu, c, b, h, w):
-    """The three bf16x6 GEMM modes accumulate every output element in the same order: mode 2 streams the weights
-    through LDS per 128-pixel tile and sends the tiles beyond the full rounds of 2 x CUs workgroups to a second launch
-    of 128-channel workgroups, mode 4 is the same in one launch, mode 1 keeps the weights resident in LDS in
-    persistent workgroups (teams of C / 64 workgroups per pixel tile).  Every result must be bit-identical."""
-    from dhd_amd import _lib
+def test_sfa_stage_is_bit_reproducible_and_precision_is_per_instance(gpu, c, b, h, w):
+    """Every precision accumulates each output element in a fixed order (per-worker partial matrices reduced by a tree, no
+    float atomics): two runs are bit-identical, forward and all gradients.  And the precision is a property of the call:
+    two stages of one process with different `gemm` interleave without influencing each other."""
     from dhd_amd.mix import channel_spatial_stage
     torch.manual_seed(c + h)
     st = channel_spatial_stage(2 * c).to(gpu).train()
+    other = channel_spatial_stage(2 * c).to(gpu).train()
+    other.load_state_dict(st.state_dict())
+    st.gemm, other.gemm = 'bf16x6', 'bf16x3'
     x = (torch.randn(b, 2 * c, h, w, device=gpu) * 0.7 + 0.1).requires_grad_()
     g = torch.randn(b, c, h, w, device=gpu)
-    lib = _lib.load()
     res = []
-    try:
-        for mode in (2, 4, 1):
-            _lib.check(lib.dhd_sfa_set_gemm_mode(mode), 'mode')
-            for p in st.parameters():
+    for rep in range(3):
+        for m in (st, other):
+            for p in m.parameters():
                 p.grad = None
             x.grad = None
-            out = st(x)
+            out = m(x)
             out.backward(g)
-            res.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in st.parameters()])
-    finally:
-        _lib.check(lib.dhd_sfa_set_gemm_mode(3), 'mode')
+            if m is st:
+                res.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in m.parameters()])
+            elif rep == 0:
+                x3 = out.detach().clone()
+    assert not torch.equal(x3, res[0][0]) and torch.allclose(x3, res[0][0], atol=2e-4)   # different precision, same result
     for other in res[1:]:
         for a, bb in zip(res[0], other):
             assert torch.equal(a, bb)
@@ -678,41 +688,57 @@ def test_uncollapsed_layouts_match_collapsed(gpu):
 
 
 def test_accelerate_caches_only_what_is_static(gpu):
-    """accelerate=True at inference: the single-grid call (view_transform_core) reuses its prepared workspace while the
-    same calibration tensors are passed unmodified and redoes it when they change; the four-grid view_transform bakes the
-    per-frame height bands into the grouping and is never cached -- a second frame with different heights and a
-    different calibration must give that frame's result (the cache used to be keyed on (plan, device) only)."""
-    from dhd_amd import MGHS
+    """accelerate=True at inference (the reference's dormant pre_compute idea, lss_heightmap.py:234-258,374-378):
+    while the same calibration tensors are passed unmodified, the four-grid view_transform reuses camera matrices and the
+    whole grouping of the full-height grid and redoes only the band grids' part per frame (dhd_mghs_lift_static); the
+    single-grid call reuses everything.  A frame with a changed height map, a frame with a changed calibration (new tensors
+    or an in-place edit) and a return to the first calibration must each give exactly what the uncached module gives."""
+    from dhd_amd import MGHS, mghs_op
     cfg, calib_np, depth, feat, hidx = _small64(330)
     hn = dict(use_dcn=False, use_aspp=False)
-    m = MGHS(**dict(cfg, heightnet_cfg=hn, accelerate=True)).to(gpu).eval()
-    plain = MGHS(**dict(cfg, heightnet_cfg=hn, accelerate=False)).to(gpu).eval()
-    calib = [T(a, gpu) for a in calib_np]
-    x = torch.zeros(1, 3, 1, 4, 11, device=gpu)
-    height = T(syn.height_probs_from_index(hidx, 65), gpu)
-    calib2 = [T(a, gpu) for a in syn.make_calibration(331, 1, 3, cfg['input_size'])]
-    height2 = T(syn.height_probs_from_index(syn.height_index(332, hidx.shape, 65), 65), gpu)
-    with torch.no_grad():
-        for cal, hgt in ((calib, height), (calib2, height2), (calib, height2)):
-            a = m.view_transform([x] + cal, T(depth, gpu), T(feat, gpu), hgt)
-            b = plain.view_transform([x] + cal, T(depth, gpu), T(feat, gpu), hgt)
-            for k in (0, 3, 4, 5):
-                assert torch.allclose(a[k], b[k], atol=1e-5), k
-        assert m._cached is None                     # nothing band-dependent was cached
-        # single grid: cached while the calibration tensors are the same objects, unmodified
-        m._set_grid(cfg['mask_2_grid'])
-        plain._set_grid(cfg['mask_2_grid'])
-        o1, _ = m.view_transform_core([x] + calib, T(depth, gpu), T(feat, gpu))
-        ws = m._cached[0]
-        o2, _ = m.view_transform_core([x] + calib, T(2 * depth, gpu), T(feat, gpu))
-        assert m._cached[0] is ws and torch.allclose(o2, 2 * o1, atol=1e-4)
-        o3, _ = m.view_transform_core([x] + calib2, T(depth, gpu), T(feat, gpu))
-        r3, _ = plain.view_transform_core([x] + calib2, T(depth, gpu), T(feat, gpu))
-        assert m._cached[0] is not ws and torch.allclose(o3, r3, atol=1e-5)
-        calib2[0][:, :, 0, 3] += 0.37                # in-place edit of a cached calibration tensor
-        o4, _ = m.view_transform_core([x] + calib2, T(depth, gpu), T(feat, gpu))
-        r4, _ = plain.view_transform_core([x] + calib2, T(depth, gpu), T(feat, gpu))
-        assert torch.allclose(o4, r4, atol=1e-5) and not torch.allclose(o4, o3, atol=1e-5)
+    mghs_op.set_deterministic(True)     # bit-comparable sums
+    try:
+        m = MGHS(**dict(cfg, heightnet_cfg=hn, accelerate=True)).to(gpu).eval()
+        plain = MGHS(**dict(cfg, heightnet_cfg=hn, accelerate=False)).to(gpu).eval()
+        calib = [T(a, gpu) for a in calib_np]
+        x = torch.zeros(1, 3, 1, 4, 11, device=gpu)
+        height = T(syn.height_probs_from_index(hidx, 65), gpu)
+        calib2 = [T(a, gpu) for a in syn.make_calibration(331, 1, 3, cfg['input_size'])]
+        height2 = T(syn.height_probs_from_index(syn.height_index(332, hidx.shape, 65), 65), gpu)
+        height3 = T(syn.height_probs_from_index(syn.height_index(333, hidx.shape, 65), 65), gpu)
+        lifts = []
+        real = mghs_op.lift
+        mghs_op.lift = lambda *a, **k: (lifts.append(bool(k.get('static'))), real(*a, **k))[1]
+        try:
+            with torch.no_grad():
+                for cal, hgt in ((calib, height), (calib, height2), (calib, height3), (calib2, height2), (calib2, height), (calib, height2)):
+                    a = m.view_transform([x] + cal, T(depth, gpu), T(feat, gpu), hgt)
+                    b = plain.view_transform([x] + cal, T(depth, gpu), T(feat, gpu), hgt)
+                    for k in (0, 3, 4, 5):
+                        assert torch.equal(a[k], b[k]), k
+                # accelerated module: full lift, static, static, full (new calibration), static, full; the plain one never static
+                assert lifts[0::2] == [False, True, True, False, True, False] and not any(lifts[1::2])
+                calib2[0][:, :, 0, 3] += 0.37            # in-place edit of a cached calibration tensor -> full lift
+                n0 = len(lifts)
+                a = m.view_transform([x] + calib2, T(depth, gpu), T(feat, gpu), height)
+                b = plain.view_transform([x] + calib2, T(depth, gpu), T(feat, gpu), height)
+                assert lifts[n0] is False and all(torch.equal(a[k], b[k]) for k in (0, 3, 4, 5))
+                # single grid: everything is reused while the calibration tensors are the same objects, unmodified
+                m._set_grid(cfg['mask_2_grid'])
+                plain._set_grid(cfg['mask_2_grid'])
+                n0 = len(lifts)
+                o1, _ = m.view_transform_core([x] + calib, T(depth, gpu), T(feat, gpu))
+                o2, _ = m.view_transform_core([x] + calib, T(2 * depth, gpu), T(feat, gpu))
+                assert len(lifts) == n0 + 1 and torch.allclose(o2, 2 * o1, atol=1e-4)      # one lift for the two calls
+                r1, _ = plain.view_transform_core([x] + calib, T(depth, gpu), T(feat, gpu))
+                assert torch.equal(o1, r1)
+                o3, _ = m.view_transform_core([x] + calib2, T(depth, gpu), T(feat, gpu))
+                r3, _ = plain.view_transform_core([x] + calib2, T(depth, gpu), T(feat, gpu))
+                assert torch.equal(o3, r3) and not torch.allclose(o3, o1, atol=1e-5)
+        finally:
+            mghs_op.lift = real
+    finally:
+        mghs_op.set_deterministic(False)
 
 
 def test_mghs_step_is_graph_capturable(gpu):
