@@ -273,7 +273,7 @@ class EndToEnd:
             return
         from dhd_amd.graph import GraphedStep
         try:
-            self.graphed = GraphedStep(lambda: self._eager_step(), warmup=2)
+            self.graphed = GraphedStep(lambda: self._eager_step(), warmup=2, emas=[self.ema] if self.ema is not None else [])
         except Exception as e:  # noqa: BLE001 -- report and keep measuring eagerly
             self.graph_error = f'{type(e).__name__}: {e}'[:300]
             self.graphed = None
@@ -430,6 +430,18 @@ def operator_roofline(hp, steps, warmup):
         bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln).backward(ogp)
     torch.cuda.synchronize()
     py_ms = (time.perf_counter() - t0) / steps * 1e3
+    # the same with the regrouping redone in every backward (index lists rebuilt per call, as voxel_pooling_v2 does in training)
+    import importlib
+    bev_mod = importlib.import_module('dhd_amd.bev_pool_v2')   # the module (dhd_amd.bev_pool_v2 the attribute is the function)
+    for it in range(3 + steps):
+        if it == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        dt.grad = ft.grad = None
+        bev_mod._regroup_cache.clear()
+        bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln).backward(ogp)
+    torch.cuda.synchronize()
+    py_uncached_ms = (time.perf_counter() - t0) / steps * 1e3
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     n_kept = int(rb.numel())
@@ -440,11 +452,16 @@ def operator_roofline(hp, steps, warmup):
     ach = (fwd_bytes + bwd_bytes) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
     return dict(bound='hbm', kernel='bev_pool_v2_fwd_kernel + bev_pool_v2_bwd_kernel (dhd_bev_pool_v2_forward/backward, incl. the '
                                     'zero-fill of the caller-owned outputs)', achieved=ach, peak=HBM_PEAK_GBPS, unit='GB/s',
-                frac=ach / HBM_PEAK_GBPS, traffic=None, launch_ms=fwd_ms + bwd_ms, forward_ms=fwd_ms, backward_ms=bwd_ms,
+                frac=ach / HBM_PEAK_GBPS,
+                traffic=(lambda p: None if None in p else int(sum(p)))([pmc_traffic(k, B) for k in ('bev_pool_v2_fwd_vec_kernel', 'bev_pool_v2_bwd_vec_kernel')]),
+                launch_ms=fwd_ms + bwd_ms, forward_ms=fwd_ms, backward_ms=bwd_ms,
                 algorithmic_bytes=fwd_bytes + bwd_bytes, forward_bytes=fwd_bytes, backward_bytes=bwd_bytes, kept_points=n_kept,
-                intervals=int(ln.numel()), python_op_fwd_bwd_ms=py_ms,
-                note='full-height grid only (Dz=1); python_op_fwd_bwd_ms = dhd_amd.bev_pool_v2(...).backward() incl. permute and the '
-                     'backward re-grouping argsort the reference also performs (bev_pool.py:47-57)')
+                intervals=int(ln.numel()), python_op_fwd_bwd_ms=py_ms, python_op_fwd_bwd_regroup_every_call_ms=py_uncached_ms,
+                note='full-height grid only (Dz=1); traffic = PMC bytes of the two kernels (the zero-fills of the caller-owned outputs are '
+                     'torch fills, not counted); python_op_fwd_bwd_ms = dhd_amd.bev_pool_v2(...).backward() incl. zero-fill and permute, with '
+                     'the backward re-grouping (bev_pool.py:47-57: argsort + gathers + run-length scan in the reference; here '
+                     'dhd_bev_pool_v2_regroup, a device counting sort) reused while the same index tensors come back; '
+                     '..._regroup_every_call_ms redoes it in every backward')
 
 
 def cpu_baseline(hp, max_batch, warmups=3, reps=5, budget_s=75.0):

@@ -75,6 +75,8 @@ _PROTOTYPES = {
     'dhd_abi_version': ([], _I),
     'dhd_bev_pool_v2_forward': ([_P] * 8 + [_I, _I, _P], _I),
     'dhd_bev_pool_v2_backward': ([_P] * 10 + [_I, _I, _P], _I),
+    'dhd_bev_pool_v2_regroup_scratch_bytes': ([_I, _I], C.c_size_t),
+    'dhd_bev_pool_v2_regroup': ([_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, C.c_size_t, _P], _I),
     'dhd_mghs_workspace_bytes': ([C.POINTER(MghsDesc), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], _I),
     'dhd_height_band': ([_P, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P], _I),
     'dhd_feat_nchw_to_nhwc': ([_P, _P, _I, _I, _I, _P], _I),
@@ -105,6 +107,8 @@ _PROTOTYPES = {
     'dhd_sfa_stage_scratch_bytes': ([_I, _I, _I, _I], C.c_size_t),
     'dhd_sfa_stage_forward': ([_P, C.POINTER(SfaWeights), _P, _P, _P, _I, _I, _I, _P], _I),
     'dhd_sfa_stage_backward': ([_P, C.POINTER(SfaWeights), _P, _P, _P, C.POINTER(SfaGrads), _P, _I, _I, _I, _P], _I),
+    'dhd_sfa_stage_forward_phase': ([_P, C.POINTER(SfaWeights), _P, _P, _P, _I, _I, _I, _I, _P, _P], _I),
+    'dhd_sfa_stage_backward_phase': ([_P, C.POINTER(SfaWeights), _P, _P, _P, C.POINTER(SfaGrads), _P, _I, _I, _I, _I, _P, _P], _I),
     'dhd_occ_loss_workspace_bytes': ([], C.c_size_t),
     'dhd_occ_loss_forward': ([_P, _P, _P, _P, C.c_int64, _I, _I, _I, _P, _P, _P], _I),
     'dhd_occ_loss_backward': ([_P, _P, _P, _P, C.c_int64, _I, _I, _I, _P, _P, _P, _P], _I),
@@ -118,6 +122,7 @@ _PROTOTYPES = {
     'dhd_stereo_cost_volume': ([_P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P], _I),
     'dhd_deform_col2im': ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     'dhd_ema_update': ([_P, _P, _P, _I, C.c_float, C.c_float, _P], _I),
+    'dhd_ema_update_dev': ([_P, _P, _P, _I, _P, _P], _I),
     'dhd_bn_supported': ([_I, _I, _I, _I], _I),
     'dhd_bn_workspace_bytes': ([_I, _I, _I], C.c_size_t),
     'dhd_bn_train_forward': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P], _I),

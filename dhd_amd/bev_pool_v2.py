@@ -43,25 +43,48 @@ class QuickCumsumCuda(torch.autograd.Function):
     def backward(ctx, out_grad):
         lib = _lib.load()
         ranks_bev, depth, feat, ranks_feat, ranks_depth = ctx.saved_tensors
-        # The backward kernel walks one feature pixel per wave, so regroup the points by pixel
-        # (what bev_pool.py:47-57 does with an argsort + run-length scan).
-        order = torch.argsort(ranks_feat, stable=True)
-        ranks_feat = ranks_feat[order].contiguous()
-        ranks_depth = ranks_depth[order].contiguous()
-        ranks_bev = ranks_bev[order].contiguous()
-        _, lengths = torch.unique_consecutive(ranks_feat, return_counts=True)
-        starts = (torch.cumsum(lengths, 0) - lengths).int()
-        lengths = lengths.int()
+        # The backward kernel walks one feature pixel per wave (or lane group), so the points are regrouped by pixel --
+        # what bev_pool.py:47-57 does with an argsort, three gathers and a run-length scan on EVERY call.  Here: a device
+        # counting sort (dhd_bev_pool_v2_regroup, no host synchronisation), kept while the same rank tensors come back
+        # unmodified (index lists of a static rig; voxel_pooling_v2 rebuilds them per call in training).
+        rd, rf, rb, starts, lengths = _regrouped(lib, ranks_depth, ranks_feat, ranks_bev, feat.numel() // int(feat.shape[-1]))
         depth_grad = depth.new_zeros(depth.shape)
         feat_grad = feat.new_zeros(feat.shape)
         out_grad = out_grad.contiguous().float()
         with torch.cuda.device(depth.device):
             rc = lib.dhd_bev_pool_v2_backward(
                 _lib.ptr(out_grad), _lib.ptr(depth_grad), _lib.ptr(feat_grad), _lib.ptr(depth), _lib.ptr(feat),
-                _lib.ptr(ranks_depth), _lib.ptr(ranks_feat), _lib.ptr(ranks_bev), _lib.ptr(lengths),
+                _lib.ptr(rd), _lib.ptr(rf), _lib.ptr(rb), _lib.ptr(lengths),
                 _lib.ptr(starts), int(feat.shape[-1]), int(lengths.numel()), _lib.stream_ptr(depth.device))
         _lib.check(rc, 'dhd_bev_pool_v2_backward')
         return depth_grad, feat_grad, None, None, None, None, None, None
+
+
+_regroup_cache = {}   # device index -> (stamp, tensors kept alive, result): the last regrouping per device
+
+
+def _regrouped(lib, ranks_depth, ranks_feat, ranks_bev, n_pixels):
+    """(ranks_depth, ranks_feat, ranks_bev) ordered by feature pixel + one (start, length) interval per pixel."""
+    dev = ranks_feat.device
+    srcs = (ranks_depth, ranks_feat, ranks_bev)
+    stamp = tuple((t.data_ptr(), t._version, t.numel()) for t in srcs) + (n_pixels,)
+    hit = _regroup_cache.get(dev.index)
+    if hit is not None and hit[0] == stamp:
+        return hit[2]
+    n = int(ranks_feat.numel())
+    with torch.cuda.device(dev):
+        out = [torch.empty(max(n, 1), dtype=torch.int32, device=dev) for _ in range(3)]
+        starts = torch.empty(n_pixels, dtype=torch.int32, device=dev)
+        lengths = torch.empty(n_pixels, dtype=torch.int32, device=dev)
+        nbytes = int(lib.dhd_bev_pool_v2_regroup_scratch_bytes(n, n_pixels))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rc = lib.dhd_bev_pool_v2_regroup(_lib.ptr(ranks_depth), _lib.ptr(ranks_feat), _lib.ptr(ranks_bev), n, n_pixels,
+                                         _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(starts), _lib.ptr(lengths),
+                                         _lib.ptr(scratch), nbytes, _lib.stream_ptr(dev))
+    _lib.check(rc, 'dhd_bev_pool_v2_regroup')
+    res = (out[0], out[1], out[2], starts, lengths)
+    _regroup_cache[dev.index] = (stamp, srcs, res)   # srcs kept alive: their addresses cannot be recycled for other lists
+    return res
 
 
 def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,

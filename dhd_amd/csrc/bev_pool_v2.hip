@@ -83,6 +83,7 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_kernel(int c, int n_in
   if (iv >= n_intervals) return;
   const int start = interval_starts[iv];
   const int len = interval_lengths[iv];
+  if (len <= 0) return;               // an empty interval (dhd_bev_pool_v2_regroup lists every pixel): nothing to write
   const int pix = ranks_feat[start];  // every point of the interval shares the pixel (bev_pool.py:47-57)
   const int n_cc = (c + DHD_WAVE - 1) / DHD_WAVE;
   for (int s0 = 0; s0 < len; s0 += DHD_WAVE) {
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_fast_kernel(int c, int
   if (iv >= n_intervals) return;
   const int start = __builtin_amdgcn_readfirstlane(interval_starts[iv]);
   const int len = __builtin_amdgcn_readfirstlane(interval_lengths[iv]);
+  if (len <= 0) return;               // empty interval: nothing to write
   const int pix = __builtin_amdgcn_readfirstlane(ranks_feat[start]);
   float fv[NCC], facc[NCC];
 #pragma unroll
@@ -259,9 +261,9 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_vec_kernel(int n_inter
   constexpr int G = DHD_WAVE / L;
   const int lane = threadIdx.x & 63, grp = lane / L, cl = lane % L;
   const int iv = (blockIdx.x * kWaves + (threadIdx.x >> 6)) * G + grp;
-  const bool valid = iv < n_intervals;
+  const int len = iv < n_intervals ? interval_lengths[iv] : 0;
+  const bool valid = len > 0;                      // empty intervals (and the padding of the last wave) write nothing
   const int start = valid ? interval_starts[iv] : 0;
-  const int len = valid ? interval_lengths[iv] : 0;
   const int pix = valid ? ranks_feat[start] : 0;   // every point of the interval shares the pixel (bev_pool.py:47-57)
   const pf4 fv = valid ? feat[(size_t)pix * L + cl] : pf4{0.f, 0.f, 0.f, 0.f};
   pf4 facc = {0.f, 0.f, 0.f, 0.f};
@@ -301,6 +303,86 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_vec_kernel(int n_inter
   if (valid) feat_grad[(size_t)pix * L + cl] = facc;  // one writer per pixel (:120-121)
 }
 
+// ------------------------------------------------------------------------------------------------
+// dhd_bev_pool_v2_regroup: the re-grouping of the point lists by feature pixel that QuickCumsumCuda.backward performs with
+// argsort + gathers + a run-length scan on every call (bev_pool.py:47-57), as a device counting sort: count per pixel ->
+// exclusive scan -> scatter, then the points of every pixel ordered by ranks_depth so that the result (and the float sums of
+// the backward kernel) do not depend on the arrival order of the counting atomics.  One interval per pixel, empty ones included
+// (length 0): no count has to travel to the host.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void regroup_count_kernel(const int* __restrict__ ranks_feat, int n_points, int n_pixels,
+                                                                int* __restrict__ count, int* __restrict__ rnk) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_points) return;
+  const int p = ranks_feat[i];
+  rnk[i] = (p >= 0 && p < n_pixels) ? atomicAdd(&count[p], 1) : -1;   // out-of-range pixels are dropped
+}
+
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(kScanBlock) void regroup_scan_kernel(const int* __restrict__ count, int n_pixels, int* __restrict__ starts,
+                                                                   int* __restrict__ lengths) {
+  __shared__ int wsum[kScanBlock / DHD_WAVE];
+  __shared__ int carry_s;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_pixels; base += kScanBlock) {
+    const int i = base + t;
+    const int v = i < n_pixels ? count[i] : 0;
+    int incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, DHD_WAVE);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int off = carry_s;
+    for (int k = 0; k < wv; ++k) off += wsum[k];
+    if (i < n_pixels) { starts[i] = off + incl - v; lengths[i] = v; }
+    __syncthreads();
+    if (t == kScanBlock - 1) carry_s = off + incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void regroup_scatter_kernel(const int* __restrict__ rd, const int* __restrict__ rf,
+                                                                  const int* __restrict__ rb, const int* __restrict__ rnk,
+                                                                  const int* __restrict__ starts, int n_points,
+                                                                  int* __restrict__ t_rd, int* __restrict__ t_rb) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_points) return;
+  const int r = rnk[i];
+  if (r < 0) return;
+  const int pos = starts[rf[i]] + r;
+  t_rd[pos] = rd[i];
+  t_rb[pos] = rb[i];
+}
+
+// final order inside a pixel: ascending ranks_depth (unique per point of a grid); thread = one grouped entry
+__global__ __launch_bounds__(kBlock) void regroup_order_kernel(const int* __restrict__ t_rd, const int* __restrict__ t_rb,
+                                                                const int* __restrict__ starts, const int* __restrict__ lengths,
+                                                                int n_pixels, int* __restrict__ o_rd, int* __restrict__ o_rf,
+                                                                int* __restrict__ o_rb) {
+  // one wave per pixel: its entries (a few dozen) are ranked against each other
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6);
+  if (p >= n_pixels) return;
+  const int s0 = starts[p], len = lengths[p];
+  for (int a = lane; a < len; a += DHD_WAVE) {
+    const int mine = t_rd[s0 + a], vox = t_rb[s0 + a];
+    int r = 0;
+    for (int k = 0; k < len; ++k) {
+      const int other = t_rd[s0 + k];
+      r += (other < mine) || (other == mine && k < a);
+    }
+    o_rd[s0 + r] = mine;
+    o_rb[s0 + r] = vox;
+    o_rf[s0 + r] = p;
+  }
+}
+
+inline size_t regroup_align(size_t v) { return (v + 63) & ~(size_t)63; }   // ints: 256-byte sections
+
 inline int vec_lanes(int c) {  // L = C / 4 when that is a power of two <= 64 and every row is 16-byte aligned, else 0
   if (c % 4 != 0) return 0;
   const int l = c / 4;
@@ -337,6 +419,43 @@ int dhd_bev_pool_v2_forward(const float* depth, const float* feat, float* out, c
   }
 #undef DHD_FWD_VEC
   DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+size_t dhd_bev_pool_v2_regroup_scratch_bytes(int n_points, int n_pixels) {
+  if (n_points < 0 || n_pixels <= 0) return 0;
+  return 4 * (regroup_align((size_t)n_pixels) + 3 * regroup_align((size_t)n_points));
+}
+
+int dhd_bev_pool_v2_regroup(const int32_t* ranks_depth, const int32_t* ranks_feat, const int32_t* ranks_bev, int n_points,
+                            int n_pixels, int32_t* ranks_depth_bp, int32_t* ranks_feat_bp, int32_t* ranks_bev_bp,
+                            int32_t* interval_starts_bp, int32_t* interval_lengths_bp, void* scratch, size_t scratch_bytes,
+                            void* stream) {
+  if (n_points < 0 || n_pixels <= 0) return DHD_EINVAL;
+  if (!interval_starts_bp || !interval_lengths_bp || !scratch) return DHD_EINVAL;
+  if (n_points > 0 && (!ranks_depth || !ranks_feat || !ranks_bev || !ranks_depth_bp || !ranks_feat_bp || !ranks_bev_bp))
+    return DHD_EINVAL;
+  if (scratch_bytes < dhd_bev_pool_v2_regroup_scratch_bytes(n_points, n_pixels)) return DHD_ENOSPACE;
+  hipStream_t st = dhd_stream(stream);
+  int* count = static_cast<int*>(scratch);
+  int* rnk = count + regroup_align((size_t)n_pixels);
+  int* t_rd = rnk + regroup_align((size_t)n_points);
+  int* t_rb = t_rd + regroup_align((size_t)n_points);
+  DHD_HIP(hipMemsetAsync(count, 0, (size_t)n_pixels * 4, st));
+  if (n_points > 0) {
+    hipLaunchKernelGGL(regroup_count_kernel, dim3(dhd_cdiv(n_points, kBlock)), dim3(kBlock), 0, st, ranks_feat, n_points, n_pixels, count,
+                       rnk);
+    DHD_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(regroup_scan_kernel, dim3(1), dim3(kScanBlock), 0, st, count, n_pixels, interval_starts_bp, interval_lengths_bp);
+  DHD_LAUNCH_CHECK();
+  if (n_points > 0) {
+    hipLaunchKernelGGL(regroup_scatter_kernel, dim3(dhd_cdiv(n_points, kBlock)), dim3(kBlock), 0, st, ranks_depth, ranks_feat, ranks_bev,
+                       rnk, interval_starts_bp, n_points, t_rd, t_rb);
+    hipLaunchKernelGGL(regroup_order_kernel, dim3(dhd_cdiv(n_pixels, kBlock / DHD_WAVE)), dim3(kBlock), 0, st, t_rd, t_rb,
+                       interval_starts_bp, interval_lengths_bp, n_pixels, ranks_depth_bp, ranks_feat_bp, ranks_bev_bp);
+    DHD_LAUNCH_CHECK();
+  }
   return DHD_OK;
 }
 

@@ -14,9 +14,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // -ffp-contract=off, so neither product is fused into the add.
 __device__ __forceinline__ float ema1(float v, float m, float d, float omd) { return v * d + omd * m; }
 
+// decay_dev != nullptr: the two factors are read from device memory {decay, 1 - decay} (a launch captured into a HIP graph
+// keeps its kernel arguments: the ramping decay of the reference must then come from memory the host refreshes per replay)
 __global__ __launch_bounds__(kEmaBlock) void ema_update_kernel(const uint64_t* __restrict__ ema_addr,
                                                                const uint64_t* __restrict__ model_addr,
-                                                               const int* __restrict__ len, float d, float omd) {
+                                                               const int* __restrict__ len, float d, float omd,
+                                                               const float* __restrict__ decay_dev) {
+  if (decay_dev) { d = decay_dev[0]; omd = decay_dev[1]; }
   const int chunk = blockIdx.x;
   float* __restrict__ e = reinterpret_cast<float*>(ema_addr[chunk]);
   const float* __restrict__ m = reinterpret_cast<const float*>(model_addr[chunk]);
@@ -64,7 +68,18 @@ extern "C" int dhd_ema_update(const uint64_t* ema_addr, const uint64_t* model_ad
   if (n_chunks == 0) return DHD_OK;
   if (!ema_addr || !model_addr || !len) return DHD_EINVAL;
   hipLaunchKernelGGL(ema_update_kernel, dim3(n_chunks), dim3(kEmaBlock), 0, dhd_stream(stream), ema_addr, model_addr, len, decay,
-                     one_minus_decay);
+                     one_minus_decay, static_cast<const float*>(nullptr));
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+extern "C" int dhd_ema_update_dev(const uint64_t* ema_addr, const uint64_t* model_addr, const int* len, int n_chunks,
+                                  const float* decay_pair, void* stream) {
+  if (n_chunks < 0) return DHD_EINVAL;
+  if (n_chunks == 0) return DHD_OK;
+  if (!ema_addr || !model_addr || !len || !decay_pair) return DHD_EINVAL;
+  hipLaunchKernelGGL(ema_update_kernel, dim3(n_chunks), dim3(kEmaBlock), 0, dhd_stream(stream), ema_addr, model_addr, len, 0.f, 0.f,
+                     decay_pair);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }

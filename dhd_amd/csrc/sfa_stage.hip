@@ -8,10 +8,13 @@
 //
 // The two 1x1 convolutions are (C x C) x (C x B*HW) float32 GEMMs on NCHW data (six of them per forward +
 // backward).  They run on the matrix cores with everything element-wise FUSED into the operand path, so no
-// intermediate but y1 and y2 is ever stored.  Two GEMM modes (dhd_sfa_set_gemm_mode):
-//   1 (default) bf16 MFMA on an exact three-way split of every float32 operand, six products per a*b:
-//               float32-level accuracy at 6/16 of the f32-MFMA cost (pw_gemm6 / pw_wgrad6, see below);
-//   0           f32 MFMA (v_mfma_f32_32x32x2_f32), a plain float32 fma chain (pw_gemm / pw_wgrad).
+// intermediate but y1 and y2 is ever stored.  GEMM precision per call (dhd_sfa_weights.gemm, include/dhd_amd.h):
+//   bf16x3 (default) bf16 MFMA on a two-way split of every float32 operand, three products per a*b (error <= 3 * 2^-18 |ab|
+//               per product): pw_gemm_res<2> (weights resident in LDS) / pw_wgrad3;
+//   bf16x6      exact three-way split, six products per a*b: float32-level accuracy at 6/16 of the f32-MFMA cost
+//               (pw_gemm_res<3>, or pw_gemm6 with the weights streamed through LDS where the resident form does not cover the
+//               channel count; pw_wgrad6);
+//   f32         f32 MFMA (v_mfma_f32_32x32x2_f32), a plain float32 fma chain (pw_gemm / pw_wgrad).
 // Common structure:
 //   * forward / dgrad GEMM: a wave owns 32 pixels x 256 output channels (128 accumulator registers).  The
 //     activation operand is loaded straight from NCHW global memory into the MFMA operand layout (lane =
@@ -387,7 +390,15 @@ __global__ __launch_bounds__(kEwBlock) void bn_backward_coef_kernel(const float*
                                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                     int training, float* __restrict__ tab, float* __restrict__ dgamma,
                                                                     float* __restrict__ dbeta, float* __restrict__ dbias, int nb,
-                                                                    int c, int hw) {
+                                                                    int c, int hw, double* __restrict__ sums_out,
+                                                                    const double* __restrict__ sums_in, const double* __restrict__ loc_fwd,
+                                                                    const float* __restrict__ shift) {
+  // Cross-rank statistics (nn.SyncBatchNorm): with `sums_out` only this rank's sums are written, [sum g][C] |
+  // [sum g (y - mu)][C] | count, as doubles; with `sums_in` (their all-reduced values) the input-gradient coefficients use
+  // the global sums and count, while dgamma / dbeta stay this rank's sums (the caller's DDP averages parameter gradients),
+  // and the convolution-bias gradient is this rank's sum of dy, which no longer vanishes rank by rank:
+  //   sum_local dy = c0 S1_local + c1 sum_local y + n_local c2,   sum_local y = loc_fwd[ch] + n_local shift[ch]  (the forward
+  //   sums are those of y - shift).
   const int ch = blockIdx.x * kEwBlock + threadIdx.x;
   if (ch >= c) return;
   double s1 = 0.0, s2 = 0.0;
@@ -395,15 +406,23 @@ __global__ __launch_bounds__(kEwBlock) void bn_backward_coef_kernel(const float*
     s1 += (double)part[((size_t)q * 2) * c + ch];
     s2 += (double)part[((size_t)q * 2 + 1) * c + ch];
   }
-  const double n = (double)nb * (double)hw;
+  const double n_loc = (double)nb * (double)hw;
+  if (sums_out) {
+    sums_out[ch] = s1; sums_out[c + ch] = s2;
+    if (ch == 0) sums_out[2 * c] = n_loc;
+    return;
+  }
+  const double n = sums_in ? sums_in[2 * c] : n_loc;
+  const double g1 = sums_in ? sums_in[ch] : s1, g2 = sums_in ? sums_in[c + ch] : s2;
   const double rs = (double)rstd[ch], mu = (double)mean[ch], ga = (double)gamma[ch];
   if (dgamma) dgamma[ch] = (float)(rs * s2);
   if (dbeta) dbeta[ch] = (float)s1;
   double c0 = ga * rs, c1 = 0.0, c2 = 0.0, db = c0 * s1;
   if (training) {
-    c1 = -ga * rs * rs * rs * s2 / n;
-    c2 = -ga * rs * s1 / n - c1 * mu;
-    db = 0.0;  // sum of dy over the batch vanishes identically
+    c1 = -ga * rs * rs * rs * g2 / n;
+    c2 = -ga * rs * g1 / n - c1 * mu;
+    db = 0.0;  // sum of dy over the (whole) batch vanishes identically
+    if (sums_in) db = c0 * s1 + c1 * (loc_fwd[ch] + n_loc * (double)shift[ch]) + n_loc * c2;
   }
   if (dbias) dbias[ch] = (float)db;
   for (int b = 0; b < nb; ++b) {
@@ -683,10 +702,6 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm_kernel(const float* __res
 // NaN/Inf inputs propagate as NaN (Inf - Inf in the split) rather than Inf.
 // ------------------------------------------------------------------------------------------------
 
-#ifndef PWABL
-#define PWABL 0  // timing experiments only (results wrong when non-zero): 1 no weight refill/barrier, 2 no split, 4 no activation prefetch
-#endif
-
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
@@ -717,7 +732,6 @@ __device__ __forceinline__ void split2_hm(float a, float b, unsigned& h, unsigne
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
-  if (PWABL & 16) { c[0] += __uint_as_float(a[0] ^ b[0]); return c; }
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
@@ -864,17 +878,14 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
         unsigned hh, mm, ll;
-        if (PWABL & 2) { hh = mm = ll = __float_as_uint(v[2 * jp]) ^ __float_as_uint(v[2 * jp + 1]); } else
         split2(v[2 * jp], v[2 * jp + 1], hh, mm, ll);
         ah[jp] = hh; am[jp] = mm; al[jp] = ll;
       }
     }
     // next weight image (after the last step: a harmless reload that nobody reads)
-    if (!(PWABL & 1)) {
 #pragma unroll
-      for (int j = 0; j < kWst; ++j) wst[j] = wsrc[(size_t)min(kc + 1, kcn - 1) * wk + j * kPwBlock + tid];
-    }
-    if (!(PWABL & 4)) issue(cset, min(kc + 2, kcn - 1));  // past the end: a harmless reload of the last step
+    for (int j = 0; j < kWst; ++j) wst[j] = wsrc[(size_t)min(kc + 1, kcn - 1) * wk + j * kPwBlock + tid];
+    issue(cset, min(kc + 2, kcn - 1));  // past the end: a harmless reload of the last step
     const u32x4* img = lds6 + (kc & 1) * kImg + lane;
 #pragma unroll
     for (int t = 0; t < COT; t += 2) {
@@ -894,12 +905,12 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
       acc[t] = mfma_bf16(ah, bh0, acc[t]);
       acc[t + 1] = mfma_bf16(ah, bh1, acc[t + 1]);
     }
-    if (!(PWABL & 1)) {
+    {
       u32x4* dst = lds6 + ((kc + 1) & 1) * kImg;
 #pragma unroll
       for (int j = 0; j < kWst; ++j) dst[j * kPwBlock + tid] = wst[j];
     }
-    if (!(PWABL & 1)) __syncthreads();
+    __syncthreads();
   };
   for (int kc = 0; kc < kcn; kc += 2) {
     step(I0{}, kc);
@@ -931,7 +942,6 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ((word >> (8 * q + e)) & 1u) ? v[e] : 0.f;
       }
-      if ((PWABL & 8) && v.x != 12345.678f) continue;
       *reinterpret_cast<f32x4*>(y + row + p) = v;
     }
     if (EPI == 0 && stat_part != nullptr) {  // block-uniform
@@ -1001,20 +1011,6 @@ __global__ __launch_bounds__(kEwBlock) void pack_weight_res_kernel(const float* 
 }
 
 constexpr int kResTrPitch = 36;
-#ifndef RES_X5
-#define RES_X5 0  // experiment: with two weight parts keep three activation parts (five products, drops only ah*bl).
-                  // Measured: stage output error 2.2e-5 -> 8.6e-6, GEMMs 96-112 -> 125-139 us (stage 1.35 -> 1.56 ms): not taken
-#endif
-
-#ifndef RESABL
-#define RESABL 0  // timing experiments only (results wrong when non-zero): 1 no stores, 2 every tile reads the pixels of tile 0 (L2-resident), 4 no MFMA,
-                  // 8 per-wave phase clocks of the one-input kernel into g_res_tl (read back with dhd_debug_res_timeline)
-#endif
-#if RESABL & 8
-__device__ unsigned long long g_res_tl[4 * 256 * 8 * 8];   // [variant][block][wave][wait, prologue, loads+mfma, epilogue, total, steps, tiles, begin]
-#define RES_CLK() __builtin_readcyclecounter()
-#endif
-
 // word with lane L replaced by the wave-uniform value sval (v_writelane_b32: one VALU instruction).  gfx940+ needs two
 // wait states between a VALU write of an SGPR (the v_cmp that made sval) and a VALU read of it; the compiler inserts
 // them for its own instructions but cannot see into inline assembly (without them: stale pass bits, found by the
@@ -1085,7 +1081,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
     wtg = min(wtg, total - 1);                    // past the end: a harmless re-read of the last tile
     t.b = wtg / nwt;
     t.wt = wtg - t.b * nwt;
-    const int pc = (RESABL & 2) ? r : min(t.wt * 32 + r, hw - 1);
+    const int pc = min(t.wt * 32 + r, hw - 1);
     t.voff = (pc + 8 * h * hw) * 4;
     t.r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in0 + (size_t)t.b * in_bstride), 0, in_bytes, 0x00020000);
     t.r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((TWO_IN ? in1 : in0) + (size_t)t.b * in_bstride), 0, in_bytes, 0x00020000);
@@ -1103,24 +1099,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
       if (TWO_IN) raw1[S][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(t.r1, t.voff, so + j * row_bytes, AUX));
     }
   };
-#if RESABL & 8
-  unsigned long long tl_wait = 0, tl_pro = 0, tl_mfma = 0, tl_epi = 0, tl_steps = 0, tl_tiles = 0;
-  const unsigned long long tl_begin = RES_CLK();
-#endif
   f32x16 acc[COB];
 
   // one 16-channel step: consume register set CS (loaded for (cur, kc)), refill it for (pf, kpf), then the MFMAs
   auto step = [&](auto cset, auto first_tag, const Tile& cur, int kc, const Tile& pf, int kpf) {
     constexpr int CS = decltype(cset)::value;
     constexpr bool FIRST = decltype(first_tag)::value;   // first step of a tile: the accumulators start from zero
-    constexpr int NTA = (NT == 2 && RES_X5) ? 3 : NT;   // parts of the activation operand
-    u32x4 at[NTA];
-#if RESABL & 8
-    const unsigned long long tl0 = RES_CLK();
-    if (!TWO_IN && D == 4) __builtin_amdgcn_s_waitcnt(0x4F78);   // vmcnt(24): this step's register set has landed
-    const unsigned long long tl1 = RES_CLK();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    u32x4 at[NT];
     {
       const int ci = 16 * kc + 8 * h;
       const float* cb = cf + (size_t)cur.b * 3 * c + ci;
@@ -1161,9 +1146,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
         unsigned hh, mm, ll;
-        if (NTA == 3) {
+        if (NT == 3) {
           split2(v[2 * jp], v[2 * jp + 1], hh, mm, ll);
-          at[NTA - 1][jp] = ll;
+          at[NT - 1][jp] = ll;
         } else {
           split2_hm(v[2 * jp], v[2 * jp + 1], hh, mm);
         }
@@ -1175,9 +1160,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
     // four prologues to the top of the loop body -- i.e. consume every register set right after it was requested.
     // Scheduling barriers pin the order  prologue(kc) -> loads(kc + D) -> MFMAs(kc).
     __builtin_amdgcn_sched_barrier(0);
-#if RESABL & 8
-    const unsigned long long tl2 = RES_CLK();
-#endif
     issue(cset, pf, kpf);
     __builtin_amdgcn_sched_barrier(0);
     const u32x4* img = ldsr + kc * (COB * NT * 64) + lane;
@@ -1193,24 +1175,18 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
 #pragma unroll
         for (int m = 0; m < NT; ++m) bf[u][m] = img[((t0 + u) * NT + m) * 64];
       // product order (smallest first): NT = 3: l*h, h*l, m*m, m*h, h*m, h*h;  NT = 2: m*h, h*m, h*h
-      //                               "x5" (three activation parts, two weight parts): l*h, m*m, m*h, h*m, h*h
-      constexpr int kProd = NT == 3 ? 6 : (NTA == 3 ? 5 : 3);
+      constexpr int kProd = NT == 3 ? 6 : 3;
       constexpr int pa3[6] = {2, 0, 1, 1, 0, 0}, pb3[6] = {0, 2, 1, 0, 1, 0};
-      constexpr int pa5[5] = {2, 1, 1, 0, 0}, pb5[5] = {0, 1, 0, 1, 0};
       constexpr int pa2[3] = {1, 0, 0}, pb2[3] = {0, 1, 0};
 #pragma unroll
       for (int q = 0; q < kProd; ++q) {
-        const int ia = NT == 3 ? pa3[q] : (NTA == 3 ? pa5[q] : pa2[q]), ib = NT == 3 ? pb3[q] : (NTA == 3 ? pb5[q] : pb2[q]);
+        const int ia = NT == 3 ? pa3[q] : pa2[q], ib = NT == 3 ? pb3[q] : pb2[q];
 #pragma unroll
         for (int u = 0; u < TP; ++u)
-          if (!(RESABL & 4) || q == 0) acc[t0 + u] = mfma_bf16(at[ia], bf[u][ib], (FIRST && q == 0) ? zero : acc[t0 + u]);
+          acc[t0 + u] = mfma_bf16(at[ia], bf[u][ib], (FIRST && q == 0) ? zero : acc[t0 + u]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-#if RESABL & 8
-    const unsigned long long tl3 = RES_CLK();
-    tl_wait += tl1 - tl0; tl_pro += tl2 - tl1; tl_mfma += tl3 - tl2; tl_steps += 1;
-#endif
   };
 
   int wtg = team * WAVES + wv;
@@ -1263,9 +1239,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
     // store instruction would write 64 separate 16-byte pieces (adjacent lanes = different channel rows): measured 40 us
     // of a 125 us GEMM.  Each half tile (16 channels x 32 pixels) goes through a wave-private LDS patch instead and is
     // written row-wise: 8 adjacent lanes = one whole 128-byte line, 8 lines per store instruction.
-#if RESABL & 8
-    const unsigned long long tl_e0 = RES_CLK();
-#endif
     const int p0 = cur.wt * 32;
     const int co0 = g * 32 * COB + r;
     const bool full = p0 + 32 <= hw;               // wave-uniform; always true when hw % 32 == 0
@@ -1310,7 +1283,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
         for (int k = 0; k < 2; ++k) {
           const f32x4 w = *reinterpret_cast<const f32x4*>(tr + ((lane >> 3) + 8 * k) * kTrPitch + 4 * (lane & 7));
           const int srow = (g * 32 * COB + 32 * t + 16 * ph + 8 * k) * row_bytes;   // scalar
-          if ((RESABL & 1) && w.x != 12345.678f) continue;
           if (st_ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), ry, vst, srow, 0);
         }
       }
@@ -1328,19 +1300,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
       }
     }
     cur = nxt;
-#if RESABL & 8
-    tl_epi += RES_CLK() - tl_e0; tl_tiles += 1;
-#endif
   }
   flush_stats();
-#if RESABL & 8
-  if (lane == 0 && blockIdx.x < 256) {   // variant: 0 one-input forward, 1 two-input forward, 2 dgrad with mask, 3 dgrad plain
-    unsigned long long* q = g_res_tl + (((TWO_IN ? 1 + EPI : 0) * 256 + blockIdx.x) * 8 + wv) * 8;
-    q[0] = tl_wait; q[1] = tl_pro; q[2] = tl_mfma; q[3] = tl_epi; q[4] = RES_CLK() - tl_begin; q[5] = tl_steps; q[6] = tl_tiles;
-    q[7] = tl_begin;
-  }
-#endif
 }
+
 
 // The GEMM epilogues' statistics rows [n][2][c] (n = samples x wave tiles: 5000 rows, 10 MB at B = 4) -> batch statistics and
 // everything bn_train_finalize_kernel derives from them, in ONE launch (stat_reduce_kernel + bn_train_finalize_kernel took
@@ -1354,7 +1317,11 @@ __global__ __launch_bounds__(kEwBlock) void bn_stats_finalize_kernel(const float
                                                                      float* __restrict__ run_var, float momentum, float eps,
                                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                                      float* __restrict__ scsh, float* __restrict__ tab, int nb, int c,
-                                                                     int hw) {
+                                                                     int hw, double* __restrict__ sums_out, double* __restrict__ sums_out2,
+                                                                     const double* __restrict__ sums_in) {
+  // Cross-rank statistics (nn.SyncBatchNorm, dhd_sfa_stage_*_phase): with `sums_out` the kernel stops after the row
+  // reduction and leaves this rank's shifted sums as doubles, [sum (y - shift)][C] | [sum (y - shift)^2][C] | count, in
+  // sums_out and sums_out2; with `sums_in` it starts from such a vector (all-reduced by the caller) instead of the rows.
   __shared__ double sm[kEwBlock][8];
   const int nblk = gridDim.x, t = threadIdx.x;
   const int cg = nblk >= 8 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;   // nblk is a multiple of 8 here
@@ -1363,6 +1330,7 @@ __global__ __launch_bounds__(kEwBlock) void bn_stats_finalize_kernel(const float
   const f32x4* p2 = reinterpret_cast<const f32x4*>(part + c + ch0);
   const size_t row4 = (size_t)(2 * c) / 4;   // f32x4 units per row
   f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, b1 = a1, b2 = a1;
+  if (sums_in) n = 0;
   int i = t;
   for (; i + kEwBlock < n; i += 2 * kEwBlock) {
     a1 += p1[(size_t)i * row4];
@@ -1389,8 +1357,15 @@ __global__ __launch_bounds__(kEwBlock) void bn_stats_finalize_kernel(const float
   }
   if (t >= 4) return;
   const int ch = ch0 + t;
-  const double s1 = sm[0][t], s2 = sm[0][4 + t];
-  const double cnt = (double)nb * (double)hw;
+  double s1 = sm[0][t], s2 = sm[0][4 + t];
+  double cnt = (double)nb * (double)hw;
+  if (sums_out) {
+    sums_out[ch] = s1; sums_out[c + ch] = s2;
+    sums_out2[ch] = s1; sums_out2[c + ch] = s2;
+    if (ch == 0) { sums_out[2 * c] = cnt; sums_out2[2 * c] = cnt; }
+    return;
+  }
+  if (sums_in) { s1 = sums_in[ch]; s2 = sums_in[c + ch]; cnt = sums_in[2 * c]; }
   const double md = s1 / cnt;
   double var = s2 / cnt - md * md;
   if (var < 0.0) var = 0.0;
@@ -1740,10 +1715,6 @@ __global__ __launch_bounds__(kWgBlock, 2) void pw_wgrad6_kernel(const float* __r
 //     touched per instruction, each line touched by four instructions).  An 8-pixel item is then assembled with one
 //     lane-pair exchange (DPP quad_perm): of the rows loaded by instructions 2a and 2a+1, the even lane keeps its piece
 //     of row 2a and takes its neighbour's, the odd lane does the same for row 2a+1.
-#ifndef WGABL
-#define WGABL 0  // timing experiments only (results wrong when non-zero): 1 loads only for the first step, 2 no MFMA, 4 no prologue / split,
-                 // 8 half the steps, 32 a quarter of the steps, 16 no partial stores
-#endif
 template <int OT, bool A_TWO, bool B_TWO, bool B_RELU>
 __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
                                                                 const float* __restrict__ acoef, size_t a_bstride,
@@ -1768,7 +1739,7 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
   // ... so that at any moment the workers together read one contiguous span of every channel row: 141 / 130 vs 133 / 128 us.)
   const int w_id = blockIdx.x;
   const int first = (int)(n_steps * w_id / n_workers);
-  const int count = ((int)(n_steps * (w_id + 1) / n_workers) - first) >> ((WGABL & 8) ? 1 : 0) >> ((WGABL & 32) ? 2 : 0);
+  const int count = (int)(n_steps * (w_id + 1) / n_workers) - first;
   auto step_of = [&](int k) { return first + min(k, count - 1); };   // past the end: the last step again
 
   // loads: instruction j reads rows 64 j + 8 wv + (lane >> 3), four pixels 4 (lane & 7) ..
@@ -1828,19 +1799,6 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
       for (int a = 0; a < NA; ++a) {
         const float k0 = op ? cfb[a][0] : cfa[a][0], k1 = op ? cfb[a][1] : cfa[a][1], k2 = op ? cfb[a][2] : cfa[a][2];
         const f32x2 k0v = {k0, k0}, k1v = {k1, k1}, k2v = {k2, k2};
-        if (WGABL & 4) {
-          const int row = 64 * (2 * a + odd) + ld_row;
-          u32x4* dst = ldsw + buf * kBuf + (it_ks * 2 + op) * kOp + (row >> 5) * 128 + (row & 31) + 32 * it_h;
-          u32x4 v0, v1;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v0[e] = __float_as_uint(raw[op][0][2 * a][e]) ^ __float_as_uint(two ? raw[op][1][2 * a][e] : k0);
-            v1[e] = __float_as_uint(raw[op][0][2 * a + 1][e]) ^ __float_as_uint(two ? raw[op][1][2 * a + 1][e] : k1);
-          }
-          dst[0] = v0;
-          dst[64] = v1;
-          continue;
-        }
         // assemble the item: [lo 4 pixels | hi 4 pixels] of this thread's row, per input
         float x[2][8];
 #pragma unroll
@@ -1889,7 +1847,7 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
     // unconditional (indices clamped to the last step, whose re-staged copy nobody reads), see pw_wgrad6_kernel.
     // (tried: operand by operand -- stage A(s+1), request A(s+2), stage B(s+1), request B(s+2): no gain)
     stage(step_of(k + 1), buf ^ 1);
-    if (!(WGABL & 1)) fetch(step_of(k + 2));
+    fetch(step_of(k + 2));
     // keep the loads of step s + 2 ahead of this step's MFMAs (the scheduler sinks them to the end)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1907,11 +1865,6 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
 #pragma unroll
         for (int t = 0; t < 2; ++t) fa[t] = ta[(((wco >> 5) + i) * 2 + t) * 64];
         // terms: 0 = high, 1 = mid; smallest products first
-        if (WGABL & 2) {
-#pragma unroll
-          for (int j = 0; j < TB; ++j) acc[i][j][0] += __uint_as_float(fa[1][0] ^ fb[j][0][0] ^ fa[0][1] ^ fb[j][1][1]);
-          continue;
-        }
 #pragma unroll
         for (int j = 0; j < TB; ++j) acc[i][j] = mfma_bf16(fa[1], fb[j][0], acc[i][j]);
 #pragma unroll
@@ -1932,7 +1885,6 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
       for (int e = 0; e < 16; ++e) {
         const int co = ob_co + wco + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
         const int ci = ob_ci + wci + 32 * j + r;
-        if ((WGABL & 16) && acc[i][j][e] != 123.456f) continue;
         po[(size_t)co * c + ci] = acc[i][j][e];
       }
 }
@@ -1972,7 +1924,7 @@ __global__ __launch_bounds__(kEwBlock) void wgrad_reduce_kernel(const float* __r
 inline size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }  // in floats: 256-byte sections
 
 struct SavedLayout {
-  size_t s, h, a1, tab_a, mean1, rstd1, scsh1, tab1, mean2, rstd2, scsh2, mask, y1, y2, total;
+  size_t s, h, a1, tab_a, mean1, rstd1, scsh1, tab1, mean2, rstd2, scsh2, loc1, loc2, mask, y1, y2, total;
 };
 SavedLayout saved_layout(int b, int c, int hw, int r) {
   SavedLayout L;
@@ -1984,6 +1936,7 @@ SavedLayout saved_layout(int b, int c, int hw, int r) {
   L.tab_a = take((size_t)b * 3 * c);
   L.mean1 = take(c); L.rstd1 = take(c); L.scsh1 = take(2 * c); L.tab1 = take((size_t)b * 3 * c);
   L.mean2 = take(c); L.rstd2 = take(c); L.scsh2 = take(2 * c);
+  L.loc1 = take(2 * (2 * (size_t)c + 1)); L.loc2 = take(2 * (2 * (size_t)c + 1));   // (2C + 1) doubles each: this rank's shifted sums + count (phased calls)
   L.mask = take((size_t)b * c * ((hw + 31) / 32));  // ReLU pass bits, one word per (32 pixels, channel): [sample][wave tile][channel]
   L.y1 = take((size_t)b * c * hw);
   L.y2 = take((size_t)b * c * hw);
@@ -2059,7 +2012,6 @@ inline int set_call_mode(int gemm) {
     default: return DHD_EINVAL;
   }
 }
-inline bool mode_streamed() { return g_gemm_mode == 2 || g_gemm_mode == 4; }
 inline bool mode_resident() { return g_gemm_mode == 1 || g_gemm_mode == 3; }
 inline int mode_terms() { return g_gemm_mode == 3 ? 2 : 3; }
 
@@ -2068,22 +2020,8 @@ constexpr size_t kResTrBytes = (size_t)kResWaves * 16 * kResTrPitch * sizeof(flo
 constexpr size_t kLdsBytes = 160 * 1024;           // per-CU LDS of gfx950
 constexpr size_t kResWeightMax = 128 * 1024;       // budget for the weight fragments
 // 32-channel output tiles per resident workgroup: the largest of 4 / 2 / 1 whose fragments fit; 0 = does not fit
-inline int res_cob_cap() {  // experiment knob: DHD_SFA_RES_COB=1|2|4 caps the output tiles per workgroup
-  static int cap = 0;
-  if (cap == 0) {
-    const char* e = getenv("DHD_SFA_RES_COB");
-    cap = e ? atoi(e) : 4;
-    if (cap != 1 && cap != 2 && cap != 4) cap = 4;
-  }
-  return cap;
-}
-inline int res_aux() {  // experiment knob: DHD_SFA_RES_AUX=2 makes the activation loads non-temporal
-  static int aux = -1;
-  if (aux < 0) { const char* e = getenv("DHD_SFA_RES_AUX"); aux = e && atoi(e) == 2 ? 2 : 0; }
-  return aux;
-}
 inline int res_cob(int c, int nt) {
-  for (int cob = res_cob_cap(); cob >= 1; cob >>= 1)
+  for (int cob = 4; cob >= 1; cob >>= 1)
     if (32 * cob <= c && (size_t)(c / 16) * cob * nt * 1024 <= kResWeightMax) return cob;
   return 0;
 }
@@ -2160,17 +2098,10 @@ int launch_pw_gemm_res(const float* in0, const float* in1, size_t in_bstride, in
     float* yo = y + (size_t)b0 * c * hw;
 #define DHD_RES(NT, COB, KCN, TWO, RELU, EPI)                                                                            \
   do {                                                                                                                \
-    if (res_aux() == 2) {                                                                                             \
-      auto kern = pw_gemm_res_kernel<NT, COB, KCN, TWO, RELU, EPI, kResWaves, 2, 4>;                                  \
-      DHD_LDS_ATTR_ONCE(kern, kLdsBytes);                                                                             \
-      hipLaunchKernelGGL(kern, grid, dim3(kResWaves * 64), shmem, st, i0, i1, in_bstride, in_bytes, cf,               \
-                         reinterpret_cast<const u32x4*>(wp), bias, rm, sp, yo, c, hw, nb, groups, nteams);            \
-    } else {                                                                                                          \
-      auto kern = pw_gemm_res_kernel<NT, COB, KCN, TWO, RELU, EPI, kResWaves, 0, 4>;                                  \
-      DHD_LDS_ATTR_ONCE(kern, kLdsBytes);                                                                             \
-      hipLaunchKernelGGL(kern, grid, dim3(kResWaves * 64), shmem, st, i0, i1, in_bstride, in_bytes, cf,               \
-                         reinterpret_cast<const u32x4*>(wp), bias, rm, sp, yo, c, hw, nb, groups, nteams);            \
-    }                                                                                                                 \
+    auto kern = pw_gemm_res_kernel<NT, COB, KCN, TWO, RELU, EPI, kResWaves, 0, 4>;                                    \
+    DHD_LDS_ATTR_ONCE(kern, kLdsBytes);                                                                               \
+    hipLaunchKernelGGL(kern, grid, dim3(kResWaves * 64), shmem, st, i0, i1, in_bstride, in_bytes, cf,                 \
+                       reinterpret_cast<const u32x4*>(wp), bias, rm, sp, yo, c, hw, nb, groups, nteams);              \
   } while (0)
 #define DHD_RES_V(NT, COB, KCN)                                                   \
   do {                                                                            \
@@ -2217,7 +2148,7 @@ int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in
   // three per CU, each about half as long), reading the same packed weights.  Measured -7 % (B = 1) and
   // -3 % (B = 2) on the stage; with more rounds the split gains nothing (B = 4: 1.715 vs 1.714 ms).
   int t_main = tps;
-  if (g_gemm_mode != 4 && g_gemm_mode != 0 && cot == 8) {
+  if (g_gemm_mode != 0 && cot == 8) {
     const int cus = cu_count();
     const long nrb = c / 256, n = (long)b * tps * nrb, slots = 2L * cus;
     if (cus > 0 && n < 2 * slots && n % slots != 0) {
@@ -2345,11 +2276,6 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
 
 extern "C" {
 
-#if RESABL & 8
-int dhd_debug_res_timeline(unsigned long long* host, int n) {
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_res_tl), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 int dhd_sfa_stage_supported(int c, int hw) { return stage_supported(c, hw) ? 1 : 0; }
 
@@ -2363,9 +2289,13 @@ size_t dhd_sfa_stage_scratch_bytes(int b, int c, int hw, int hidden) {
   return scratch_layout(b, c, hw, hidden).total * sizeof(float);
 }
 
-int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, void* saved, void* scratch, int b, int c, int hw,
-                          void* stream) {
-  if (!x || !w || !out || !saved || !scratch || b <= 0) return DHD_EINVAL;
+// Forward in up to three phases, cut at the two BatchNorm statistics points.  sync == nullptr: all phases in one call with
+// this call's own statistics.  sync != nullptr (nn.SyncBatchNorm): phases [lo, hi]; a phase that ends at a statistics point
+// leaves this rank's sums in `sync` ((2C + 1) doubles: [sum (y - bias)][C] | [sum (y - bias)^2][C] | count), the next phase
+// starts from the caller's all-reduced vector in the same place.
+static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, float* out, void* saved, void* scratch, int b, int c, int hw,
+                              int lo, int hi, double* sync, void* stream) {
+  if (!x || !w || !saved || !scratch || b <= 0 || (hi == 2 && !out)) return DHD_EINVAL;
   if (!stage_supported(c, hw) || w->hidden <= 0) return DHD_EUNSUPPORTED;
   if (!w->fc1_w || !w->fc1_b || !w->fc2_w || !w->fc2_b || !w->conv1_w || !w->conv1_b || !w->bn1_w || !w->bn1_b || !w->conv2_w ||
       !w->conv2_b || !w->bn2_w || !w->bn2_b)
@@ -2381,46 +2311,65 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
   const dim3 planes2(kPlaneChunks, b * 2 * c), planes(kPlaneChunks, b * c);
   const dim3 per_ch(dhd_cdiv(c, kEwBlock));
   const bool fused_stats = w->training && g_gemm_mode >= 1;  // BatchNorm sums come out of the GEMM epilogue
+  if (sync && !fused_stats) return DHD_EUNSUPPORTED;         // cross-rank statistics: training mode, bf16 GEMM precisions
   int stat_rows = 0;
+  int rc;
 
-  hipLaunchKernelGGL(plane_mean_kernel, planes2, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw);
-  hipLaunchKernelGGL(fc_forward_kernel, dim3(b), dim3(kFcBlock), (size_t)(2 * c + r) * sizeof(float), st, sc + T.mean_part,
-                     w->fc1_w, w->fc1_b, w->fc2_w, w->fc2_b, sv + S.s, sv + S.h, sv + S.a1, sv + S.tab_a, c, r, hw);
-  DHD_LAUNCH_CHECK();
-  int rc = launch_pack(w->conv1_w, 0, sc + T.wp1, c, st, w->conv2_w, sc + T.wp2);
-  if (rc != DHD_OK) return rc;
-
-  // y1 = conv1(blend1(x))
-  rc = launch_pw_gemm(x, x + (size_t)c * hw, (size_t)2 * c * hw, c, sv + S.tab_a, false, sc + T.wp1, w->conv1_b, nullptr, nullptr,
-                      nullptr, fused_stats ? sc + T.stat_part : nullptr, sv + S.y1, 0, b, c, hw, st, &stat_rows);
-  if (rc != DHD_OK) return rc;
-  if (w->training) {
-    if (fused_stats) {  // the GEMM epilogue left per-(sample, wave tile) sums shifted by the bias
+  if (lo <= 0) {
+    hipLaunchKernelGGL(plane_mean_kernel, planes2, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw);
+    hipLaunchKernelGGL(fc_forward_kernel, dim3(b), dim3(kFcBlock), (size_t)(2 * c + r) * sizeof(float), st, sc + T.mean_part,
+                       w->fc1_w, w->fc1_b, w->fc2_w, w->fc2_b, sv + S.s, sv + S.h, sv + S.a1, sv + S.tab_a, c, r, hw);
+    DHD_LAUNCH_CHECK();
+    rc = launch_pack(w->conv1_w, 0, sc + T.wp1, c, st, w->conv2_w, sc + T.wp2);
+    if (rc != DHD_OK) return rc;
+    // y1 = conv1(blend1(x))
+    rc = launch_pw_gemm(x, x + (size_t)c * hw, (size_t)2 * c * hw, c, sv + S.tab_a, false, sc + T.wp1, w->conv1_b, nullptr, nullptr,
+                        nullptr, fused_stats ? sc + T.stat_part : nullptr, sv + S.y1, 0, b, c, hw, st, &stat_rows);
+    if (rc != DHD_OK) return rc;
+    if (sync) {   // this rank's sums only (also kept in `saved` for the backward's convolution-bias gradient)
       hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, sc + T.stat_part, stat_rows, w->conv1_b, w->bn1_w,
                          w->bn1_b, w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1,
-                         sv + S.tab1, b, c, hw);
-    } else {
-      hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y1, sc + T.part, c, hw);
-      hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, b * kPlaneChunks, sv + S.y1, hw, w->bn1_w,
-                         w->bn1_b, w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1,
-                         sv + S.tab1, b, c, hw);
+                         sv + S.tab1, b, c, hw, sync, reinterpret_cast<double*>(sv + S.loc1), nullptr);
+      DHD_LAUNCH_CHECK();
     }
-  } else {
-    hipLaunchKernelGGL(bn_eval_coef_kernel, per_ch, dim3(kEwBlock), 0, st, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, w->eps1,
-                       sv + S.mean1, sv + S.rstd1, sv + S.scsh1, sv + S.tab1, b, c);
   }
-  DHD_LAUNCH_CHECK();
-  // y2 = conv2(relu(bn1(y1)))
-  rc = launch_pw_gemm(sv + S.y1, nullptr, (size_t)c * hw, c, sv + S.tab1, true, sc + T.wp2, w->conv2_b, nullptr, nullptr,
-                      reinterpret_cast<unsigned*>(sv + S.mask), fused_stats ? sc + T.stat_part : nullptr, sv + S.y2, 0,
-                      b, c, hw, st, &stat_rows);
-  if (rc != DHD_OK) return rc;
+  if (hi <= 0) return DHD_OK;
+  if (lo <= 1) {
+    if (w->training) {
+      if (fused_stats) {  // the GEMM epilogue left per-(sample, wave tile) sums shifted by the bias
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, sc + T.stat_part, stat_rows, w->conv1_b, w->bn1_w,
+                           w->bn1_b, w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1,
+                           sv + S.tab1, b, c, hw, nullptr, nullptr, sync);
+      } else {
+        hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y1, sc + T.part, c, hw);
+        hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, b * kPlaneChunks, sv + S.y1, hw, w->bn1_w,
+                           w->bn1_b, w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1,
+                           sv + S.tab1, b, c, hw);
+      }
+    } else {
+      hipLaunchKernelGGL(bn_eval_coef_kernel, per_ch, dim3(kEwBlock), 0, st, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, w->eps1,
+                         sv + S.mean1, sv + S.rstd1, sv + S.scsh1, sv + S.tab1, b, c);
+    }
+    DHD_LAUNCH_CHECK();
+    // y2 = conv2(relu(bn1(y1)))
+    rc = launch_pw_gemm(sv + S.y1, nullptr, (size_t)c * hw, c, sv + S.tab1, true, sc + T.wp2, w->conv2_b, nullptr, nullptr,
+                        reinterpret_cast<unsigned*>(sv + S.mask), fused_stats ? sc + T.stat_part : nullptr, sv + S.y2, 0,
+                        b, c, hw, st, &stat_rows);
+    if (rc != DHD_OK) return rc;
+    if (sync) {
+      hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, sc + T.stat_part, stat_rows, w->conv2_b, w->bn2_w,
+                         w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, sv + S.mean2, sv + S.rstd2, sv + S.scsh2,
+                         sc + T.tab_g2, b, c, hw, sync, reinterpret_cast<double*>(sv + S.loc2), nullptr);
+      DHD_LAUNCH_CHECK();
+    }
+  }
+  if (hi <= 1) return DHD_OK;
   float* tab_unused = sc + T.tab_g2;  // bn2 has no consumer GEMM in forward; table slot reused as a sink
   if (w->training) {
     if (fused_stats) {  // the GEMM epilogue left per-(sample, wave tile) sums shifted by the bias
       hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, sc + T.stat_part, stat_rows, w->conv2_b, w->bn2_w,
                          w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, sv + S.mean2, sv + S.rstd2, sv + S.scsh2,
-                         tab_unused, b, c, hw);
+                         tab_unused, b, c, hw, nullptr, nullptr, sync);
     } else {
       hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y2, sc + T.part, c, hw);
       hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, b * kPlaneChunks, sv + S.y2, hw, w->bn2_w,
@@ -2436,14 +2385,18 @@ int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, 
   return DHD_OK;
 }
 
-int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void* saved, const float* gout, float* gx,
-                           const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw, void* stream) {
-  if (!x || !w || !saved || !gout || !gx || !grads || !scratch || b <= 0) return DHD_EINVAL;
+// Backward in up to three phases, cut where the two BatchNorm backward passes need their sums (sum g, sum g (y - mu)); `sync`
+// as in stage_forward_impl ((2C + 1) doubles: [sum g][C] | [sum g (y - mu)][C] | count).
+static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const void* saved, const float* gout, float* gx,
+                               const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw, int lo, int hi, double* sync,
+                               void* stream) {
+  if (!x || !w || !saved || !gout || !grads || !scratch || b <= 0 || (hi == 2 && !gx)) return DHD_EINVAL;
   if (!stage_supported(c, hw) || w->hidden <= 0) return DHD_EUNSUPPORTED;
   if (!grads->fc1_w || !grads->fc1_b || !grads->fc2_w || !grads->fc2_b || !grads->conv1_w || !grads->conv1_b || !grads->bn1_w ||
       !grads->bn1_b || !grads->conv2_w || !grads->conv2_b || !grads->bn2_w || !grads->bn2_b)
     return DHD_EINVAL;
   if (set_call_mode(w->gemm) != DHD_OK) return DHD_EINVAL;
+  if (sync && !(w->training && g_gemm_mode >= 1)) return DHD_EUNSUPPORTED;
   hipStream_t st = dhd_stream(stream);
   const int r = w->hidden;
   const SavedLayout S = saved_layout(b, c, hw, r);
@@ -2453,27 +2406,44 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
   const dim3 planes(kPlaneChunks, b * c);
   const dim3 per_ch(dhd_cdiv(c, kEwBlock));
   const size_t cs = (size_t)c * hw;
+  int rc;
 
-  int rc = launch_pack(w->conv1_w, 1, sc + T.wp1t, c, st, w->conv2_w, sc + T.wp2t);
-  if (rc != DHD_OK) return rc;
-  // g2 = dL/ds2, BatchNorm-2 sums, go-part of dL/da
-  hipLaunchKernelGGL(blend2_bn_bwd_kernel, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, sv + S.mean2, gout,
-                     sc + T.g2, sc + T.part, sc + T.da1, c, hw);
-  hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn2_w, sv + S.mean2, sv + S.rstd2,
-                     w->training, sc + T.tab_g2, grads->bn2_w, grads->bn2_b, grads->conv2_b, b, c, hw);
-  DHD_LAUNCH_CHECK();
-  // dW2 = dy2 . z1^T
-  rc = launch_pw_wgrad(sc + T.g2, sv + S.y2, sc + T.tab_g2, cs, sv + S.y1, nullptr, sv + S.tab1, cs, true, sc + T.wpart,
-                           grads->conv2_w, b, c, hw, st);
-  if (rc != DHD_OK) return rc;
-  // g1 = (W2^T dy2) * [z1 > 0]
-  rc = launch_pw_gemm(sc + T.g2, sv + S.y2, cs, c, sc + T.tab_g2, false, sc + T.wp2t, nullptr, sv + S.y1, sv + S.scsh1,
-                      reinterpret_cast<unsigned*>(const_cast<float*>(sv + S.mask)), nullptr, sc + T.g1, 1, b,
-                      c, hw, st);
-  if (rc != DHD_OK) return rc;
-  hipLaunchKernelGGL(pair_sums_kernel, planes, dim3(kEwBlock), 0, st, sc + T.g1, sv + S.y1, sv + S.mean1, sc + T.part, c, hw);
+  if (lo <= 0) {
+    rc = launch_pack(w->conv1_w, 1, sc + T.wp1t, c, st, w->conv2_w, sc + T.wp2t);
+    if (rc != DHD_OK) return rc;
+    // g2 = dL/ds2, BatchNorm-2 sums, go-part of dL/da
+    hipLaunchKernelGGL(blend2_bn_bwd_kernel, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, sv + S.mean2, gout,
+                       sc + T.g2, sc + T.part, sc + T.da1, c, hw);
+    if (sync)
+      hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn2_w, sv + S.mean2, sv + S.rstd2,
+                         w->training, sc + T.tab_g2, grads->bn2_w, grads->bn2_b, grads->conv2_b, b, c, hw, sync, nullptr, nullptr, nullptr);
+    DHD_LAUNCH_CHECK();
+  }
+  if (hi <= 0) return DHD_OK;
+  if (lo <= 1) {
+    hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn2_w, sv + S.mean2, sv + S.rstd2,
+                       w->training, sc + T.tab_g2, grads->bn2_w, grads->bn2_b, grads->conv2_b, b, c, hw, nullptr, sync,
+                       reinterpret_cast<const double*>(sv + S.loc2), w->conv2_b);
+    DHD_LAUNCH_CHECK();
+    // dW2 = dy2 . z1^T
+    rc = launch_pw_wgrad(sc + T.g2, sv + S.y2, sc + T.tab_g2, cs, sv + S.y1, nullptr, sv + S.tab1, cs, true, sc + T.wpart,
+                         grads->conv2_w, b, c, hw, st);
+    if (rc != DHD_OK) return rc;
+    // g1 = (W2^T dy2) * [z1 > 0]
+    rc = launch_pw_gemm(sc + T.g2, sv + S.y2, cs, c, sc + T.tab_g2, false, sc + T.wp2t, nullptr, sv + S.y1, sv + S.scsh1,
+                        reinterpret_cast<unsigned*>(const_cast<float*>(sv + S.mask)), nullptr, sc + T.g1, 1, b,
+                        c, hw, st);
+    if (rc != DHD_OK) return rc;
+    hipLaunchKernelGGL(pair_sums_kernel, planes, dim3(kEwBlock), 0, st, sc + T.g1, sv + S.y1, sv + S.mean1, sc + T.part, c, hw);
+    if (sync)
+      hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn1_w, sv + S.mean1, sv + S.rstd1,
+                         w->training, sc + T.tab_g1, grads->bn1_w, grads->bn1_b, grads->conv1_b, b, c, hw, sync, nullptr, nullptr, nullptr);
+    DHD_LAUNCH_CHECK();
+  }
+  if (hi <= 1) return DHD_OK;
   hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn1_w, sv + S.mean1, sv + S.rstd1,
-                     w->training, sc + T.tab_g1, grads->bn1_w, grads->bn1_b, grads->conv1_b, b, c, hw);
+                     w->training, sc + T.tab_g1, grads->bn1_w, grads->bn1_b, grads->conv1_b, b, c, hw, nullptr, sync,
+                     reinterpret_cast<const double*>(sv + S.loc1), w->conv1_b);
   DHD_LAUNCH_CHECK();
   // dW1 = dy1 . u^T
   rc = launch_pw_wgrad(sc + T.g1, sv + S.y1, sc + T.tab_g1, cs, x, x + cs, sv + S.tab_a, 2 * cs, false, sc + T.wpart, grads->conv1_w,
@@ -2493,6 +2463,29 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
                      c, hw);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
+}
+
+int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, void* saved, void* scratch, int b, int c, int hw,
+                          void* stream) {
+  return stage_forward_impl(x, w, out, saved, scratch, b, c, hw, 0, 2, nullptr, stream);
+}
+
+int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void* saved, const float* gout, float* gx,
+                           const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw, void* stream) {
+  return stage_backward_impl(x, w, saved, gout, gx, grads, scratch, b, c, hw, 0, 2, nullptr, stream);
+}
+
+int dhd_sfa_stage_forward_phase(const float* x, const dhd_sfa_weights* w, float* out, void* saved, void* scratch, int b, int c, int hw,
+                                int phase, double* sync_sums, void* stream) {
+  if (phase < 0 || phase > 2 || !sync_sums || (reinterpret_cast<uintptr_t>(sync_sums) & 7)) return DHD_EINVAL;
+  return stage_forward_impl(x, w, out, saved, scratch, b, c, hw, phase, phase, sync_sums, stream);
+}
+
+int dhd_sfa_stage_backward_phase(const float* x, const dhd_sfa_weights* w, const void* saved, const float* gout, float* gx,
+                                 const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw, int phase, double* sync_sums,
+                                 void* stream) {
+  if (phase < 0 || phase > 2 || !sync_sums || (reinterpret_cast<uintptr_t>(sync_sums) & 7)) return DHD_EINVAL;
+  return stage_backward_impl(x, w, saved, gout, gx, grads, scratch, b, c, hw, phase, phase, sync_sums, stream);
 }
 
 }  // extern "C"

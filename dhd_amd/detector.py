@@ -64,6 +64,8 @@ class ResNet(nn.Module):
         super().__init__()
         blocks = self.arch[depth][:num_stages]
         self.out_indices, self.with_cp, self.norm_eval = tuple(out_indices), with_cp, norm_eval
+        if not -1 <= frozen_stages <= num_stages:
+            raise ValueError(f'ResNet: frozen_stages={frozen_stages} outside [-1, num_stages={num_stages}]')
         self.frozen_stages = frozen_stages
         if pretrained:
             # mmdet loads e.g. 'torchvision://resnet50' here; neither torchvision nor a network exists in this
@@ -86,6 +88,7 @@ class ResNet(nn.Module):
             name = f'layer{i + 1}'
             setattr(self, name, nn.Sequential(*layer))
             self.res_layers.append(name)
+        self._freeze_stages()   # as mmdet's ResNet.__init__: frozen parameters never reach an optimizer built before .train()
 
     def forward(self, x):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
@@ -637,7 +640,8 @@ class DHD_stereo(DHD):
         l02l1 = c02l0.matmul(small_inverse(c12l0))[:, 0].view(B, 1, 1, 4, 4)
         l02l1 = l02l1[:, :, :, [True, True, False, True], :][:, :, :, :, [True, True, False, True]]
         vt = self.img_view_transformer
-        key = (str(grid.device), grid.dtype, W, H, tuple(vt.grid_interval.tolist()), tuple(vt.grid_lower_bound.tolist()))
+        key = (str(grid.device), grid.dtype, str(inp.device), inp.dtype, W, H, tuple(vt.grid_interval.tolist()),
+               tuple(vt.grid_lower_bound.tolist()))   # `norm` below is built with inp's dtype / device
         if getattr(self, '_f2b_key', None) != key:   # constants of the module: built (host -> device) once, not per step
             feat2bev = torch.zeros((3, 3), dtype=grid.dtype)
             feat2bev[0, 0], feat2bev[1, 1] = vt.grid_interval[0], vt.grid_interval[1]

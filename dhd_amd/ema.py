@@ -74,6 +74,20 @@ class ModelEMA:
         for p in self.ema.parameters():
             p.requires_grad_(False)
         self._key, self._cpu, self._tables = None, [], {}
+        self._decay_dev = {}     # device -> float32[2] {d, 1 - d}: read by launches captured into a HIP graph
+        self.captured = False    # an update has been captured: advance() must run before every replay (GraphedStep does)
+
+    def _set_decay_dev(self, d):
+        pair = torch.tensor([d, 1.0 - d], dtype=torch.float32)   # 1 - d in double, both rounded to float32 (ema.py:58-59)
+        for dev, t in self._decay_dev.items():
+            t.copy_(pair, non_blocking=True)
+
+    def advance(self):
+        """Host side of ONE update whose kernel launch was captured into a HIP graph: the update count moves on and the decay of
+        this update is placed where the captured launch reads it.  Call before every replay (dhd_amd.graph.GraphedStep does it
+        for the ModelEMA objects it is given); without it a replay would repeat the decay and the count of the capture."""
+        self.updates += 1
+        self._set_decay_dev(self.decay(self.updates))
 
     def _plan(self, ours, theirs):
         """Sort the state into CPU pairs and per-device chunk tables (redone only when a tensor moved)."""
@@ -102,8 +116,15 @@ class ModelEMA:
 
     def update(self, trainer, model):
         with torch.no_grad():
-            self.updates += 1
-            d = self.decay(self.updates)
+            capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+            if capturing:
+                # recorded, not executed: the count and the decay belong to the replays (advance()); kernel arguments would
+                # be frozen at their capture-time values, so the launch reads {d, 1 - d} from device memory
+                self.captured = True
+                d = self.decay(self.updates + 1)
+            else:
+                self.updates += 1
+                d = self.decay(self.updates)
             ours, theirs = _state_tensors(self.ema), _state_tensors(model.module if is_parallel(model) else model)
             if len(ours) != len(theirs):
                 raise KeyError('ModelEMA: the model state no longer matches the EMA copy')
@@ -119,9 +140,17 @@ class ModelEMA:
                     if self.events is not None:
                         marks = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                         marks[0].record()
-                    # Python computes 1 - d in double and torch rounds both scalars to float32 (ema.py:58-59)
-                    _lib.check(_lib.load().dhd_ema_update(_lib.ptr(tab.ema_addr), _lib.ptr(tab.model_addr), _lib.ptr(tab.len), tab.n,
-                                                          float(d), float(1.0 - d), _lib.stream_ptr(dev)), 'dhd_ema_update')
+                    if capturing:
+                        if dev not in self._decay_dev:
+                            raise _lib.DhdError('ModelEMA: run one eager update (a warm-up step) before capturing it into a graph')
+                        _lib.check(_lib.load().dhd_ema_update_dev(_lib.ptr(tab.ema_addr), _lib.ptr(tab.model_addr), _lib.ptr(tab.len), tab.n,
+                                                                  _lib.ptr(self._decay_dev[dev]), _lib.stream_ptr(dev)), 'dhd_ema_update_dev')
+                    else:
+                        if dev not in self._decay_dev:   # allocated outside any capture
+                            self._decay_dev[dev] = torch.zeros(2, dtype=torch.float32, device=dev)
+                        # Python computes 1 - d in double and torch rounds both scalars to float32 (ema.py:58-59)
+                        _lib.check(_lib.load().dhd_ema_update(_lib.ptr(tab.ema_addr), _lib.ptr(tab.model_addr), _lib.ptr(tab.len), tab.n,
+                                                              float(d), float(1.0 - d), _lib.stream_ptr(dev)), 'dhd_ema_update')
                     if self.events is not None:
                         marks[1].record()
                         self.events.append(marks)

@@ -12,10 +12,19 @@ import torch
 
 class GraphedStep:
     """Capture `step_fn()` (no arguments; it must read its inputs from tensors that stay alive and in place) after
-    `warmup` eager runs on a side stream, then replay it.  `step_fn` returns a tensor (e.g. the loss) or None."""
+    `warmup` eager runs on a side stream, then replay it.  `step_fn` returns a tensor (e.g. the loss) or None.
 
-    def __init__(self, step_fn, warmup=3):
+    Host-side scalars are frozen at capture: a kernel argument computed in Python (a float learning rate set by a
+    scheduler, a decay factor) keeps its capture-time value in every replay, and host counters do not advance.  What must
+    change per step has to live in device memory and be refreshed before the replay: `before_replay` callables run before
+    every `graph.replay()`.  `emas`: ModelEMA objects whose update is part of the step -- their ramping decay and update
+    count (ema.py:29,55; the count is written into the EMA checkpoints) are advanced per replay (ModelEMA.advance).  For
+    the optimizer use a capturable one with a tensor learning rate if a schedule has to act inside the graph."""
+
+    def __init__(self, step_fn, warmup=3, before_replay=(), emas=()):
         self.step_fn = step_fn
+        self.before_replay = list(before_replay) + [e.advance for e in emas]
+        self._emas = list(emas)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -26,8 +35,13 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.result = step_fn()
+        for e in self._emas:
+            if not e.captured:
+                raise RuntimeError('GraphedStep: a ModelEMA was passed in `emas` but its update is not part of the captured step')
 
     def __call__(self):
+        for fn in self.before_replay:
+            fn()
         self.graph.replay()
         return self.result
 

@@ -161,16 +161,28 @@ class _FusedStage(torch.autograd.Function):
         wts.momentum1, wts.momentum2 = _bn_momentum(bn1, training), _bn_momentum(bn2, training)
         if training and not bn1.training:
             wts.bn1_mean = wts.bn1_var = wts.bn2_mean = wts.bn2_var = None
+        group = _sync_group(stage)   # None, or the process group whose ranks share BatchNorm statistics (nn.SyncBatchNorm)
         with torch.cuda.device(dev):
             saved = torch.empty(lib.dhd_sfa_stage_saved_bytes(b, c, hw, hidden), dtype=torch.uint8, device=dev)
             scratch = _stage_scratch(dev, lib.dhd_sfa_stage_scratch_bytes(b, c, hw, hidden))
             out = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
-            _lib.check(lib.dhd_sfa_stage_forward(_lib.ptr(x), C.byref(wts), _lib.ptr(out), _lib.ptr(saved), _lib.ptr(scratch),
-                                                 b, c, hw, _lib.stream_ptr(dev)), 'dhd_sfa_stage_forward')
+            if group is None:
+                _lib.check(lib.dhd_sfa_stage_forward(_lib.ptr(x), C.byref(wts), _lib.ptr(out), _lib.ptr(saved), _lib.ptr(scratch),
+                                                     b, c, hw, _lib.stream_ptr(dev)), 'dhd_sfa_stage_forward')
+            else:
+                # the operator cut at its two statistics points; (2C + 1) float64 sums are all-reduced in between
+                sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+                for phase in range(3):
+                    _lib.check(lib.dhd_sfa_stage_forward_phase(_lib.ptr(x), C.byref(wts), _lib.ptr(out), _lib.ptr(saved), _lib.ptr(scratch),
+                                                               b, c, hw, phase, _lib.ptr(sums), _lib.stream_ptr(dev)),
+                               'dhd_sfa_stage_forward_phase')
+                    if phase < 2:
+                        _all_reduce_sum(sums, group)
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, saved, *ps)
             ctx.wts = wts
             ctx.dims = (b, c, hw)
+            ctx.group = group
         return out
 
     @staticmethod
@@ -188,22 +200,52 @@ class _FusedStage(torch.autograd.Function):
             for n, g in zip(_STAGE_PARAMS, gps):
                 setattr(grads, n, g.data_ptr())
             scratch = _stage_scratch(dev, lib.dhd_sfa_stage_scratch_bytes(b, c, hw, ctx.wts.hidden))
-            _lib.check(lib.dhd_sfa_stage_backward(_lib.ptr(x), C.byref(ctx.wts), _lib.ptr(saved), _lib.ptr(go), _lib.ptr(gx),
-                                                  C.byref(grads), _lib.ptr(scratch), b, c, hw, _lib.stream_ptr(dev)),
-                       'dhd_sfa_stage_backward')
+            if ctx.group is None:
+                _lib.check(lib.dhd_sfa_stage_backward(_lib.ptr(x), C.byref(ctx.wts), _lib.ptr(saved), _lib.ptr(go), _lib.ptr(gx),
+                                                      C.byref(grads), _lib.ptr(scratch), b, c, hw, _lib.stream_ptr(dev)),
+                           'dhd_sfa_stage_backward')
+            else:
+                sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+                for phase in range(3):
+                    _lib.check(lib.dhd_sfa_stage_backward_phase(_lib.ptr(x), C.byref(ctx.wts), _lib.ptr(saved), _lib.ptr(go), _lib.ptr(gx),
+                                                                C.byref(grads), _lib.ptr(scratch), b, c, hw, phase, _lib.ptr(sums),
+                                                                _lib.stream_ptr(dev)), 'dhd_sfa_stage_backward_phase')
+                    if phase < 2:
+                        _all_reduce_sum(sums, ctx.group)
         need = ctx.needs_input_grad
         return (gx if need[0] else None, None) + tuple(g if n else None for g, n in zip(gps, need[2:]))
 
 
 def needs_cross_rank_statistics(stage):
-    """True when a BatchNorm of the stage was converted to nn.SyncBatchNorm (SyncbnControlHook, DHD-L.py) and is
-    training in a process group of more than one rank: its statistics must be all-reduced, which the stage operator
-    (this rank's batch only) does not do -- the generic path, which calls the real modules, runs instead."""
+    """True when a BatchNorm of the stage was converted to nn.SyncBatchNorm (SyncbnControlHook, DHD-L.py:308-311) and is
+    training in a process group of more than one rank: its statistics are sums over all ranks' batches."""
+    return _sync_group(stage) is not None
+
+
+_WORLD = object()   # marker: the default process group
+
+
+def _sync_group(stage):
+    """The process group over which the stage's BatchNorm statistics are shared, or None (plain BatchNorm, eval mode, or a
+    world of one rank).  nn.SyncBatchNorm.process_group is None for the default group."""
     sp = stage.spacial_leanring
-    if not any(isinstance(bn, nn.SyncBatchNorm) and bn.training for bn in (sp[1], sp[4])):
-        return False
+    bns = [bn for bn in (sp[1], sp[4]) if isinstance(bn, nn.SyncBatchNorm) and bn.training]
+    if not bns:
+        return None
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if len(bns) != 2 or bns[0].process_group is not bns[1].process_group:
+        raise _lib.DhdError('SFA: the two BatchNorm layers of the stage must both be SyncBatchNorm over the same process group')
+    pg = bns[0].process_group
+    if dist.get_world_size(pg) <= 1:
+        return None
+    return _WORLD if pg is None else pg
+
+
+def _all_reduce_sum(t, group):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=None if group is _WORLD else group)
 
 
 def fused_stage_supported(stage, x):
@@ -216,8 +258,8 @@ def fused_stage_supported(stage, x):
     sp = stage.spacial_leanring
     if sp[0].weight.shape != (stage.channels, stage.channels, 1, 1) or sp[1].weight is None or sp[4].weight is None:
         return False
-    if needs_cross_rank_statistics(stage):
-        return False
+    if needs_cross_rank_statistics(stage) and (stage.gemm or default_gemm()) == 'f32':
+        return False     # the phased operator (cross-rank statistics) exists for the bf16 GEMM precisions
     return bool(_lib.load().dhd_sfa_stage_supported(stage.channels, x.shape[2] * x.shape[3]))
 
 

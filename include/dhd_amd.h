@@ -63,6 +63,18 @@ int dhd_bev_pool_v2_backward(const float* out_grad, float* depth_grad, float* fe
                              const int32_t* interval_lengths_bp, const int32_t* interval_starts_bp,
                              int c, int n_intervals_bp, void* stream);
 
+/* The re-grouping QuickCumsumCuda.backward performs on every call (bev_pool.py:47-57: argsort by ranks_feat, three
+ * gathers, run-length scan) as a device counting sort without host synchronisation: the point lists ordered by feature
+ * pixel (inside a pixel by ascending ranks_depth: deterministic) and ONE interval per pixel, empty pixels included with
+ * length 0 -- pass n_intervals_bp = n_pixels to dhd_bev_pool_v2_backward, which skips empty intervals.  n_pixels =
+ * B*N*fH*fW (rows of feat); points whose ranks_feat is outside [0, n_pixels) are dropped.  The *_bp lists have n_points
+ * entries (only the first sum(lengths) are written), interval_*_bp n_pixels.  scratch: dhd_bev_pool_v2_regroup_scratch_bytes. */
+size_t dhd_bev_pool_v2_regroup_scratch_bytes(int n_points, int n_pixels);
+int dhd_bev_pool_v2_regroup(const int32_t* ranks_depth, const int32_t* ranks_feat, const int32_t* ranks_bev,
+                            int n_points, int n_pixels, int32_t* ranks_depth_bp, int32_t* ranks_feat_bp,
+                            int32_t* ranks_bev_bp, int32_t* interval_starts_bp, int32_t* interval_lengths_bp,
+                            void* scratch /*[dev]*/, size_t scratch_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------ *
  * 2. Fused MGHS view transform (replaces the 4x get_ego_coor + 4x voxel_pooling_prepare_v2
  *    + 4x bev_pool_v2 + permute + cat chain of models/necks/lss_heightmap.py:380-459).
@@ -341,6 +353,27 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
                            const float* gout, float* gx, const dhd_sfa_grads* grads, void* scratch,
                            int b, int c, int hw, void* stream);
 
+/* The same operator under nn.SyncBatchNorm (core/hook/syncbncontrol.py:18-32 converts the stage's two BatchNorms when
+ * DHD-L.py:308-311 turns SyncbnControlHook on): forward and backward are cut at the points where BatchNorm needs sums over
+ * the whole (cross-rank) batch.  Call phase 0, 1, 2 in order; between two phases all-reduce (SUM) the (2C + 1) float64 values
+ * of sync_sums over the ranks -- a phase that ends at a statistics point writes this rank's [sum][C] | [second sum][C] |
+ * count there, the next phase reads the reduced vector from the same place:
+ *   forward  0: channel mean, fc, conv1            -> sums of (y1 - bias), (y1 - bias)^2
+ *            1: BatchNorm-1 statistics, ReLU, conv2 -> sums of (y2 - bias), (y2 - bias)^2
+ *            2: BatchNorm-2 statistics, sigmoid, blend -> out          (`out` may be NULL in phases 0 and 1)
+ *   backward 0: blend backward                     -> sums of g2, g2 (y2 - mean2)
+ *            1: BatchNorm-2 backward, dW2, dgrad 2  -> sums of g1, g1 (y1 - mean1)
+ *            2: BatchNorm-1 backward, dW1, dgrad 1, fc backward -> gx  (`gx` may be NULL in phases 0 and 1)
+ * Running statistics are updated from the global sums (identical on every rank); dgamma / dbeta / the convolution-bias
+ * gradients are this rank's contributions (the caller's DDP averages parameter gradients), exactly as torch's
+ * SyncBatchNorm.  Training mode and the bf16 GEMM precisions only (DHD_EUNSUPPORTED otherwise).  With one rank and no
+ * all-reduce the three phases reproduce dhd_sfa_stage_forward / backward. */
+int dhd_sfa_stage_forward_phase(const float* x, const dhd_sfa_weights* w, float* out, void* saved, void* scratch,
+                                int b, int c, int hw, int phase, double* sync_sums /*[dev] 2C+1*/, void* stream);
+int dhd_sfa_stage_backward_phase(const float* x, const dhd_sfa_weights* w, const void* saved, const float* gout,
+                                 float* gx, const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw,
+                                 int phase, double* sync_sums /*[dev] 2C+1*/, void* stream);
+
 /* ------------------------------------------------------------------------------------ *
  * 5. Occupancy-head losses (models/dense_heads/occ_head.py:102-139, predictor.loss): the
  *    class-balanced camera-masked cross entropy (models/losses/cross_entropy_loss.py:12-63,
@@ -443,6 +476,11 @@ int dhd_stereo_cost_volume(const float* prev_nhwc, const float* curr_nhwc, const
  * ------------------------------------------------------------------------------------ */
 int dhd_ema_update(const uint64_t* ema_addr, const uint64_t* model_addr, const int* len, int n_chunks,
                    float decay, float one_minus_decay, void* stream);
+/* The same with the two factors in device memory, decay_pair = {decay, one_minus_decay}: for a launch that is captured into a
+ * HIP graph (kernel arguments are frozen at capture; the reference's decay ramps with the update count, ema.py:29,55), the
+ * host refreshes the pair before every replay. */
+int dhd_ema_update_dev(const uint64_t* ema_addr, const uint64_t* model_addr, const int* len, int n_chunks,
+                       const float* decay_pair /*[dev] float[2]*/, void* stream);
 
 /* ------------------------------------------------------------------------------------ *
  * 9. Training-mode BatchNorm2d of the dense callers (torch.nn.BatchNorm2d semantics: biased batch

@@ -16,7 +16,7 @@ if [[ " $WHAT " == *" hotpath "* ]]; then
 B="python $R/bench.py --steps 20 --warmup 3 --cpu-samples 0 --no-e2e"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hp -o hp -- $B 2>/dev/null | grep '^{' > $OUT/bench_hotpath_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mo -o mo -- $B --no-sfa 2>/dev/null | grep '^{' > $OUT/bench_mghs_only_under_rocprof.json
-P="python $R/bench.py --steps 5 --warmup 2 --cpu-samples 0 --no-e2e --no-operator"
+P="python $R/bench.py --steps 5 --warmup 2 --cpu-samples 0 --no-e2e"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o pf -- $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pw -o pw -- $P > /dev/null 2>&1
 cp $(find $OUT/hp -name 'hp_kernel_stats.csv') $OUT/hotpath_kernel_stats.csv
@@ -38,7 +38,7 @@ head -1 $(find $OUT/ef -name 'ef_counter_collection.csv') > $OUT/pmc_ema.csv
 grep -h ema_update_kernel $(find $OUT/ef -name 'ef_counter_collection.csv') $(find $OUT/ew -name 'ew_counter_collection.csv') >> $OUT/pmc_ema.csv
 rm -rf $OUT/es $OUT/ef $OUT/ew
 fi
-PREV=${PREV_PROFILES:-$R/profiles/r2}
+PREV=${PREV_PROFILES:-$R/profiles/r3}
 [ -f $OUT/pmc_fetch_size.csv ] || cp $PREV/pmc_fetch_size.csv $PREV/pmc_write_size.csv $OUT/
 [ -f $OUT/pmc_ema.csv ] || cp $PREV/pmc_ema.csv $OUT/ 2>/dev/null || head -1 $OUT/pmc_fetch_size.csv > $OUT/pmc_ema.csv
 cd $R
@@ -65,14 +65,14 @@ for k in sorted(set(f) | set(w)):
     if k.startswith('Cijk') or 'at::native' in k or k.startswith('__amd'): continue
     ks[k] = dict(FETCH_SIZE_KB=f.get(k, 0.0), WRITE_SIZE_KB=w.get(k, 0.0), hbm_bytes_per_launch=int((2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024))
 json.dump(dict(samples_per_gpu=4, source_sha256=kernel_source_sha256(),
-               command='rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 5 --warmup 2 --cpu-samples 0 --no-e2e --no-operator (two separate passes)',
+               command='rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 5 --warmup 2 --cpu-samples 0 --no-e2e (two separate passes)',
                correction='bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of a wide coalesced read)',
                kernels=ks), open(out + '/pmc_summary.json', 'w'), indent=1)
 print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in ks.items()}, indent=0)[:3000])
 PY
 # the plain bench line last, with the fresh PMC summary in place (bench.py reports `traffic` only for a matching source hash)
 if [[ " $WHAT " == *" hotpath "* ]]; then
-cp $OUT/pmc_summary.json $R/profiles/r2/pmc_summary.json
+mkdir -p $R/profiles/r3 && cp $OUT/pmc_summary.json $R/profiles/r3/pmc_summary.json
 cd $R && python bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err
 fi
 ls -la $OUT

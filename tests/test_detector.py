@@ -273,7 +273,9 @@ def test_whole_step_hip_graph_replays_the_eager_step(gpu):
     calib = [torch.from_numpy(a).to(gpu) for a in syn.make_calibration(5, 1, 2, cfg['input_size'])]
     x = torch.randn(1, 2, 16, 4, 11, device=gpu)
 
-    def make(model):
+    from dhd_amd import ModelEMA
+
+    def make(model, ema):
         # plain SGD: parameter differences stay proportional to gradient differences (library convolutions may pick another
         # algorithm, i.e. another rounding, from one call to the next; Adam's 1/|g| would amplify that)
         opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9)
@@ -285,23 +287,43 @@ def test_whole_step_hip_graph_replays_the_eager_step(gpu):
             loss = model['sfa'](torch.cat([lo, mid], 1)).square().mean() + bev.square().mean() + hi.mean()
             loss.backward()
             opt.step()
+            ema.update(None, model)      # the configs' MEGVIIEMAHook.after_train_iter: part of the step
             return loss.detach()
         return step
     from dhd_amd import mghs_op
     eager_model, graph_model = copy.deepcopy(base), copy.deepcopy(base)
+    # a young EMA: its decay d = 0.999 (1 - exp(-updates / 2000)) changes by whole percents from one update to the next, so a
+    # replay that repeated the decay of the capture (kernel arguments are frozen in a graph) would be far off
+    eager_ema, graph_ema = ModelEMA(eager_model, 0.9990, updates=40), ModelEMA(graph_model, 0.9990, updates=40)
     mghs_op.set_deterministic(True)   # bit-reproducible pooling sums: the two runs see identical gradients
     try:
-        eager = make(eager_model)
-        for _ in range(3 + 3):
+        eager = make(eager_model, eager_ema)
+        for _ in range(3 + 5):
             eager()
-        graphed = GraphedStep(make(graph_model), warmup=3)   # 3 eager warm-up steps on a side stream, then capture (not executed)
-        for _ in range(3):
+        # 3 eager warm-up steps on a side stream, then capture (not executed), then 5 replays
+        graphed = GraphedStep(make(graph_model, graph_ema), warmup=3, emas=[graph_ema])
+        assert graph_ema.updates == 43 and graph_ema.captured
+        for _ in range(4):
             graphed()
+        before = [p.detach().clone() for p in graph_ema.ema.parameters()]
+        graphed()
         torch.cuda.synchronize()
     finally:
         mghs_op.set_deterministic(False)
     for (k, p), q in zip(eager_model.named_parameters(), graph_model.parameters()):
         assert torch.allclose(p, q, atol=1e-4, rtol=1e-3), k
+    # the EMA's update count (it is written into epoch_N_ema.pth, ema.py:106-117) follows the replays, and the fifth replay
+    # applied the decay of update 48 -- bit for bit the reference's two-rounding expression (ema.py:58-59) on the weights
+    # that replay produced -- not the decay of the capture (update 44), which a kernel argument would have frozen
+    assert eager_ema.updates == graph_ema.updates == 48
+    d48, d44 = graph_ema.decay(48), graph_ema.decay(44)
+    assert abs(d48 - d44) > 1e-3
+    n_diff = 0
+    with torch.no_grad():
+        for b4, q, m in zip(before, graph_ema.ema.parameters(), graph_model.parameters()):
+            assert torch.equal(q, b4 * d48 + (1.0 - d48) * m)
+            n_diff += int((q != b4 * d44 + (1.0 - d44) * m).sum())
+    assert n_diff > 1000
 
 
 @pytest.mark.gpu
@@ -441,3 +463,20 @@ def test_config5_four_lifted_frames_full_size_pooled_tensors_vs_oracle(gpu):
                  'mix.mysk_7.spacial_leanring.3.weight', 'occ_head.predicter.0.weight'):
         gr = dict(m.named_parameters())[name].grad
         assert gr is not None and torch.isfinite(gr).all() and gr.abs().sum() > 0, name
+
+
+def test_resnet_frozen_stages_take_effect_at_construction():
+    """mmdet's ResNet calls _freeze_stages() at the end of __init__: a model handed to an optimizer before any .train() call
+    must already have the stem and the frozen stages without gradients and their BatchNorms in eval mode."""
+    from dhd_amd.detector import ResNet
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = ResNet(depth=50, num_stages=4, out_indices=(2, 3), frozen_stages=1)
+    assert not m.conv1.weight.requires_grad and not m.bn1.training
+    assert all(not p.requires_grad for p in m.layer1.parameters()) and not m.layer1[0].bn1.training
+    assert all(p.requires_grad for p in m.layer2.parameters())
+    n_trainable = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert n_trainable == sum(p.numel() for p in m.parameters()) - sum(p.numel() for mm in (m.conv1, m.bn1, m.layer1) for p in mm.parameters())
+    with pytest.raises(ValueError):
+        ResNet(depth=50, num_stages=4, frozen_stages=5)

@@ -67,8 +67,8 @@ def _worker(rank, world, port, q):
     d = 0.9990 * (1 - __import__('math').exp(-10561 / 2000))
     moved = float((ema_w - net.depth_conv[-1].weight).abs().max())
     want = float((d * (net.depth_conv[-1].weight + 0.1 * grad) + (1 - d) * net.depth_conv[-1].weight - ema_w).abs().max())
-    # SyncbnControlHook converts every BatchNorm, the SFA stage's two included: with more than one rank the stage
-    # operator (local statistics) must step aside for the generic path
+    # SyncbnControlHook converts every BatchNorm, the SFA stage's two included: with more than one rank the stage's
+    # statistics are cross-rank sums (the stage operator then runs in its phased form, tests/test_gpu_parity.py)
     from dhd_amd.mix import channel_spatial_stage, needs_cross_rank_statistics
     st = channel_spatial_stage(256)
     assert not needs_cross_rank_statistics(st)

@@ -87,6 +87,44 @@ def test_bev_pool_v2_operator_vs_oracle(gpu, channels):
     np.testing.assert_allclose(ft.grad.cpu().numpy(), fg, atol=1e-5, rtol=1e-5)
 
 
+def test_bev_pool_v2_regroup_vs_argsort(gpu):
+    """dhd_bev_pool_v2_regroup (device counting sort by feature pixel, ascending ranks_depth inside a pixel, one interval per
+    pixel incl. empty ones) against the reference's formulation (bev_pool.py:47-57: argsort by ranks_feat, run-length scan) on
+    ragged lists: many empty pixels, one pixel holding most points, out-of-range pixel ids (dropped), and the empty list."""
+    import ctypes as C
+    from dhd_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    for n_points, n_pixels in ((5000, 700), (3, 64), (0, 10), (40000, 9000)):
+        rf = torch.randint(0, n_pixels, (n_points,), generator=g)
+        if n_points > 100:
+            rf[::3] = 17                     # a heavy pixel
+            rf[5] = n_pixels + 4             # out of range: dropped
+            rf[6] = -2
+        rd = torch.randperm(max(n_points, 1), generator=g)[:n_points]
+        rb = torch.randint(0, 1000, (n_points,), generator=g)
+        d = lambda t: t.int().to(gpu).contiguous()
+        rfd, rdd, rbd = d(rf), d(rd), d(rb)
+        out = [torch.full((max(n_points, 1),), -7, dtype=torch.int32, device=gpu) for _ in range(3)]
+        starts = torch.empty(n_pixels, dtype=torch.int32, device=gpu)
+        lengths = torch.empty(n_pixels, dtype=torch.int32, device=gpu)
+        nb = int(lib.dhd_bev_pool_v2_regroup_scratch_bytes(n_points, n_pixels))
+        scratch = torch.empty(nb, dtype=torch.uint8, device=gpu)
+        assert lib.dhd_bev_pool_v2_regroup(_lib.ptr(rdd), _lib.ptr(rfd), _lib.ptr(rbd), n_points, n_pixels, _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                           _lib.ptr(out[2]), _lib.ptr(starts), _lib.ptr(lengths), _lib.ptr(scratch), nb - 1, None) == -2
+        _lib.check(lib.dhd_bev_pool_v2_regroup(_lib.ptr(rdd), _lib.ptr(rfd), _lib.ptr(rbd), n_points, n_pixels, _lib.ptr(out[0]),
+                                               _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(starts), _lib.ptr(lengths), _lib.ptr(scratch), nb,
+                                               _lib.stream_ptr(gpu)), 'regroup')
+        keep = (rf >= 0) & (rf < n_pixels)
+        rf_k, rd_k, rb_k = rf[keep], rd[keep], rb[keep]
+        order = torch.argsort(rf_k * (max(n_points, 1) + 1) + rd_k)          # by pixel, then by ranks_depth
+        n_kept = int(keep.sum())
+        assert torch.equal(out[1][:n_kept].cpu().long(), rf_k[order]) and torch.equal(out[0][:n_kept].cpu().long(), rd_k[order])
+        assert torch.equal(out[2][:n_kept].cpu().long(), rb_k[order])
+        cnt = torch.bincount(rf_k, minlength=n_pixels)
+        assert torch.equal(lengths.cpu().long(), cnt) and torch.equal(starts.cpu().long(), torch.cumsum(cnt, 0) - cnt)
+
+
 def test_bev_pool_v2_empty_and_cpu_tensor_errors(gpu):
     from dhd_amd import bev_pool_v2, _lib
     z = torch.zeros(0, dtype=torch.int32, device=gpu)
@@ -1176,3 +1214,110 @@ def test_batchnorm2d_training_vs_torch(gpu, dtype, tol, shape):
     with torch.no_grad():     # eval mode is the parent's path
         x = torch.randn(shape, device=gpu).to(dtype)
         assert torch.equal(ours(x), torch.nn.functional.batch_norm(x, ours.running_mean, ours.running_var, ours.weight, ours.bias, False, 0.0, ours.eps))
+
+
+# ---------------------------------------------------------------------------------------------
+# SFA stage under nn.SyncBatchNorm (DHD-L.py:308-311 SyncbnControlHook): the phased operator, two ranks sharing cuda:0 over gloo
+# ---------------------------------------------------------------------------------------------
+
+def _syncbn_stage_worker(rank, world, port, q, gemm):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from dhd_amd.mix import channel_spatial_stage, fused_stage_supported, needs_cross_rank_statistics
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    c, h, w, per = 128, 20, 28, 2
+    torch.manual_seed(5)
+    st = channel_spatial_stage(2 * c)
+    with torch.no_grad():
+        for bn in (st.spacial_leanring[1], st.spacial_leanring[4]):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    st = torch.nn.SyncBatchNorm.convert_sync_batchnorm(st).to(dev).train()
+    st.gemm = gemm
+    g = torch.Generator().manual_seed(77)
+    x_all = torch.randn(world * per, 2 * c, h, w, generator=g) * 0.7 + 0.1
+    w_all = torch.randn(world * per, c, h, w, generator=g)
+    x = x_all[rank * per:(rank + 1) * per].to(dev).requires_grad_()
+    assert needs_cross_rank_statistics(st) and fused_stage_supported(st, x)
+    out = st(x)                                    # dhd_sfa_stage_forward_phase x 3, two all-reduces of 2C + 1 doubles
+    (out * w_all[rank * per:(rank + 1) * per].to(dev)).sum().backward()
+    # plain numpy data: tensors would travel as file descriptors of this process, which is gone by the time the parent reads
+    res = dict(out=out.detach().cpu().numpy(), gx=x.grad.cpu().numpy(), grads={k: p.grad.cpu().numpy() for k, p in st.named_parameters()},
+               buffers={k: v.cpu().numpy() for k, v in st.named_buffers()})
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('gemm', ['bf16x6', 'bf16x3'])
+def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm):
+    """core/hook/syncbncontrol.py:18-32 converts every BatchNorm at epoch 0 of DHD-L.py (:308-311), the stage's two included.
+    The fused operator then runs cut at its statistics points (dhd_sfa_stage_forward_phase / backward_phase) with the
+    (2C + 1) float64 sums all-reduced in between.  Two ranks (sharing the GPU over gloo) with two samples each must
+    reproduce plain PyTorch with ordinary BatchNorm on the four samples in one process -- which is what SyncBatchNorm
+    means: outputs and input gradients per rank, parameter gradients as the sum of the ranks' contributions (the loss is a
+    sum over samples), running statistics identical on both ranks and equal to the full-batch ones."""
+    import socket
+    import torch.multiprocessing as mp
+    from dhd_amd.mix import channel_spatial_stage
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_stage_worker, args=(r, world, port, q, gemm)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # the reference: ordinary modules, the whole batch, float64
+    c, h, w, per = 128, 20, 28, 2
+    torch.manual_seed(5)
+    ref = channel_spatial_stage(2 * c)
+    with torch.no_grad():
+        for bn in (ref.spacial_leanring[1], ref.spacial_leanring[4]):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    sp = ref.spacial_leanring
+    plain = torch.nn.Sequential(sp[0], torch.nn.BatchNorm2d(c), torch.nn.ReLU(), sp[3], torch.nn.BatchNorm2d(c))
+    for i in (1, 4):
+        plain[i].load_state_dict(sp[i].state_dict())
+    ref.spacial_leanring = plain
+    ref = ref.double().train()
+    g = torch.Generator().manual_seed(77)
+    x_all = (torch.randn(world * per, 2 * c, h, w, generator=g) * 0.7 + 0.1).double().requires_grad_()
+    w_all = torch.randn(world * per, c, h, w, generator=g).double()
+    a = ref.fc(x_all.mean(dim=(2, 3)))[..., None, None]
+    xb, xv = x_all[:, :c], x_all[:, c:]
+    gate = torch.sigmoid(ref.spacial_leanring(a * xb + (1 - a) * xv))
+    out = gate * (a * xb) + (1 - gate) * ((1 - a) * xv)
+    (out * w_all).sum().backward()
+    f = GEMM_MODES[gemm]
+    for r in range(world):
+        sl = slice(r * per, (r + 1) * per)
+        np.testing.assert_allclose(res[r]['out'], out[sl].detach().numpy(), atol=2e-5 * min(f, 5.0), rtol=1e-4)
+        gref = x_all.grad[sl].numpy()
+        np.testing.assert_allclose(res[r]['gx'], gref, atol=1e-4 * f * np.abs(gref).max(), rtol=1e-3)
+    names = {k: k for k, _ in ref.named_parameters()}
+    for k, p in ref.named_parameters():
+        got = sum(res[r]['grads'][k].astype(np.float64) for r in range(world))
+        want = p.grad.numpy()
+        np.testing.assert_allclose(got, want, atol=3e-4 * f * max(1.0, np.abs(want).max()), rtol=1e-3, err_msg=k)
+    for k, v in ref.named_buffers():
+        if 'running' in k:
+            for r in range(world):
+                np.testing.assert_allclose(res[r]['buffers'][k], v.numpy(), atol=1e-5, rtol=1e-5, err_msg=k)
+            assert np.array_equal(res[0]['buffers'][k], res[1]['buffers'][k])
+    # the convolution-bias gradients vanish only as a SUM over ranks: each rank's own contribution is non-zero
+    assert np.abs(res[0]['grads']['spacial_leanring.0.bias']).max() > 1e-4
