@@ -127,6 +127,12 @@ def parse():
                    help="hotpath: precision of the SFA stage's C x C GEMMs in the main timed loop (default: the library default, bf16x3; "
                         "the bf16x6 step time is reported beside it either way)")
     p.add_argument('--bucket-mb', type=int, default=64, help='e2e under DDP: gradient bucket size (MB)')
+    p.add_argument('--no-ddp-static-graph', dest='ddp_static_graph', action='store_false',
+                   help='e2e under DDP: DistributedDataParallel(static_graph=False) (default: static_graph=True -- the step has the same '
+                        'autograd graph every iteration; exercised with two ranks over gloo incl. the no_sync() comparison)')
+    p.add_argument('--ddp-graph', action='store_true',
+                   help='e2e under DDP: capture the whole step, RCCL all-reduces included, into a HIP graph (N = 1 always does; with N > 1 '
+                        'it is opt-in because it cannot be validated on the one-GPU development box: falls back to eager on a capture error)')
     return p.parse_args()
 
 
@@ -223,7 +229,8 @@ class EndToEnd:
     """DHD-S exactly as projects/configs/DHD/DHD-S.py:42-155 (random init, synthetic 6-camera batch,
     SURVEY.md 8d config 2): forward_train -> sum of the four losses -> backward -> grad clip 5 -> AdamW."""
 
-    def __init__(self, dev, batch, seed, world, amp, model='dhd-s', ema=True, graph=False, bucket_mb=64):
+    def __init__(self, dev, batch, seed, world, amp, model='dhd-s', ema=True, graph=False, bucket_mb=64, static_graph=False,
+                 ddp_graph=False):
         import dhd_amd
         from dhd_amd.detector import dhd_l_model_cfg, dhd_m_model_cfg, dhd_s_model_cfg
         torch.manual_seed(seed)
@@ -241,7 +248,7 @@ class EndToEnd:
         self.net = self.model
         if world > 1:
             self.net = torch.nn.parallel.DistributedDataParallel(self.model, device_ids=[dev.index], bucket_cap_mb=bucket_mb,
-                                                                 gradient_as_bucket_view=True)
+                                                                 gradient_as_bucket_view=True, static_graph=bool(static_graph))
         self.opt = torch.optim.AdamW(self.params, lr=2e-4, weight_decay=1e-2, fused=True, capturable=bool(graph))  # DHD-S.py:262
         # custom_hooks of all three configs (DHD-S.py:272-278): weight EMA after every iteration
         self.ema = dhd_amd.ModelEMA(self.model, 0.9990, updates=10560) if ema else None
@@ -265,7 +272,8 @@ class EndToEnd:
         self.B = batch
         self.graphed = None
         self.graph_error = None
-        self.want_graph = bool(graph) and world == 1
+        # N > 1: the captured step would contain the RCCL all-reduces (capturable in principle); opt-in, see --ddp-graph
+        self.want_graph = bool(graph) and (world == 1 or bool(ddp_graph))
 
     def capture(self):
         """After the eager warm-up: the whole step as one HIP graph (dhd_amd/graph.py); falls back to eager on failure."""
@@ -305,7 +313,8 @@ class EndToEnd:
 
 
 def run_e2e(a, rank, world, dev):
-    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp, a.model, not a.no_ema, graph=not a.no_graph, bucket_mb=a.bucket_mb)
+    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp, a.model, not a.no_ema, graph=not a.no_graph, bucket_mb=a.bucket_mb,
+                   static_graph=a.ddp_static_graph, ddp_graph=a.ddp_graph)
     for _ in range(a.warmup):
         job.step(False)
     job.capture()
@@ -576,12 +585,32 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
         fence()
         return ddist.max_over_ranks(time.perf_counter() - t0, dev) / n
 
+    n_params = None
     for amp in ('off', 'fp16'):
-        job = EndToEnd(dev, a.batch, 1000 + rank, world, amp, 'dhd-s', True, graph=not a.no_graph, bucket_mb=a.bucket_mb)
+        tag = 'fp32' if amp == 'off' else 'fp16'
+        # A rank that fails (out of memory, a bad kernel ...) must not leave the others waiting in a collective, and rank 0
+        # must be able to report a failure it did not see: the construction and the warm-up -- where such errors show -- run
+        # under try, then ALL ranks exchange their error texts and abandon the leg together if any of them failed.
+        job, err = None, None
+        try:
+            job = EndToEnd(dev, a.batch, 1000 + rank, world, amp, 'dhd-s', True, graph=not a.no_graph, bucket_mb=a.bucket_mb,
+                           static_graph=a.ddp_static_graph, ddp_graph=a.ddp_graph)
+            n_params = job.n_params
+        except Exception as exc:  # noqa: BLE001
+            err = f'{type(exc).__name__}: {exc}'[:300]
+        errs = ddist.gather_errors(err)
+        if errs:
+            out[tag] = dict(error=errs)
+            del job
+            torch.cuda.empty_cache()
+            continue
         for _ in range(warmup):
             job.step(False)
         eager = timed(job, 2) if job.want_graph else None
         job.capture()
+        if world > 1 and job.want_graph:   # a capture that failed on one rank only: every rank goes back to eager
+            if ddist.gather_errors(job.graph_error):
+                job.graphed = None
         per_step = timed(job, steps)
         rec = dict(samples_per_s=a.batch * world / per_step, ms_per_step=1e3 * per_step, steps=steps, warmup=warmup,
                    hip_graph=job.graphed is not None)
@@ -590,19 +619,23 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
         if job.graph_error:
             rec['hip_graph_error'] = job.graph_error
         if world > 1:
+            graphed, job.graphed = job.graphed, None     # the no_sync() comparison runs eagerly
             with job.net.no_sync():
                 job.step(False)
                 rec['ms_per_step_no_allreduce'] = 1e3 * timed(job, steps)
-            rec['exposed_allreduce_ms'] = max(0.0, rec['ms_per_step'] - rec['ms_per_step_no_allreduce'])
+            job.graphed = graphed
+            base = rec.get('ms_per_step_eager', rec['ms_per_step']) if graphed is not None else rec['ms_per_step']
+            rec['exposed_allreduce_ms'] = max(0.0, base - rec['ms_per_step_no_allreduce'])
             rec['allreduce_bytes'] = 4 * job.n_params
-        out['fp32' if amp == 'off' else 'fp16'] = rec
-        n_params = job.n_params
+            rec['bucket_mb'] = a.bucket_mb
+            rec['static_graph'] = bool(a.ddp_static_graph)
+        out[tag] = rec
         del job
         torch.cuda.empty_cache()
     out['config'] = dict(workload='DHD-S (configs[1]/[2]) whole detector: ResNet-50 + FPN, MGHS (HIP), BEV encoder, 3 UNets, SFA (HIP stage), '
                                   'predictor + losses (HIP); forward_train + backward + grad-clip + AdamW + weight EMA (HIP); random init',
                          samples_per_gpu=a.batch, global_batch=a.batch * world, params=n_params,
-                         parallelism=f'DDP x{world} ({"RCCL" if a.dist_backend == "nccl" else "gloo, test only"} bucketed all-reduce, 64 MB buckets, '
+                         parallelism=f'DDP x{world} ({"RCCL" if a.dist_backend == "nccl" else "gloo, test only"} bucketed all-reduce, {a.bucket_mb} MB buckets, '
                                      f'overlapped with backward)' if world > 1 else 'single GPU')
     return out
 
@@ -729,7 +762,7 @@ def main():
         # no launcher environment: start one rank per GPU ourselves (the reference's tools/dist_train.sh:11-20 does the same
         # with torch.distributed.launch), then this process becomes the launcher
         have = torch.cuda.device_count()
-        if have < a.gpus:
+        if have < a.gpus and a.dist_backend != 'gloo':   # gloo (test only): ranks may share a GPU
             raise SystemExit(f'--gpus {a.gpus} requested but only {have} GPU(s) are visible')
         import socket
         with socket.socket() as sock:

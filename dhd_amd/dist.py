@@ -65,6 +65,17 @@ def sum_over_ranks(value, device='cpu'):
     return float(t.item())
 
 
+def gather_errors(err):
+    """`err`: this rank's error text or None.  Returns the list of 'rank r: text' over ALL ranks (empty = every rank is fine),
+    identical on every rank: a leg that failed on any rank can be abandoned by all of them together, and rank 0 can report a
+    failure it did not see itself.  To be called at points every rank reaches (not from inside a failed collective)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [] if err is None else [f'rank 0: {err}']
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, err)
+    return [f'rank {r}: {e}' for r, e in enumerate(got) if e is not None]
+
+
 def shutdown():
     if dist.is_initialized():
         dist.barrier()

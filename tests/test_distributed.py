@@ -33,6 +33,9 @@ def _worker(rank, world, port, q):
     D.barrier()
     slow = D.max_over_ranks(1.0 + r)
     total = D.sum_over_ranks(hi - lo)
+    # a failure on one rank is known to every rank (bench.py abandons an end-to-end leg on all ranks together and rank 0
+    # reports errors it did not see itself)
+    assert D.gather_errors('boom' if r == 1 else None) == ['rank 1: boom'] and D.gather_errors(None) == []
     # DDP over the dense producer: each rank sees different samples, gradients come out averaged
     torch.manual_seed(0)
     net = HeightNet(16, 16, 9, use_dcn=False, use_aspp=False)
