@@ -114,6 +114,7 @@ _PROTOTYPES = {
     'dhd_occ_loss_backward': ([_P, _P, _P, _P, C.c_int64, _I, _I, _I, _P, _P, _P, _P], _I),
     'dhd_occ_argmax_hist': ([_P, _P, _P, C.c_int64, _I, _P, _P, _P], _I),
     'dhd_sparse_bin_labels': ([_P, _P, _I, _I, _I, _I, C.c_float, C.c_float, _I, C.c_float, C.c_float, _I, _P, _P, _P], _I),
+    'dhd_sparse_bin_labels_sid': ([_P, _P, _I, _I, _I, _I, C.c_float, C.c_float, _I, C.c_float, C.c_float, _I, _P, _P, _P], _I),
     'dhd_bin_bce_workspace_bytes': ([], C.c_size_t),
     'dhd_bin_bce_forward': ([_P, _P, _P, _I, _I, _I, C.c_float, _P, _P, _P], _I),
     'dhd_bin_bce_backward': ([_P, _P, _P, _I, _I, _I, C.c_float, _P, _P, _P, _P], _I),

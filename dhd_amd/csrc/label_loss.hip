@@ -30,6 +30,17 @@ __device__ __forceinline__ int bin_of(float v, float offset, float step, int n_b
   return (g < (float)(n_bins + 1) && g >= 0.0f) ? (int)g : 0;
 }
 
+// spacing-increasing depth bins (sid=True, lss_heightmap.py:655-660): g = (log(v) - log(d0)) * (D - 1) / log((d1 - 1) / d0) + 1,
+// every operation rounded to float32 in the reference's order; log_d0 and den are the float32 values torch computed on the
+// host, log(v) is the device's float32 logarithm (<= 1 ulp: a value within an ulp of a bin boundary may fall on the other side)
+__device__ __forceinline__ int bin_of_sid(float v, float log_d0, float den, int n_bins) {
+  float g = __fsub_rn(logf(v), log_d0);
+  g = __fdiv_rn(__fmul_rn(g, (float)(n_bins - 1)), den);
+  g = __fadd_rn(g, 1.0f);
+  return (g < (float)(n_bins + 1) && g >= 0.0f) ? (int)g : 0;
+}
+
+template <bool SID>
 __global__ __launch_bounds__(kBlock) void sparse_bin_labels(const float* __restrict__ gt_depth, const float* __restrict__ gt_height,
                                                             int n_pix, int fh, int fw, int ds, float d_off, float d_step, int d_bins,
                                                             float h_off, float h_step, int h_bins, int16_t* __restrict__ dbin,
@@ -50,7 +61,7 @@ __global__ __launch_bounds__(kBlock) void sparse_bin_labels(const float* __restr
   md = wave_min(md);
   mh = wave_min(mh);
   if (lane == 0) {
-    dbin[pix] = (int16_t)bin_of(md, d_off, d_step, d_bins);
+    dbin[pix] = (int16_t)(SID ? bin_of_sid(md, d_off, d_step, d_bins) : bin_of(md, d_off, d_step, d_bins));
     hbin[pix] = (int16_t)bin_of(mh, h_off, h_step, h_bins);
   }
 }
@@ -131,8 +142,23 @@ int dhd_sparse_bin_labels(const float* gt_depth, const float* gt_height, int bn,
     return DHD_EINVAL;
   const long n_pix = (long)bn * fh * fw;
   if (n_pix > (1L << 30)) return DHD_EUNSUPPORTED;
-  hipLaunchKernelGGL(sparse_bin_labels, dim3(dhd_cdiv(n_pix, kBlock / DHD_WAVE)), dim3(kBlock), 0, dhd_stream(stream), gt_depth,
+  hipLaunchKernelGGL(sparse_bin_labels<false>, dim3(dhd_cdiv(n_pix, kBlock / DHD_WAVE)), dim3(kBlock), 0, dhd_stream(stream), gt_depth,
                      gt_height, (int)n_pix, fh, fw, downsample, depth_offset, depth_step, depth_bins, height_offset, height_step,
+                     height_bins, depth_bin, height_bin);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+int dhd_sparse_bin_labels_sid(const float* gt_depth, const float* gt_height, int bn, int fh, int fw, int downsample, float log_d0,
+                              float log_ratio, int depth_bins, float height_offset, float height_step, int height_bins,
+                              int16_t* depth_bin, int16_t* height_bin, void* stream) {
+  if (!gt_depth || !gt_height || !depth_bin || !height_bin || bn <= 0 || fh <= 0 || fw <= 0 || downsample <= 0) return DHD_EINVAL;
+  if (depth_bins <= 1 || height_bins <= 0 || depth_bins > 32000 || height_bins > 32000 || log_ratio == 0.f || height_step == 0.f)
+    return DHD_EINVAL;
+  const long n_pix = (long)bn * fh * fw;
+  if (n_pix > (1L << 30)) return DHD_EUNSUPPORTED;
+  hipLaunchKernelGGL(sparse_bin_labels<true>, dim3(dhd_cdiv(n_pix, kBlock / DHD_WAVE)), dim3(kBlock), 0, dhd_stream(stream), gt_depth,
+                     gt_height, (int)n_pix, fh, fw, downsample, log_d0, log_ratio, depth_bins, height_offset, height_step,
                      height_bins, depth_bin, height_bin);
   DHD_LAUNCH_CHECK();
   return DHD_OK;

@@ -67,12 +67,7 @@ class ResNet(nn.Module):
         if not -1 <= frozen_stages <= num_stages:
             raise ValueError(f'ResNet: frozen_stages={frozen_stages} outside [-1, num_stages={num_stages}]')
         self.frozen_stages = frozen_stages
-        if pretrained:
-            # mmdet loads e.g. 'torchvision://resnet50' here; neither torchvision nor a network exists in this
-            # environment, so say so instead of silently training from random initialisation
-            import warnings
-            warnings.warn(f'ResNet(pretrained={pretrained!r}): checkpoint loading is not implemented, weights stay at their '
-                          'random initialisation; load a state dict explicitly', stacklevel=2)
+        self.pretrained = pretrained
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
@@ -88,6 +83,19 @@ class ResNet(nn.Module):
             name = f'layer{i + 1}'
             setattr(self, name, nn.Sequential(*layer))
             self.res_layers.append(name)
+        if pretrained:
+            # mmdet's ResNet.init_weights loads `pretrained` (DHD-S.py:53: 'torchvision://resnet50').  A local file in
+            # torchvision's key layout (conv1, bn1, layer1..4; its `fc` is ignored) is loaded; schemes that need a network or
+            # torchvision itself cannot be served here: say so instead of silently training from random initialisation
+            import os
+            import warnings
+            if os.path.isfile(str(pretrained)):
+                from .checkpoint import load_checkpoint
+                load_checkpoint(self, pretrained, strict=False, quiet=True)
+            else:
+                warnings.warn(f'ResNet(pretrained={pretrained!r}): checkpoint loading is not implemented for this scheme (no network, no '
+                              'torchvision), weights stay at their random initialisation; pass a local file or load a state dict explicitly',
+                              stacklevel=2)
         self._freeze_stages()   # as mmdet's ResNet.__init__: frozen parameters never reach an optimizer built before .train()
 
     def forward(self, x):

@@ -6,8 +6,9 @@ import torch
 from . import _lib
 
 
-def bin_labels(gt_depth, gt_height, downsample, depth_cfg, n_depth, height_offset, height_step, n_height):
-    """(B,N,H,W) sparse maps -> (depth_bin, height_bin), each (B*N*fH*fW) int16; 0 = no label."""
+def bin_labels(gt_depth, gt_height, downsample, depth_cfg, n_depth, height_offset, height_step, n_height, sid=False):
+    """(B,N,H,W) sparse maps -> (depth_bin, height_bin), each (B*N*fH*fW) int16; 0 = no label.  sid: spacing-increasing
+    depth bins (lss_heightmap.py:655-660)."""
     gt_depth = _lib.require_gpu_tensor(gt_depth.contiguous(), torch.float32, 'gt_depth')
     gt_height = _lib.require_gpu_tensor(gt_height.contiguous(), torch.float32, 'gt_height')
     b, n, h, w = gt_depth.shape
@@ -18,6 +19,15 @@ def bin_labels(gt_depth, gt_height, downsample, depth_cfg, n_depth, height_offse
     with torch.cuda.device(dev):
         dbin = torch.empty(b * n * fh * fw, dtype=torch.int16, device=dev)
         hbin = torch.empty_like(dbin)
+        if sid:
+            # the two scalars exactly as the reference forms them: float32 tensors through torch.log (:656-658)
+            log_d0 = float(torch.log(torch.tensor(depth_cfg[0]).float()))
+            log_ratio = float(torch.log(torch.tensor(depth_cfg[1] - 1.).float() / depth_cfg[0]))
+            _lib.check(_lib.load().dhd_sparse_bin_labels_sid(_lib.ptr(gt_depth), _lib.ptr(gt_height), b * n, fh, fw, downsample,
+                                                             log_d0, log_ratio, n_depth, float(height_offset), float(height_step),
+                                                             n_height, _lib.ptr(dbin), _lib.ptr(hbin), _lib.stream_ptr(dev)),
+                       'dhd_sparse_bin_labels_sid')
+            return dbin, hbin
         # the reference subtracts the Python double (d0 - dstep) from a float32 tensor: the scalar is rounded to float32
         _lib.check(_lib.load().dhd_sparse_bin_labels(_lib.ptr(gt_depth), _lib.ptr(gt_height), b * n, fh, fw, downsample,
                                                      float(depth_cfg[0] - depth_cfg[2]), float(depth_cfg[2]), n_depth,

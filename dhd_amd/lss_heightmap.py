@@ -308,12 +308,12 @@ class MGHS(nn.Module):
     def _hip_labels(self, gt_depth, gt_height):
         from . import label_loss
         return label_loss.bin_labels(gt_depth.float(), gt_height.float(), self.downsample, self.grid_config['depth'], self.D,
-                                     self.height_range[0], self.height_interval, self.H)
+                                     self.height_range[0], self.height_interval, self.H, sid=self.sid)
 
     def get_height_loss(self, gt_depth, gt_height, height):
-        """BCE over foreground pixels (those with a depth label), reference :595-622.  On the GPU (non-SID
-        binning) labels are bin indices and the loss is one HIP operator (csrc/label_loss.hip)."""
-        if height.is_cuda and not self.sid:
+        """BCE over foreground pixels (those with a depth label), reference :595-622.  On the GPU labels are bin
+        indices and the loss is one HIP operator (csrc/label_loss.hip)."""
+        if height.is_cuda:
             from . import label_loss
             dbin, hbin = self._hip_labels(gt_depth, gt_height)
             return label_loss.fg_bce(height, hbin, dbin, self.loss_height_weight)
@@ -358,7 +358,7 @@ class MGHS_Depth(MGHS):
 
     def get_depth_and_height_loss(self, gt_depth, gt_height, depth, height):
         """reference :859-897 -> (loss_depth, loss_height)."""
-        if height.is_cuda and not self.sid:
+        if height.is_cuda:
             from . import label_loss
             dbin, hbin = self._hip_labels(gt_depth, gt_height)
             return (label_loss.fg_bce(depth, dbin, dbin, self.loss_depth_weight),

@@ -420,6 +420,14 @@ int dhd_sparse_bin_labels(const float* gt_depth, const float* gt_height, int bn,
                           float height_offset, float height_step, int height_bins,
                           int16_t* depth_bin, int16_t* height_bin, void* stream);
 
+/* The same with spacing-increasing depth bins (MGHS(sid=True), lss_heightmap.py:655-660):
+ *   g = (log(m) - log_d0) * (depth_bins - 1) / log_ratio + 1,   log_d0 = log(d0), log_ratio = log((d1 - 1) / d0),
+ * both as the float32 values torch computes on the host; the height labels are binned linearly as above. */
+int dhd_sparse_bin_labels_sid(const float* gt_depth, const float* gt_height, int bn, int fh, int fw,
+                              int downsample, float log_d0, float log_ratio, int depth_bins,
+                              float height_offset, float height_step, int height_bins,
+                              int16_t* depth_bin, int16_t* height_bin, void* stream);
+
 size_t dhd_bin_bce_workspace_bytes(void);
 /* loss[0] = weight * sum_{pixels with fg_bin > 0} sum_c BCE(pred[b,c,pixel], [c == bin-1]) / max(1, n_fg)
  * (F.binary_cross_entropy, logs clamped at -100; :612-622).  pred is (bn, c, hw), the softmax map in

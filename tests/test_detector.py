@@ -480,3 +480,53 @@ def test_resnet_frozen_stages_take_effect_at_construction():
     assert n_trainable == sum(p.numel() for p in m.parameters()) - sum(p.numel() for mm in (m.conv1, m.bn1, m.layer1) for p in mm.parameters())
     with pytest.raises(ValueError):
         ResNet(depth=50, num_stages=4, frozen_stages=5)
+
+
+def test_checkpoint_ingestion_for_the_reference_key_names(tmp_path):
+    """DHD-S.py:280 `load_from` / :53 `pretrained`: a checkpoint in the layout mmcv writes ({'meta', 'state_dict'} with the
+    reference's key names, optionally under a DataParallel `module.` prefix) loads into the mirrored detector key for key;
+    a torchvision-layout ResNet-50 file initialises the image backbone; mismatches are reported, not silently skipped."""
+    import warnings
+    import dhd_amd
+    from dhd_amd.detector import ResNet, dhd_s_model_cfg
+    cfg = dhd_s_model_cfg()
+    cfg['img_backbone'] = dict(cfg['img_backbone'], pretrained=None)
+    torch.manual_seed(0)
+    src = dhd_amd.build_detector(cfg)
+    ref_keys = ('img_view_transformer.depth_net.weight', 'img_view_transformer.height_net.reduce_conv.0.weight',
+                'mix.mysk_7.fc.0.weight', 'mix.mysk_7.spacial_leanring.3.weight', 'occ_head.predicter.0.weight',
+                'img_backbone.layer4.2.conv3.weight', 'img_voxel_encoder2.inc.double_conv.0.weight')
+    sd = src.state_dict()
+    assert all(k in sd for k in ref_keys)
+    path = tmp_path / 'epoch_24.pth'
+    torch.save(dict(meta=dict(epoch=24, iter=84408), state_dict={'module.' + k: v for k, v in sd.items()}), path)   # saved from inside MMDataParallel
+    torch.manual_seed(1)
+    dst = dhd_amd.build_detector(cfg)
+    assert not torch.equal(dst.state_dict()[ref_keys[0]], sd[ref_keys[0]])
+    ckpt = dhd_amd.load_checkpoint(dst, str(path), strict=True)
+    assert ckpt['meta']['epoch'] == 24 and ckpt['_load_report'] == dict(missing=[], unexpected=[], mismatched=[])
+    for k, v in dst.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # a backbone-only file in torchvision's layout (its classifier `fc` is not part of the trunk)
+    tv = {k[len('img_backbone.'):]: v for k, v in sd.items() if k.startswith('img_backbone.')}
+    tv.update({'fc.weight': torch.zeros(1000, 2048), 'fc.bias': torch.zeros(1000)})
+    tv_path = tmp_path / 'resnet50-0676ba61.pth'
+    torch.save(tv, tv_path)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')            # a local file loads without the "not implemented" warning
+        net = ResNet(depth=50, out_indices=(2, 3), pretrained=str(tv_path))
+    assert torch.equal(net.layer3[5].conv2.weight, sd['img_backbone.layer3.5.conv2.weight'])
+    # prefix selection, size mismatch reporting, and the schemes that cannot be served
+    net2 = ResNet(depth=50, out_indices=(2, 3))
+    rep = dhd_amd.load_checkpoint(net2, str(path), prefix='img_backbone', quiet=True)['_load_report']
+    assert rep['missing'] == [] and rep['unexpected'] == [] and torch.equal(net2.conv1.weight, sd['img_backbone.conv1.weight'])
+    bad = dict(sd)
+    bad['occ_head.predicter.0.weight'] = torch.zeros(3, 3)
+    torch.save(dict(state_dict=bad), tmp_path / 'bad.pth')
+    with pytest.warns(UserWarning):
+        rep = dhd_amd.load_checkpoint(dst, str(tmp_path / 'bad.pth'))['_load_report']
+    assert rep['mismatched'][0][0] == 'occ_head.predicter.0.weight'
+    with pytest.raises(RuntimeError):
+        dhd_amd.load_checkpoint(dst, str(tmp_path / 'bad.pth'), strict=True, quiet=True)
+    with pytest.raises(IOError):
+        dhd_amd.load_checkpoint(dst, 'torchvision://resnet50')

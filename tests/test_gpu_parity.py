@@ -1014,6 +1014,39 @@ def test_height_and_depth_loss_vs_torch_mirror_full_size(gpu):
         assert (a.grad - b.grad).abs().max().item() <= 1e-5 * scale
 
 
+def test_sid_depth_labels_on_the_gpu_vs_the_reference_formulation(gpu):
+    """MGHS(sid=True): spacing-increasing depth bins (lss_heightmap.py:655-660) are binned by dhd_sparse_bin_labels_sid
+    instead of a PyTorch branch.  Labels against the reference's own formulation evaluated on the CPU (float32 torch.log);
+    the device logarithm may differ in the last bit, so a value within an ulp of a bin boundary may move by one bin: at
+    most a handful of the ~7 000 labelled pixels; the loss agrees to 1e-4."""
+    import dhd_amd
+    from dhd_amd import label_loss
+    cfg = syn.dhd_s_config()
+    m = dhd_amd.build_neck(dict(cfg, type='MGHS', sid=True, heightnet_cfg=dict(use_dcn=False, use_aspp=False)))
+    assert m.sid and m.D == 44
+    gen = torch.Generator().manual_seed(8)
+    B, N = 2, 6
+    sel = torch.rand(B, N, 256, 704, generator=gen) < 0.02
+    gd = torch.rand(B, N, 256, 704, generator=gen) * 50.0 * sel
+    gh = (torch.rand(B, N, 256, 704, generator=gen) * 7.4 - 1.5) * sel
+    ref_onehot = m.get_downsampled_gt_depth(gd)                        # the reference's expression, CPU
+    ref_bin = torch.where(ref_onehot.sum(1) > 0, ref_onehot.argmax(1) + 1, torch.zeros(1, dtype=torch.long))
+    dbin, hbin = label_loss.bin_labels(gd.to(gpu), gh.to(gpu), m.downsample, m.grid_config['depth'], m.D, m.height_range[0],
+                                       m.height_interval, m.H, sid=True)
+    got = dbin.cpu().long()
+    assert (ref_bin > 0).sum() > 5000
+    diff = got != ref_bin
+    assert int(diff.sum()) <= 4 and int((got - ref_bin).abs().max()) <= 1, (int(diff.sum()), int((got - ref_bin).abs().max()))
+    lin, _ = label_loss.bin_labels(gd.to(gpu), gh.to(gpu), m.downsample, m.grid_config['depth'], m.D, m.height_range[0],
+                                   m.height_interval, m.H, sid=False)
+    assert int((lin.cpu().long() != got).sum()) > 1000                  # really another binning
+    hp = torch.softmax(torch.randn(B * N, m.H, 16, 44, generator=gen), 1)
+    mg = m.to(gpu)
+    loss_gpu = mg.get_height_loss(gd.to(gpu), gh.to(gpu), hp.to(gpu))
+    loss_ref = dhd_amd.build_neck(dict(cfg, type='MGHS', sid=True, heightnet_cfg=dict(use_dcn=False, use_aspp=False))).get_height_loss(gd, gh, hp)
+    assert abs(float(loss_gpu) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
+
+
 def test_rasterise_points_vs_oracle_and_reference_golden(gpu):
     """dhd_points_to_maps: bit-identical to the oracle (stable-sort semantics) on the golden G7 points and on a
     6-camera, 34 k-point, 256x704 case; against the reference's own maps everywhere except the tie pixels."""
