@@ -186,20 +186,29 @@ class HotPath:
         # backward: out_grad read once + depth / context read + depth_grad / feat_grad written
         self.pool_bwd_bytes = batch * (4 * C * 17 * 200 * 200 + 2 * (4 * N * D * fh * fw + 4 * N * fh * fw * C))
 
+    def make_events(self, n_steps):
+        """HIP events of the timed loop, created BEFORE it (hipEventCreate inside the loop cost up to 0.1 ms apiece on some
+        boxes: more than the MGHS-only step itself)."""
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        self._free_events = [[ev() for _ in range(7)] for _ in range(n_steps)]
+
     def step(self, record):
         cfg = self.cfg
+        pool = self._free_events.pop() if record and getattr(self, '_free_events', None) else None
+        if record and pool is None:
+            pool = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
         # dhd_mghs_lift: height argmax -> band, context re-layout, geometry + grouping (4 launches)
         _, feat_nhwc = mghs_op.lift(self.plan, self.calib, self.height, cfg['height_range'], cfg['mask_range'], self.feat, self.ws)
         if record:
             # HIP events on the launch stream, around the streaming kernel only
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = pool[0], pool[1]
             outs = mghs_op.pool_forward_phases(self.plan, self.depth, feat_nhwc, self.ws, between=e0.record)
             e1.record()
             self.ev.append((e0, e1))
         else:
             outs = mghs_op.pool_forward(self.plan, self.depth, feat_nhwc, self.ws)
         if record:
-            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0, b1 = pool[2], pool[3]
             b0.record()
         dg, fg = mghs_op.pool_backward(self.plan, self.depth, feat_nhwc, self.out_grads, self.ws)
         if record:
@@ -212,7 +221,7 @@ class HotPath:
                 prm.grad = None
             if record:
                 # HIP events on the launch stream around the stage's forward and backward calls
-                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e = pool[4:7]
                 e[0].record()
                 y = self.stage(self.x)
                 e[1].record()
@@ -796,10 +805,13 @@ def main():
         ddist.barrier()
         torch.cuda.synchronize()
 
+    hp.make_events((a.steps + 3) // 4)
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        hp.step(True)
+    for k in range(a.steps):
+        # HIP events around the dominant kernel / the backward / the SFA stage on every 4th timed step (and the first): each
+        # recorded step carries seven extra marker packets and host calls, 35 us on a 0.34 ms MGHS-only step
+        hp.step(k % 4 == 0)
     fence()
     elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
 

@@ -57,7 +57,8 @@ class SfaWeights(C.Structure):
                  ('fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'conv1_w', 'conv1_b', 'bn1_w', 'bn1_b', 'bn1_mean', 'bn1_var',
                   'conv2_w', 'conv2_b', 'bn2_w', 'bn2_b', 'bn2_mean', 'bn2_var')] +
                 [('hidden', C.c_int32), ('training', C.c_int32), ('eps1', C.c_float), ('eps2', C.c_float),
-                 ('momentum1', C.c_float), ('momentum2', C.c_float), ('gemm', C.c_int32)])
+                 ('momentum1', C.c_float), ('momentum2', C.c_float), ('gemm', C.c_int32),
+                 ('bn1_batches', C.c_void_p), ('bn2_batches', C.c_void_p)])
 
 
 SFA_GEMM = {'default': 0, 'bf16x6': 1, 'f32': 2, 'bf16x3': 3}   # dhd_sfa_weights.gemm

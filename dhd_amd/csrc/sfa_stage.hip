@@ -76,8 +76,7 @@ __device__ __forceinline__ void chunk_range4(int hw, int* lo, int* hi) {
 // small dense pieces: channel mean -> fc -> a, and its backward
 // ------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(kEwBlock) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ part, int hw) {
-  __shared__ float sm[kEwBlock / DHD_WAVE];
+__device__ __forceinline__ void plane_mean_block(const float* __restrict__ x, float* __restrict__ part, int hw, float* sm) {
   const size_t plane = blockIdx.y;
   const f32x4* p4 = reinterpret_cast<const f32x4*>(x + plane * hw);
   int lo, hi;
@@ -97,9 +96,15 @@ __global__ __launch_bounds__(kEwBlock) void plane_mean_kernel(const float* __res
   if (threadIdx.x == 0) part[plane * kPlaneChunks + blockIdx.x] = tot;
 }
 
+__global__ __launch_bounds__(kEwBlock) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ part, int hw) {
+  __shared__ float sm[kEwBlock / DHD_WAVE];
+  plane_mean_block(x, part, hw, sm);
+}
+
 // one block per sample: s = mean, h = relu(fc1 s), a = sigmoid(fc2 h); blend table (a, 1-a, 0).  The kernel is a
 // chain of dependent L2 round trips on the stage's critical path, so each phase puts all its loads in flight at
-// once: 16 waves x 4 rows of fc1 per pass, 16-byte loads of the fc2 rows.
+// once: 16 waves x 4 rows of fc1 per pass, 16-byte loads of the fc2 rows.  (Round 3, tried: both weight matrices requested
+// into registers before the first barrier -- 96 more registers in a 1024-thread block: 15.9 -> 20.5 us, reverted.)
 constexpr int kFcBlock = 1024;
 __global__ __launch_bounds__(kFcBlock) void fc_forward_kernel(const float* __restrict__ part, const float* __restrict__ w1,
                                                               const float* __restrict__ b1, const float* __restrict__ w2,
@@ -293,9 +298,11 @@ __global__ __launch_bounds__(kEwBlock) void bn_train_finalize_kernel(const float
                                                                      float* __restrict__ run_mean, float* __restrict__ run_var,
                                                                      float momentum, float eps, float* __restrict__ mean,
                                                                      float* __restrict__ rstd, float* __restrict__ scsh,
-                                                                     float* __restrict__ tab, int nb, int c, int hw) {
+                                                                     float* __restrict__ tab, int nb, int c, int hw,
+                                                                     long long* __restrict__ batches_tracked) {
   const int ch = blockIdx.x * kEwBlock + threadIdx.x;
   if (ch >= c) return;
+  if (ch == 0 && batches_tracked) *batches_tracked += 1;   // nn.BatchNorm2d.num_batches_tracked
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll 8
   for (int q = 0; q < n_part; ++q) {
@@ -980,11 +987,9 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm6_kernel(const float* __re
 
 // Weight (rows x k; or its transpose) -> per-team-member slices of MFMA B fragments:
 //   packed16[(((g*KC + kc)*COB + t)*NT + term)*64 + lane] = term(M[g*32*COB + 32 t + (lane&31)][16 kc + 8 (lane>>5) + j]), j = 0..7
-__global__ __launch_bounds__(kEwBlock) void pack_weight_res_kernel(const float* __restrict__ w, const float* __restrict__ w_second,
-                                                                   int transpose, u32x4* __restrict__ packed,
-                                                                   u32x4* __restrict__ packed_second, int c, int cob, int nt) {
-  if (blockIdx.y == 1) { w = w_second; packed = packed_second; }   // both convolutions' weights in one launch
-  const int idx = blockIdx.x * kEwBlock + threadIdx.x;  // (g, kc, t, lane)
+__device__ __forceinline__ void pack_weight_res_block(const float* __restrict__ w, int transpose, u32x4* __restrict__ packed, int c,
+                                                      int cob, int nt, int block) {
+  const int idx = block * kEwBlock + threadIdx.x;  // (g, kc, t, lane)
   const int kcn = c / 16;
   if (idx >= (c / 32) * kcn * 64) return;
   int q = idx;
@@ -1008,6 +1013,32 @@ __global__ __launch_bounds__(kEwBlock) void pack_weight_res_kernel(const float* 
   dst[0] = h;
   dst[64] = m;
   if (nt == 3) dst[128] = l;
+}
+
+__global__ __launch_bounds__(kEwBlock) void pack_weight_res_kernel(const float* __restrict__ w, const float* __restrict__ w_second,
+                                                                   int transpose, u32x4* __restrict__ packed,
+                                                                   u32x4* __restrict__ packed_second, int c, int cob, int nt) {
+  // both convolutions' weights in one launch
+  pack_weight_res_block(blockIdx.y == 1 ? w_second : w, transpose, blockIdx.y == 1 ? packed_second : packed, c, cob, nt, blockIdx.x);
+}
+
+// The forward's first launch: the channel means of x (blockIdx.y < n_planes) and, in rows of extra blocks, all FOUR weight
+// images of the call -- conv1 / conv2 for the forward GEMMs and their transposes for the backward's data-gradient GEMMs, which
+// round 2 packed in two separate launches (one per direction) on the critical path of either pass.
+struct PackJob {
+  const float* w[2];     // conv1, conv2
+  u32x4* dst[4];         // conv1, conv2, conv1^T, conv2^T
+  int c, cob, nt, blocks_each;
+};
+
+__global__ __launch_bounds__(kEwBlock) void plane_mean_pack_kernel(const float* __restrict__ x, float* __restrict__ part, int hw,
+                                                                   int n_planes, PackJob job) {
+  __shared__ float sm[kEwBlock / DHD_WAVE];
+  if ((int)blockIdx.y < n_planes) { plane_mean_block(x, part, hw, sm); return; }
+  const int pb = ((int)blockIdx.y - n_planes) * kPlaneChunks + (int)blockIdx.x;
+  const int which = pb / job.blocks_each;
+  if (which >= 4) return;
+  pack_weight_res_block(job.w[which & 1], which >> 1, job.dst[which], job.c, job.cob, job.nt, pb % job.blocks_each);
 }
 
 constexpr int kResTrPitch = 36;
@@ -1190,27 +1221,39 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
   };
 
   int wtg = team * WAVES + wv;
-  // BatchNorm statistics of the output (EPI 0): bf16x3 keeps them per lane over all of the wave's tiles and writes ONE row
-  // per wave, stat_part[team * WAVES + wave][2][c] (1024 rows instead of 5000 at B = 4, and no cross-lane exchange or store
-  // per tile); bf16x6 writes a row per (sample, wave tile) like the streamed kernels, whose results it reproduces bit for bit
+  // BatchNorm statistics of the output (EPI 0): bf16x3 keeps them per lane over all of the wave's tiles; at the end the
+  // workgroup's eight waves meet in LDS and ONE row per workgroup is written, stat_part[team][2][c] (each member of a team
+  // its own channels): 128 rows at B = 4, where round 2 wrote a row per wave (1 024) and round 1 one per (sample, wave
+  // tile) (5 000) -- the finalize kernel that reads them is a latency chain on the stage's critical path.  bf16x6 writes a
+  // row per (sample, wave tile) like the streamed kernels, whose results it reproduces bit for bit.
   constexpr bool kWaveStats = EPI == 0 && NT == 2;
   float ws1[COB], ws2[COB];
 #pragma unroll
   for (int t = 0; t < COB; ++t) ws1[t] = ws2[t] = 0.f;
-  auto flush_stats = [&]() {
+  auto flush_stats = [&]() {   // every wave of the workgroup calls this exactly once (it contains a barrier)
     if (!kWaveStats || stat_part == nullptr) return;
-    float* q = stat_part + ((size_t)(team * WAVES + wv) * 2) * c + g * 32 * COB + r;
 #pragma unroll
     for (int t = 0; t < COB; ++t) {
       const float s1 = ws1[t] + __shfl_xor(ws1[t], 32, DHD_WAVE), s2 = ws2[t] + __shfl_xor(ws2[t], 32, DHD_WAVE);
       if (h == 0) {
-        q[32 * t] = s1;
-        q[c + 32 * t] = s2;
+        tr[32 * t + r] = s1;                       // the wave's store patch: [2][COB * 32] floats
+        tr[COB * 32 + 32 * t + r] = s2;
+      }
+    }
+    __syncthreads();
+    if (wv == 0) {
+      const float* all = cf + ((nb * 3 * c + 3) & ~3);
+      float* q = stat_part + ((size_t)team * 2) * c + g * 32 * COB;
+      for (int i = lane; i < 2 * COB * 32; i += DHD_WAVE) {
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < WAVES; ++w8) v += all[w8 * (16 * kTrPitch) + i];
+        q[(i / (COB * 32)) * c + (i % (COB * 32))] = v;
       }
     }
   };
-  if (wtg >= total) {                              // wave-uniform; no barrier follows
-    flush_stats();                                 // zeros: every row of the table is written
+  if (wtg >= total) {                              // wave-uniform
+    flush_stats();                                 // zeros into the workgroup's sum
     return;
   }
   // epilogue operands are requested long before they are used: a load issued inside the epilogue is waited for at once,
@@ -1318,7 +1361,7 @@ __global__ __launch_bounds__(kEwBlock) void bn_stats_finalize_kernel(const float
                                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                                      float* __restrict__ scsh, float* __restrict__ tab, int nb, int c,
                                                                      int hw, double* __restrict__ sums_out, double* __restrict__ sums_out2,
-                                                                     const double* __restrict__ sums_in) {
+                                                                     const double* __restrict__ sums_in, long long* __restrict__ batches_tracked) {
   // Cross-rank statistics (nn.SyncBatchNorm, dhd_sfa_stage_*_phase): with `sums_out` the kernel stops after the row
   // reduction and leaves this rank's shifted sums as doubles, [sum (y - shift)][C] | [sum (y - shift)^2][C] | count, in
   // sums_out and sums_out2; with `sums_in` it starts from such a vector (all-reduced by the caller) instead of the rows.
@@ -1366,6 +1409,7 @@ __global__ __launch_bounds__(kEwBlock) void bn_stats_finalize_kernel(const float
     return;
   }
   if (sums_in) { s1 = sums_in[ch]; s2 = sums_in[c + ch]; cnt = sums_in[2 * c]; }
+  if (ch == 0 && batches_tracked) *batches_tracked += 1;   // nn.BatchNorm2d.num_batches_tracked (one kernel launch less per BatchNorm)
   const double md = s1 / cnt;
   double var = s2 / cnt - md * md;
   if (var < 0.0) var = 0.0;
@@ -1924,7 +1968,7 @@ __global__ __launch_bounds__(kEwBlock) void wgrad_reduce_kernel(const float* __r
 inline size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }  // in floats: 256-byte sections
 
 struct SavedLayout {
-  size_t s, h, a1, tab_a, mean1, rstd1, scsh1, tab1, mean2, rstd2, scsh2, loc1, loc2, mask, y1, y2, total;
+  size_t s, h, a1, tab_a, mean1, rstd1, scsh1, tab1, mean2, rstd2, scsh2, loc1, loc2, wp1t, wp2t, mask, y1, y2, total;
 };
 SavedLayout saved_layout(int b, int c, int hw, int r) {
   SavedLayout L;
@@ -1937,6 +1981,7 @@ SavedLayout saved_layout(int b, int c, int hw, int r) {
   L.mean1 = take(c); L.rstd1 = take(c); L.scsh1 = take(2 * c); L.tab1 = take((size_t)b * 3 * c);
   L.mean2 = take(c); L.rstd2 = take(c); L.scsh2 = take(2 * c);
   L.loc1 = take(2 * (2 * (size_t)c + 1)); L.loc2 = take(2 * (2 * (size_t)c + 1));   // (2C + 1) doubles each: this rank's shifted sums + count (phased calls)
+  L.wp1t = take(2 * (size_t)c * c); L.wp2t = take(2 * (size_t)c * c);   // transposed weight images, packed by the forward for the backward
   L.mask = take((size_t)b * c * ((hw + 31) / 32));  // ReLU pass bits, one word per (32 pixels, channel): [sample][wave tile][channel]
   L.y1 = take((size_t)b * c * hw);
   L.y2 = take((size_t)b * c * hw);
@@ -1945,14 +1990,14 @@ SavedLayout saved_layout(int b, int c, int hw, int r) {
 }
 
 struct ScratchLayout {
-  size_t wp1, wp2, wp1t, wp2t, part, da1, da2, tab_g2, tab_g1, dpre2, dh, ds, mean_part, stat_part, g2, g1, du, wpart, total;
+  size_t wp1, wp2, part, da1, da2, tab_g2, tab_g1, dpre2, dh, ds, mean_part, stat_part, g2, g1, du, wpart, total;
 };
 ScratchLayout scratch_layout(int b, int c, int hw, int r) {
   ScratchLayout L;
   size_t o = 0;
   auto take = [&](size_t n) { size_t at = o; o += align_up(n); return at; };
   const size_t cc = (size_t)c * c, plane = (size_t)b * c * hw;
-  L.wp1 = take(2 * cc); L.wp2 = take(2 * cc); L.wp1t = take(2 * cc); L.wp2t = take(2 * cc);  // f32 images: cc, bf16x6 images: 1.5 cc
+  L.wp1 = take(2 * cc); L.wp2 = take(2 * cc);  // f32 images: cc, bf16x6 images: 1.5 cc (the transposed ones: SavedLayout)
   L.part = take((size_t)b * kPlaneChunks * 2 * c);
   L.stat_part = take((size_t)b * ((hw + 31) / 32 + 64) * 2 * c);   // a row per (sample, wave tile), or per wave of every launch (<= tiles + 63 each)
   L.da1 = take((size_t)b * kPlaneChunks * c);
@@ -2094,7 +2139,7 @@ int launch_pw_gemm_res(const float* in0, const float* in1, size_t in_bstride, in
     const float* cf = coef + (size_t)b0 * 3 * c;
     unsigned* rm = relu_mask ? relu_mask + (size_t)b0 * nwt * c : nullptr;
     float* sp = stat_part ? stat_part + (size_t)rows_done * 2 * c : nullptr;
-    rows_done += nt == 2 ? nteams * kResWaves : (int)total;
+    rows_done += nt == 2 ? nteams : (int)total;
     float* yo = y + (size_t)b0 * c * hw;
 #define DHD_RES(NT, COB, KCN, TWO, RELU, EPI)                                                                            \
   do {                                                                                                                \
@@ -2316,12 +2361,25 @@ static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, float* o
   int rc;
 
   if (lo <= 0) {
-    hipLaunchKernelGGL(plane_mean_kernel, planes2, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw);
+    if (res_supported(c)) {
+      PackJob job;
+      job.w[0] = w->conv1_w; job.w[1] = w->conv2_w;
+      job.dst[0] = reinterpret_cast<u32x4*>(sc + T.wp1); job.dst[1] = reinterpret_cast<u32x4*>(sc + T.wp2);
+      job.dst[2] = reinterpret_cast<u32x4*>(sv + S.wp1t); job.dst[3] = reinterpret_cast<u32x4*>(sv + S.wp2t);
+      job.c = c; job.nt = mode_terms(); job.cob = res_cob(c, job.nt);
+      job.blocks_each = dhd_cdiv((c / 32) * (c / 16) * 64, kEwBlock);
+      const dim3 grid(kPlaneChunks, b * 2 * c + dhd_cdiv(4 * job.blocks_each, kPlaneChunks));
+      hipLaunchKernelGGL(plane_mean_pack_kernel, grid, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw, b * 2 * c, job);
+    } else {
+      hipLaunchKernelGGL(plane_mean_kernel, planes2, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw);
+      rc = launch_pack(w->conv1_w, 0, sc + T.wp1, c, st, w->conv2_w, sc + T.wp2);
+      if (rc != DHD_OK) return rc;
+      rc = launch_pack(w->conv1_w, 1, sv + S.wp1t, c, st, w->conv2_w, sv + S.wp2t);
+      if (rc != DHD_OK) return rc;
+    }
     hipLaunchKernelGGL(fc_forward_kernel, dim3(b), dim3(kFcBlock), (size_t)(2 * c + r) * sizeof(float), st, sc + T.mean_part,
                        w->fc1_w, w->fc1_b, w->fc2_w, w->fc2_b, sv + S.s, sv + S.h, sv + S.a1, sv + S.tab_a, c, r, hw);
     DHD_LAUNCH_CHECK();
-    rc = launch_pack(w->conv1_w, 0, sc + T.wp1, c, st, w->conv2_w, sc + T.wp2);
-    if (rc != DHD_OK) return rc;
     // y1 = conv1(blend1(x))
     rc = launch_pw_gemm(x, x + (size_t)c * hw, (size_t)2 * c * hw, c, sv + S.tab_a, false, sc + T.wp1, w->conv1_b, nullptr, nullptr,
                         nullptr, fused_stats ? sc + T.stat_part : nullptr, sv + S.y1, 0, b, c, hw, st, &stat_rows);
@@ -2329,7 +2387,7 @@ static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, float* o
     if (sync) {   // this rank's sums only (also kept in `saved` for the backward's convolution-bias gradient)
       hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, sc + T.stat_part, stat_rows, w->conv1_b, w->bn1_w,
                          w->bn1_b, w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1,
-                         sv + S.tab1, b, c, hw, sync, reinterpret_cast<double*>(sv + S.loc1), nullptr);
+                         sv + S.tab1, b, c, hw, sync, reinterpret_cast<double*>(sv + S.loc1), nullptr, nullptr);
       DHD_LAUNCH_CHECK();
     }
   }
@@ -2339,12 +2397,12 @@ static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, float* o
       if (fused_stats) {  // the GEMM epilogue left per-(sample, wave tile) sums shifted by the bias
         hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, sc + T.stat_part, stat_rows, w->conv1_b, w->bn1_w,
                            w->bn1_b, w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1,
-                           sv + S.tab1, b, c, hw, nullptr, nullptr, sync);
+                           sv + S.tab1, b, c, hw, nullptr, nullptr, sync, reinterpret_cast<long long*>(w->bn1_batches));
       } else {
         hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y1, sc + T.part, c, hw);
         hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, b * kPlaneChunks, sv + S.y1, hw, w->bn1_w,
                            w->bn1_b, w->bn1_mean, w->bn1_var, w->momentum1, w->eps1, sv + S.mean1, sv + S.rstd1, sv + S.scsh1,
-                           sv + S.tab1, b, c, hw);
+                           sv + S.tab1, b, c, hw, reinterpret_cast<long long*>(w->bn1_batches));
       }
     } else {
       hipLaunchKernelGGL(bn_eval_coef_kernel, per_ch, dim3(kEwBlock), 0, st, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, w->eps1,
@@ -2359,7 +2417,7 @@ static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, float* o
     if (sync) {
       hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, sc + T.stat_part, stat_rows, w->conv2_b, w->bn2_w,
                          w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, sv + S.mean2, sv + S.rstd2, sv + S.scsh2,
-                         sc + T.tab_g2, b, c, hw, sync, reinterpret_cast<double*>(sv + S.loc2), nullptr);
+                         sc + T.tab_g2, b, c, hw, sync, reinterpret_cast<double*>(sv + S.loc2), nullptr, nullptr);
       DHD_LAUNCH_CHECK();
     }
   }
@@ -2369,12 +2427,12 @@ static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, float* o
     if (fused_stats) {  // the GEMM epilogue left per-(sample, wave tile) sums shifted by the bias
       hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, sc + T.stat_part, stat_rows, w->conv2_b, w->bn2_w,
                          w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, sv + S.mean2, sv + S.rstd2, sv + S.scsh2,
-                         tab_unused, b, c, hw, nullptr, nullptr, sync);
+                         tab_unused, b, c, hw, nullptr, nullptr, sync, reinterpret_cast<long long*>(w->bn2_batches));
     } else {
       hipLaunchKernelGGL(moments_kernel, planes, dim3(kEwBlock), 0, st, sv + S.y2, sc + T.part, c, hw);
       hipLaunchKernelGGL(bn_train_finalize_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, b * kPlaneChunks, sv + S.y2, hw, w->bn2_w,
                          w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, sv + S.mean2, sv + S.rstd2, sv + S.scsh2,
-                         tab_unused, b, c, hw);
+                         tab_unused, b, c, hw, reinterpret_cast<long long*>(w->bn2_batches));
     }
   } else {
     hipLaunchKernelGGL(bn_eval_coef_kernel, per_ch, dim3(kEwBlock), 0, st, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, w->eps2,
@@ -2409,8 +2467,6 @@ static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const v
   int rc;
 
   if (lo <= 0) {
-    rc = launch_pack(w->conv1_w, 1, sc + T.wp1t, c, st, w->conv2_w, sc + T.wp2t);
-    if (rc != DHD_OK) return rc;
     // g2 = dL/ds2, BatchNorm-2 sums, go-part of dL/da
     hipLaunchKernelGGL(blend2_bn_bwd_kernel, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, sv + S.mean2, gout,
                        sc + T.g2, sc + T.part, sc + T.da1, c, hw);
@@ -2430,7 +2486,7 @@ static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const v
                          grads->conv2_w, b, c, hw, st);
     if (rc != DHD_OK) return rc;
     // g1 = (W2^T dy2) * [z1 > 0]
-    rc = launch_pw_gemm(sc + T.g2, sv + S.y2, cs, c, sc + T.tab_g2, false, sc + T.wp2t, nullptr, sv + S.y1, sv + S.scsh1,
+    rc = launch_pw_gemm(sc + T.g2, sv + S.y2, cs, c, sc + T.tab_g2, false, sv + S.wp2t, nullptr, sv + S.y1, sv + S.scsh1,
                         reinterpret_cast<unsigned*>(const_cast<float*>(sv + S.mask)), nullptr, sc + T.g1, 1, b,
                         c, hw, st);
     if (rc != DHD_OK) return rc;
@@ -2450,7 +2506,7 @@ static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const v
                        b, c, hw, st);
   if (rc != DHD_OK) return rc;
   // du = W1^T dy1
-  rc = launch_pw_gemm(sc + T.g1, sv + S.y1, cs, c, sc + T.tab_g1, false, sc + T.wp1t, nullptr, nullptr, nullptr, nullptr, nullptr, sc + T.du, 2, b, c,
+  rc = launch_pw_gemm(sc + T.g1, sv + S.y1, cs, c, sc + T.tab_g1, false, sv + S.wp1t, nullptr, nullptr, nullptr, nullptr, nullptr, sc + T.du, 2, b, c,
                       hw, st);
   if (rc != DHD_OK) return rc;
   hipLaunchKernelGGL(blend1_da_kernel, planes, dim3(kEwBlock), 0, st, x, sc + T.du, sc + T.da2, c, hw);

@@ -109,13 +109,20 @@ def default_gemm():
 
 
 def _bn_momentum(bn, training):
-    """Update factor nn.BatchNorm2d would use for this call (torch/nn/modules/batchnorm.py: forward)."""
+    """(update factor nn.BatchNorm2d would use for this call, device address of num_batches_tracked for the operator to
+    increment or None) -- torch/nn/modules/batchnorm.py: forward.  With a fixed momentum the counter is pure bookkeeping
+    and the stage operator increments it itself; momentum=None (cumulative average) needs its value on the host."""
     if not (training and bn.track_running_stats):
-        return 0.0
-    bn.num_batches_tracked.add_(1)
+        return 0.0, None
     if bn.momentum is None:
-        return 1.0 / float(bn.num_batches_tracked)
-    return float(bn.momentum)
+        bn.num_batches_tracked.add_(1)
+        return 1.0 / float(bn.num_batches_tracked), None
+    nbt = bn.num_batches_tracked
+    if nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64:
+        return float(bn.momentum), nbt.data_ptr()
+    if nbt is not None:
+        nbt.add_(1)
+    return float(bn.momentum), None
 
 
 _STAGE_PARAMS = ('fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'conv1_w', 'conv1_b', 'bn1_w', 'bn1_b',
@@ -158,7 +165,7 @@ class _FusedStage(torch.autograd.Function):
         wts.hidden, wts.training = hidden, training
         wts.gemm = _lib.SFA_GEMM[stage.gemm or default_gemm()]   # per call; backward reuses this struct
         wts.eps1, wts.eps2 = bn1.eps, bn2.eps
-        wts.momentum1, wts.momentum2 = _bn_momentum(bn1, training), _bn_momentum(bn2, training)
+        (wts.momentum1, wts.bn1_batches), (wts.momentum2, wts.bn2_batches) = _bn_momentum(bn1, training), _bn_momentum(bn2, training)
         if training and not bn1.training:
             wts.bn1_mean = wts.bn1_var = wts.bn2_mean = wts.bn2_var = None
         group = _sync_group(stage)   # None, or the process group whose ranks share BatchNorm statistics (nn.SyncBatchNorm)

@@ -316,6 +316,8 @@ typedef struct dhd_sfa_weights { /* [dev] float32 */
   float eps1, eps2;
   float momentum1, momentum2; /* update factor of the running statistics */
   int32_t gemm;         /* DHD_SFA_GEMM_* below */
+  int64_t* bn1_batches; /* [dev] nn.BatchNorm2d.num_batches_tracked of the two layers, or NULL: incremented by one in a */
+  int64_t* bn2_batches; /*       training-mode forward (instead of two one-element launches by the caller)              */
 } dhd_sfa_weights;
 
 typedef struct dhd_sfa_grads { /* [dev] float32 outputs, shapes as in dhd_sfa_weights, overwritten */
