@@ -382,6 +382,27 @@ def hbm_calibration(dev, nbytes, reps=20, warmup=3):
     return out, nbytes
 
 
+def lift_timing(hp, reps=20, warmup=3):
+    """dhd_mghs_lift (band ids + context re-layout + geometry + grouping, every frame: training) against
+    dhd_mghs_lift_static (static rig at inference, SURVEY 8f-1: camera matrices and the full-height grid's grouping reused,
+    only the band grids' entries redone), HIP events around the call, on a workspace with its own scratch."""
+    cfg = hp.cfg
+    ws = hp.plan.new_workspace(hp.dev, private_scratch=True)
+    out = {}
+    for name, static in (('lift_us', False), ('lift_static_us', True)):
+        ev = []
+        for it in range(warmup + reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            mghs_op.lift(hp.plan, hp.calib, hp.height, cfg['height_range'], cfg['mask_range'], hp.feat, ws, static=static)
+            e1.record()
+            if it >= warmup:
+                ev.append((e0, e1))
+        torch.cuda.synchronize()
+        out[name] = 1e3 * float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    return out
+
+
 def operator_roofline(hp, steps, warmup):
     """The operator-level drop-in on its own (include/dhd_amd.h section 1 = bev_pool.cpp:30-39,74-85): the full-height
     grid with reference-style index lists (ranks_depth / ranks_feat / ranks_bev sorted by voxel, interval starts /
@@ -829,6 +850,7 @@ def main():
         elapsed_x6 = ddist.max_over_ranks(time.perf_counter() - t0, dev)
         hp.stage.gemm = main_gemm
     cal_ms, cal_bytes = hbm_calibration(dev, hp.pool_fwd_bytes)   # every rank runs it, rank 0 reports
+    lift_us = lift_timing(hp)
 
     line = None
     if rank == 0:
@@ -853,7 +875,10 @@ def main():
                           # same-run, same-timer calibration streams over the same number of bytes (hbm_calibration)
                           memset_ms=cal_ms['memset'], fill_ms=cal_ms['fill'], read_ms=cal_ms['read'], calibration_bytes=cal_bytes,
                           frac_of_fill=cal_ms['fill'] / kern_ms, frac_of_memset=cal_ms['memset'] / kern_ms,
-                          fill_GBps=cal_bytes / (cal_ms['fill'] * 1e-3) / 1e9, read_GBps=cal_bytes / (cal_ms['read'] * 1e-3) / 1e9))
+                          fill_GBps=cal_bytes / (cal_ms['fill'] * 1e-3) / 1e9, read_GBps=cal_bytes / (cal_ms['read'] * 1e-3) / 1e9,
+                          event_samples=len(hp.ev)))
+        line['prepare'] = dict(lift_us, note='dhd_mghs_lift = height argmax -> band + context re-layout + geometry + grouping (4 launches, '
+                               'every frame in training); dhd_mghs_lift_static = the same for a static rig at inference (SURVEY 8f-1)')
         if elapsed_x6 is not None:
             line['ms_per_step_bf16x6'] = 1e3 * elapsed_x6 / a.steps
             line['value_bf16x6'] = a.batch * world * a.steps / elapsed_x6

@@ -42,8 +42,7 @@ struct Layout {
   int flags;       // dhd_mghs_desc.flags
   // scratch carve (device pointers): valid from prepare to the forward after it
   int* count;      // [V]     entries per voxel                      } one contiguous, zero-filled range per prepare:
-  unsigned long long* scan_state;  // [n_chunks] look-back words       } count | scan_state | ticket
-  int* ticket;     // [64]    chunk ticket of the single-pass scan   }
+  unsigned long long* scan_state;  // [n_chunks] chunk aggregates      } count | scan_state
   int* offset;     // [V+1]   exclusive prefix of count            (entry index space)
   int* key;        // [2P]    voxel id of point p in grid 0 ([p]) and in its band grid ([P+p]); -1 = dropped
   int* rnk;        // [2P]    arrival rank of the point inside its voxel
@@ -59,7 +58,7 @@ struct Layout {
   int* nzoff;      // [V+1]   exclusive prefix of (count > 0)      (non-empty voxel ordinal, "slot")
   int* nzvox;      // [min(2P, V)] voxel id of every slot
   int* p_slot;     // [2P]    slot of point p in grid 0 ([p]) and in its band grid ([P+p]); -1 = dropped
-  size_t zero_bytes;  // bytes of the count | scan_state | ticket range
+  size_t zero_bytes;  // bytes of the count | scan_state range
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -124,14 +123,16 @@ inline int make_layout(const dhd_mghs_desc* d, const dhd_mghs_workspace* ws, Lay
     if ((reinterpret_cast<uintptr_t>(ws->state) | reinterpret_cast<uintptr_t>(ws->scratch)) & 255) return DHD_EINVAL;
   }
   const size_t P2 = 2 * (size_t)L->P;
-  const size_t max_slots = P2 < (size_t)L->V ? P2 : (size_t)L->V;
+  // non-empty voxels ("slots"): grid 0 receives at most one entry per point, the band grids TOGETHER at most one per point
+  // (a pixel belongs to one band), and no grid more slots than it has voxels
+  const size_t v0 = (size_t)L->vox_base[1], vb = (size_t)L->V - v0, pp = (size_t)L->P;
+  const size_t max_slots = (v0 < pp ? v0 : pp) + (vb < pp ? vb : pp);
   L->n_slots_max = (int)max_slots;
   size_t off = 0;
   char* base = ws ? static_cast<char*>(ws->scratch) : nullptr;
   auto carve = [&](size_t n_words) { int* p = reinterpret_cast<int*>(base + off); off = align_up(off + n_words * 4, 256); return p; };
   L->count = carve((size_t)L->V);
   L->scan_state = reinterpret_cast<unsigned long long*>(carve(2 * (size_t)L->n_chunks));
-  L->ticket = carve(64);
   L->zero_bytes = off;
   L->offset = carve((size_t)L->V + 1);
   L->key = carve(P2);

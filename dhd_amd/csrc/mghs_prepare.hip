@@ -149,7 +149,7 @@ __device__ __forceinline__ void camera_block(const Layout& L, const dhd_calib& c
 
 // ---------------------------------------------------------------------------------------
 // Prologue: everything of a lift that depends on nothing computed before it, as the roles of ONE launch (a block
-// takes the role its index falls into): zero-fill of the counters and of the scan's look-back words, the per-camera
+// takes the role its index falls into): zero-fill of the counters and of the scan's chunk aggregates, the per-camera
 // matrices, height argmax -> band id, NCHW -> NHWC of the context features.  (Round 2 issued them as a memset and
 // four kernels of 5-8 us each, none of which fills the chip.)
 // ---------------------------------------------------------------------------------------
@@ -288,14 +288,14 @@ __global__ __launch_bounds__(kBlock) void mghs_voxel_index_kernel(Layout L, dhd_
 
 // ---------------------------------------------------------------------------------------
 // Exclusive scans over the per-voxel counters in ONE pass: `offset` = prefix of count (entry index), `nzoff` = prefix of
-// (count > 0) (slot index).  A block takes the next chunk of kChunk counters by ticket (so every predecessor chunk has
-// started), publishes its chunk aggregate as one 64-bit word [valid:1 | entries:31 | slots:32], and then adds up the
-// published words of ALL its predecessors, its 256 threads polling 256 words at a time.  No block waits for another
-// block's PREFIX, only for aggregates, which every block publishes before it waits for anything: the chain of a decoupled
-// look-back (a block adopts the inclusive prefix of a predecessor, which had to wait for its own predecessors ...) does not
-// exist.  Measured at B = 4 (1 328 chunks): 6 + 11 us as a chunk-sum pass and a scan pass (round 2), 30 us as a classic
-// look-back with all chunks starting at once, and the form below.  Value and flag share one word, written and read with
-// relaxed device-scope atomics: no fences are needed.
+// (count > 0) (slot index).  Block i takes chunk i of kChunk counters, publishes its chunk aggregate as one 64-bit word
+// [valid:1 | entries:31 | slots:32], and then adds up the published words of ALL its predecessors, its 256 threads polling
+// 256 words at a time.  No block waits for another block's PREFIX, only for aggregates, which every block publishes before
+// it waits for anything: the chain of a decoupled look-back (a block adopts the inclusive prefix of a predecessor, which had
+// to wait for its own predecessors ...) does not exist, and a block only ever waits for lower-numbered blocks, which the
+// dispatcher starts first.  Measured at B = 4 (1 328 chunks): 6 + 11 us as a chunk-sum pass and a scan pass (round 2);
+// 30 us with chunks handed out by an atomic ticket (1 328 returning atomics on one address), with or without a look-back
+// chain; 14 us as below.  Value and flag share one word, written and read with relaxed device-scope atomics: no fences.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long scan_word(int entries, int slots) {
   return (1ull << 63) | ((unsigned long long)(unsigned)entries << 32) | (unsigned long long)(unsigned)slots;
@@ -468,7 +468,7 @@ int lift_impl(const dhd_mghs_desc* desc, const dhd_calib* calib, const float* he
   }
   // static rig: grid 0's counters stay (up to the last whole 256-byte block of them: the few counters of grid 0 in the
   // block shared with grid 1 are re-counted... they are not -- so the boundary must be aligned); the band grids'
-  // counters, the look-back words and the ticket are cleared
+  // counters and the scan's chunk aggregates are cleared
   size_t keep = 0;
   if (static_rig) {
     keep = (size_t)L.vox_base[1] * 4;
