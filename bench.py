@@ -86,15 +86,16 @@ def pmc_summary(batch):
     return best
 
 
-def sfa_forward_traffic(batch):
-    """Sum of the committed PMC traffic of the kernels one dhd_sfa_stage_forward call launches (training mode, default GEMM
-    mode), or None.  The two GEMMs are found by their template arguments <terms, tiles, K steps, TWO_IN, RELU, EPI, ...>:
-    conv1 = two inputs / no ReLU / epilogue 0, conv2 = one input / ReLU / epilogue 0."""
+def sfa_forward_traffic(batch, terms=2):
+    """Sum of the committed PMC traffic of the kernels one dhd_sfa_stage_forward call launches (training mode; `terms` = 2:
+    the default bf16x3 GEMMs, 3: bf16x6), or None.  The two GEMMs are found by their template arguments <terms, tiles, K steps,
+    TWO_IN, RELU, EPI, ...>: conv1 = two inputs / no ReLU / epilogue 0, conv2 = one input / ReLU / epilogue 0.  (The counter
+    passes run both precisions, so the small finalize kernel's figure is an average over them: +-5 MB of ~1.8 GB.)"""
     k = pmc_summary(batch)
     import re
-    conv1 = [v for n, v in k.items() if re.match(r'pw_gemm_res_kernel<\d+,\d+,\d+,true,false,0,', n)]
-    conv2 = [v for n, v in k.items() if re.match(r'pw_gemm_res_kernel<\d+,\d+,\d+,false,true,0,', n)]
-    calls = {'plane_mean_kernel': 1, 'fc_forward_kernel': 1, 'pack_weight_res_kernel': 1, 'bn_stats_finalize_kernel': 2, 'blend2_bn_kernel': 1}
+    conv1 = [v for n, v in k.items() if re.match(rf'pw_gemm_res_kernel<{terms},\d+,\d+,true,false,0,', n)]
+    conv2 = [v for n, v in k.items() if re.match(rf'pw_gemm_res_kernel<{terms},\d+,\d+,false,true,0,', n)]
+    calls = {'plane_mean_pack_kernel': 1, 'fc_forward_kernel': 1, 'bn_stats_finalize_kernel': 2, 'blend2_bn_kernel': 1}
     if len(conv1) != 1 or len(conv2) != 1 or any(n not in k for n in calls):
         return None
     return int(conv1[0] + conv2[0] + sum(k[n] * m for n, m in calls.items()))
@@ -899,7 +900,7 @@ def main():
             line['roofline_sfa_stage'] = dict(
                 bound='hbm', kernel='dhd_sfa_stage_forward (plane_mean, fc, 2 x pw_gemm_res, stat reductions, blend2_bn)',
                 achieved=fwd_bytes / (fwd_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit='GB/s',
-                frac=fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, traffic=sfa_forward_traffic(a.batch), launch_ms=fwd_ms,
+                frac=fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, traffic=sfa_forward_traffic(a.batch, 3 if a.sfa_gemm == 'bf16x6' else 2), launch_ms=fwd_ms,
                 algorithmic_bytes=fwd_bytes,
                 backward_ms=bwd_ms, gemm_tflops_fp32_equivalent=6 * gemm_flop / ((fwd_ms + bwd_ms) * 1e-3) / 1e12,
                 note='six C x C GEMMs per forward+backward; GEMM precision as config.sfa_gemm (include/dhd_amd.h: dhd_sfa_weights.gemm); '
