@@ -9,8 +9,8 @@ torch.manual_seed(0)
 st = channel_spatial_stage(1024).to(dev)
 x = torch.randn(b, 1024, 200, 200, device=dev, requires_grad=True)
 g = torch.randn(b, 512, 200, 200, device=dev)
-for mode in (2, 1, 3):
-    _lib.check(_lib.load().dhd_sfa_set_gemm_mode(mode), 'mode')
+for mode in ('bf16x6', 'bf16x3'):
+    st.gemm = mode
     for it in range(8):
         if it == 3:
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -19,4 +19,4 @@ for mode in (2, 1, 3):
         x.grad = None
         st(x).backward(g)
     torch.cuda.synchronize()
-    print('C=512 B=%d mode %d stage fwd+bwd ms %.3f' % (b, mode, (time.perf_counter() - t0) / 5 * 1e3))
+    print('C=512 B=%d %s stage fwd+bwd ms %.3f' % (b, mode, (time.perf_counter() - t0) / 5 * 1e3))

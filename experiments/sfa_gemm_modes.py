@@ -1,5 +1,5 @@
-"""Accuracy (vs float64 PyTorch) and speed of the SFA stage under the GEMM modes (dhd_sfa_set_gemm_mode):
-0 f32 MFMA, 2 bf16x6 streamed weights, 1 bf16x6 resident weights, 3 bf16x3 resident weights."""
+"""Accuracy (vs float64 PyTorch) and speed of the SFA stage under the GEMM precisions (dhd_sfa_weights.gemm, per call):
+f32 (f32 MFMA), bf16x6, bf16x3 (default)."""
 import copy, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dhd_amd import _lib
@@ -23,28 +23,24 @@ ref = copy.deepcopy(st).double()
 xd = x.double().requires_grad_()
 od = plain(ref, xd); od.backward(g.double())
 res = {}
-for mode, name in ((0, 'f32 MFMA'), (2, 'x6 stream'), (1, 'x6 resident'), (3, 'x3 resident'), (None, 'torch fp32')):
+for mode, name in (('f32', 'f32 MFMA'), ('bf16x6', 'bf16x6'), ('bf16x3', 'bf16x3'), (None, 'torch fp32')):
     m = copy.deepcopy(st)
     xx = x.clone().requires_grad_()
     if mode is None:
         o = plain(m, xx)
     else:
-        _lib.check(_lib.load().dhd_sfa_set_gemm_mode(mode), 'mode')
+        m.gemm = mode
         o = m(xx)
     o.backward(g)
     eo = (o.double() - od).abs().max().item()
-    if mode == 2:
-        keep = [o.detach().clone(), xx.grad.clone()]
-    if mode == 1:
-        print('   resident x6 bit-identical to streamed x6:', torch.equal(o, keep[0]), torch.equal(xx.grad, keep[1]))
     d = (xx.grad.double() - xd.grad).abs()
     med = d.flatten()[::97].median().item()
     frac = (d > 1e-4).float().mean().item()
     w1 = m.spacial_leanring[0].weight.grad.double() - ref.spacial_leanring[0].weight.grad
     w2 = m.spacial_leanring[3].weight.grad.double() - ref.spacial_leanring[3].weight.grad
     print(f'{name:10s} out max err {eo:.2e} | gx median err {med:.2e}, frac>1e-4 {frac:.2e} | dW1 rel {w1.norm().item()/ref.spacial_leanring[0].weight.grad.norm().item():.2e} dW2 rel {w2.norm().item()/ref.spacial_leanring[3].weight.grad.norm().item():.2e}')
-for mode in (0, 2, 1, 3):
-    _lib.check(_lib.load().dhd_sfa_set_gemm_mode(mode), 'mode')
+for mode in ('f32', 'bf16x6', 'bf16x3'):
+    st.gemm = mode
     xx = torch.randn(4, 512, 200, 200, device=dev, requires_grad=True)
     gg = torch.randn(4, 256, 200, 200, device=dev)
     for it in range(12):

@@ -5,11 +5,10 @@ from dhd_amd.mix import channel_spatial_stage
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device('cuda:0')
-if len(sys.argv) > 3:
-    from dhd_amd import _lib
-    _lib.check(_lib.load().dhd_sfa_set_gemm_mode(int(sys.argv[3])), 'mode')
 torch.manual_seed(0)
 st = channel_spatial_stage(512).to(dev)
+if len(sys.argv) > 3:
+    st.gemm = sys.argv[3]           # bf16x3 | bf16x6 | f32 (dhd_sfa_weights.gemm, per call)
 x = torch.randn(b, 512, 200, 200, device=dev, requires_grad=True)
 g = torch.randn(b, 256, 200, 200, device=dev)
 for it in range(n + 2):
