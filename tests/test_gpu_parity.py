@@ -779,6 +779,39 @@ def test_accelerate_caches_only_what_is_static(gpu):
         mghs_op.set_deterministic(False)
 
 
+def test_static_lift_full_size_is_bit_identical_to_a_full_lift(gpu):
+    """dhd_mghs_lift_static at the full DHD-S size, B = 4: after one full lift, three frames with new height maps (new
+    bands) and new depth / context values each redo only the band grids' grouping; in deterministic mode the four pooled
+    tensors are bit-identical to those of a full dhd_mghs_lift on a fresh workspace, frame by frame."""
+    from dhd_amd import mghs_op
+    from oracle import mghs_oracle as O
+    cfg = syn.dhd_s_config()
+    B, N = 4, 6
+    calib_np = syn.make_calibration(401, B, N, cfg['input_size'])
+    axes = O.frustum_axes(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    grids = [mghs_op.grid_from_cfg(g) for g in grid_cfgs(cfg)]
+    plan = mghs_op.Plan(B, N, 44, 16, 44, 64, grids, deterministic=True)
+    calib, keep = device_calib(calib_np, axes, gpu)
+    ws_static = plan.new_workspace(gpu, private_scratch=True)
+    kept = None
+    with torch.no_grad():
+        for frame in range(4):
+            depth, feat, hidx = syn.lift_inputs(410 + 7 * frame, B, N, 44, 16, 44, 64, 65)
+            height = T(syn.height_probs_from_index(hidx, 65), gpu)
+            a = mghs_op.mghs_lift_pool(plan, calib, height, cfg['height_range'], cfg['mask_range'], T(depth, gpu), T(feat, gpu),
+                                       ws_static, static=frame > 0)
+            b = mghs_op.mghs_lift_pool(plan, calib, height, cfg['height_range'], cfg['mask_range'], T(depth, gpu), T(feat, gpu),
+                                       plan.new_workspace(gpu, private_scratch=True))
+            for k, (x, y) in enumerate(zip(a, b)):
+                assert torch.equal(x, y), (frame, k)
+            k_now, _ = mghs_op.stats(plan, ws_static)
+            if frame == 0:
+                kept = k_now
+                assert kept[0] > 400000
+            else:
+                assert k_now[0] == kept[0] and k_now[1:] != kept[1:]      # grid 0's grouping is the static part, the bands moved
+
+
 def test_mghs_step_is_graph_capturable(gpu):
     """prepare + forward + backward are plain launches / async memsets on the caller's stream: the
     whole view transform can be captured into a HIP graph and replayed on new inputs."""
@@ -1253,7 +1286,7 @@ def test_batchnorm2d_training_vs_torch(gpu, dtype, tol, shape):
 # SFA stage under nn.SyncBatchNorm (DHD-L.py:308-311 SyncbnControlHook): the phased operator, two ranks sharing cuda:0 over gloo
 # ---------------------------------------------------------------------------------------------
 
-def _syncbn_stage_worker(rank, world, port, q, gemm):
+def _syncbn_stage_worker(rank, world, port, q, gemm, sizes=(2, 2)):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1265,7 +1298,8 @@ def _syncbn_stage_worker(rank, world, port, q, gemm):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
-    c, h, w, per = 128, 20, 28, 2
+    c, h, w = 128, 20, 28
+    lo, hi = sum(sizes[:rank]), sum(sizes[:rank + 1])        # this rank's samples (the ranks may hold different numbers)
     torch.manual_seed(5)
     st = channel_spatial_stage(2 * c)
     with torch.no_grad():
@@ -1275,12 +1309,12 @@ def _syncbn_stage_worker(rank, world, port, q, gemm):
     st = torch.nn.SyncBatchNorm.convert_sync_batchnorm(st).to(dev).train()
     st.gemm = gemm
     g = torch.Generator().manual_seed(77)
-    x_all = torch.randn(world * per, 2 * c, h, w, generator=g) * 0.7 + 0.1
-    w_all = torch.randn(world * per, c, h, w, generator=g)
-    x = x_all[rank * per:(rank + 1) * per].to(dev).requires_grad_()
+    x_all = torch.randn(sum(sizes), 2 * c, h, w, generator=g) * 0.7 + 0.1
+    w_all = torch.randn(sum(sizes), c, h, w, generator=g)
+    x = x_all[lo:hi].to(dev).requires_grad_()
     assert needs_cross_rank_statistics(st) and fused_stage_supported(st, x)
     out = st(x)                                    # dhd_sfa_stage_forward_phase x 3, two all-reduces of 2C + 1 doubles
-    (out * w_all[rank * per:(rank + 1) * per].to(dev)).sum().backward()
+    (out * w_all[lo:hi].to(dev)).sum().backward()
     # plain numpy data: tensors would travel as file descriptors of this process, which is gone by the time the parent reads
     res = dict(out=out.detach().cpu().numpy(), gx=x.grad.cpu().numpy(), grads={k: p.grad.cpu().numpy() for k, p in st.named_parameters()},
                buffers={k: v.cpu().numpy() for k, v in st.named_buffers()})
@@ -1289,12 +1323,12 @@ def _syncbn_stage_worker(rank, world, port, q, gemm):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('gemm', ['bf16x6', 'bf16x3'])
-def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm):
+@pytest.mark.parametrize('gemm,sizes', [('bf16x6', (2, 2)), ('bf16x3', (2, 2)), ('bf16x6', (3, 1))])
+def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm, sizes):
     """core/hook/syncbncontrol.py:18-32 converts every BatchNorm at epoch 0 of DHD-L.py (:308-311), the stage's two included.
     The fused operator then runs cut at its statistics points (dhd_sfa_stage_forward_phase / backward_phase) with the
-    (2C + 1) float64 sums all-reduced in between.  Two ranks (sharing the GPU over gloo) with two samples each must
-    reproduce plain PyTorch with ordinary BatchNorm on the four samples in one process -- which is what SyncBatchNorm
+    (2C + 1) float64 sums all-reduced in between.  Two ranks (sharing the GPU over gloo) with two samples each -- or
+    three and one: the counts travel with the sums -- must reproduce plain PyTorch with ordinary BatchNorm on the four samples in one process -- which is what SyncBatchNorm
     means: outputs and input gradients per rank, parameter gradients as the sum of the ranks' contributions (the loss is a
     sum over samples), running statistics identical on both ranks and equal to the full-batch ones."""
     import socket
@@ -1307,7 +1341,7 @@ def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm):
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_syncbn_stage_worker, args=(r, world, port, q, gemm)) for r in range(world)]
+    procs = [ctx.Process(target=_syncbn_stage_worker, args=(r, world, port, q, gemm, sizes)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))
@@ -1315,7 +1349,7 @@ def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm):
         p.join(120)
         assert p.exitcode == 0
     # the reference: ordinary modules, the whole batch, float64
-    c, h, w, per = 128, 20, 28, 2
+    c, h, w = 128, 20, 28
     torch.manual_seed(5)
     ref = channel_spatial_stage(2 * c)
     with torch.no_grad():
@@ -1329,8 +1363,8 @@ def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm):
     ref.spacial_leanring = plain
     ref = ref.double().train()
     g = torch.Generator().manual_seed(77)
-    x_all = (torch.randn(world * per, 2 * c, h, w, generator=g) * 0.7 + 0.1).double().requires_grad_()
-    w_all = torch.randn(world * per, c, h, w, generator=g).double()
+    x_all = (torch.randn(sum(sizes), 2 * c, h, w, generator=g) * 0.7 + 0.1).double().requires_grad_()
+    w_all = torch.randn(sum(sizes), c, h, w, generator=g).double()
     a = ref.fc(x_all.mean(dim=(2, 3)))[..., None, None]
     xb, xv = x_all[:, :c], x_all[:, c:]
     gate = torch.sigmoid(ref.spacial_leanring(a * xb + (1 - a) * xv))
@@ -1338,7 +1372,7 @@ def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm):
     (out * w_all).sum().backward()
     f = GEMM_MODES[gemm]
     for r in range(world):
-        sl = slice(r * per, (r + 1) * per)
+        sl = slice(sum(sizes[:r]), sum(sizes[:r + 1]))
         np.testing.assert_allclose(res[r]['out'], out[sl].detach().numpy(), atol=2e-5 * min(f, 5.0), rtol=1e-4)
         gref = x_all.grad[sl].numpy()
         np.testing.assert_allclose(res[r]['gx'], gref, atol=1e-4 * f * np.abs(gref).max(), rtol=1e-3)
