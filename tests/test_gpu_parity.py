@@ -779,6 +779,30 @@ def test_accelerate_caches_only_what_is_static(gpu):
         mghs_op.set_deterministic(False)
 
 
+def test_batch_of_eight_equals_two_batches_of_four(gpu):
+    """B = 8 at the full DHD-S size: 5.44 M voxel counters = 2 656 scan chunks, more workgroups than the chip holds at once
+    (the single-pass scan waits only for lower-numbered chunks, which are dispatched first).  Samples are independent, so
+    in deterministic mode the pooled tensors and both gradients of the batch of eight are bit-identical to those of its
+    two halves run as batches of four."""
+    from dhd_amd import mghs_op
+    cfg = syn.dhd_s_config()
+    calib_np = syn.make_calibration(501, 8, 6, cfg['input_size'])
+    depth, feat, hidx = syn.lift_inputs(502, 8, 6, 44, 16, 44, 64, 65)
+    mghs_op.set_deterministic(True)
+    try:
+        outs8, grads8, _ = run_fused(gpu, cfg, calib_np, depth, feat, hidx, weights_seed=None)
+        halves = []
+        for h in range(2):
+            sl, bn = slice(4 * h, 4 * h + 4), slice(24 * h, 24 * h + 24)
+            o, _, _ = run_fused(gpu, cfg, [a[sl] for a in calib_np], depth[bn], feat[bn], hidx[bn])
+            halves.append(o)
+    finally:
+        mghs_op.set_deterministic(False)
+    for k in range(4):
+        assert np.array_equal(outs8[k][:4], halves[0][k]) and np.array_equal(outs8[k][4:], halves[1][k]), k
+    assert np.count_nonzero(outs8[0]) > 1000000
+
+
 def test_static_lift_full_size_is_bit_identical_to_a_full_lift(gpu):
     """dhd_mghs_lift_static at the full DHD-S size, B = 4: after one full lift, three frames with new height maps (new
     bands) and new depth / context values each redo only the band grids' grouping; in deterministic mode the four pooled
