@@ -200,12 +200,65 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_fast_kernel(int c, int
 
 // ---------------------------------------------------------------------------------------------------------------
 // Sub-wave forms for C = 4 L, L a power of two (C = 64: L = 16).  The operator is a gather over many short intervals
-// (DHD-S, B = 4: 81 k voxels of 7.8 points on average; 17 k pixels of 37 points): a whole wave per interval leaves the
-// kernel at the latency of its dependent chain index -> depth -> row -> store with ~10 rounds of resident waves.  Here L
-// lanes serve one interval (a lane = four channels, 16-byte accesses, a 4 C-byte row = one contiguous piece per group)
-// and a wave carries 64 / L intervals side by side: 4x fewer waves, 4x more gathers in flight per wave.
+// (DHD-S, B = 4: 81 k voxels of 7.8 points on average, the longest 256; 17 k pixels of 37 points): a whole wave per
+// interval leaves the kernel at the latency of its dependent chain index -> depth -> row -> store with ~10 rounds of
+// resident waves.  Here L lanes serve one interval (a lane = four channels, 16-byte accesses, a 4 C-byte row = one contiguous
+// piece per group) and a wave carries 64 / L intervals side by side: 4x fewer waves, 4x more gathers in flight per wave.
+//
+// Round 3: the kernel's time was the serial chain of its LONGEST interval (a batch of L points = three dependent round
+// trips: index words -> depth value / row address -> row; a 256-point voxel = 16 batches one after the other = 40 us,
+// whatever the other 81 k intervals did).  Now (a) the index words and depth values of kChunk batches are requested
+// together before the first row gather (2 round trips per kChunk * L points instead of 2 per L), and (b) an interval
+// longer than kChunk * L points is not walked by its own L lanes: after the short ones the whole wave takes it, every
+// group a quarter of each 64-point batch, and the groups' partial sums are added in a fixed order (deterministic).
 // ---------------------------------------------------------------------------------------------------------------
 using pf4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kChunk = 4;   // batches of L points whose index words are in flight together
+
+// Sum over the L lanes of a group, result in every lane.  L = 16 is one DPP row: two rotations and two quad
+// permutations on the VALU instead of four trips through the LDS crossbar.
+template <int L>
+__device__ __forceinline__ float lanes_sum(float v) {
+  if constexpr (L == 16) {
+    v = dpp_add<0x128, 0xf>(v);   // row_ror:8
+    v = dpp_add<0x124, 0xf>(v);   // row_ror:4
+    v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    return v;
+  } else {
+#pragma unroll
+    for (int m = 1; m < L; m <<= 1) v += __shfl_xor(v, m, DHD_WAVE);
+    return v;
+  }
+}
+
+// acc += sum over the group's rows of the chunk: batch b, row k of this group sits in source lane grp * L + k of rf[b] /
+// dv[b]; rows k >= cnt[b] do not exist (cnt is uniform within the group, dv is 0 there).
+template <int L>
+__device__ __forceinline__ pf4 fwd_chunk(pf4 acc, const int (&rf)[kChunk], const float (&dv)[kChunk], const int (&cnt)[kChunk],
+                                         const pf4* __restrict__ feat, int grp, int cl) {
+  constexpr int U = L < 8 ? L : 8;
+#pragma unroll
+  for (int b = 0; b < kChunk; ++b) {
+    if (!__any(cnt[b] > 0)) break;       // wave-uniform: batches are filled in order
+#pragma unroll
+    for (int k0 = 0; k0 < L; k0 += U) {
+      pf4 f[U];
+      float d[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u;
+        const int q = __shfl(rf[b], grp * L + k, DHD_WAVE);
+        d[u] = __shfl(dv[b], grp * L + k, DHD_WAVE);
+        f[u] = k < cnt[b] ? feat[(size_t)q * L + cl] : pf4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += f[u] * d[u];
+    }
+  }
+  return acc;
+}
 
 template <int L>
 __global__ __launch_bounds__(kBlock) void bev_pool_v2_fwd_vec_kernel(int n_intervals, const float* __restrict__ depth,
@@ -220,33 +273,60 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_fwd_vec_kernel(int n_inter
   const bool valid = iv < n_intervals;
   const int start = valid ? interval_starts[iv] : 0;
   const int len = valid ? interval_lengths[iv] : 0;
-  const int vox = valid ? ranks_bev[start] : 0;     // requested with the first indices, not after the gathers
+  const int vox = (valid && len > 0) ? ranks_bev[start] : 0;     // requested with the first indices, not after the gathers
+  const bool is_long = G > 1 && len > kChunk * L;
+  const int own = is_long ? 0 : len;               // points this group walks by itself
   pf4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int s0 = 0; __any(s0 < len); s0 += L) {
-    const int cnt = min(L, len - s0);              // group-uniform, <= 0 when this group is done
-    int rf = 0;
-    float dv = 0.f;
-    if (cl < cnt) {
-      rf = ranks_feat[start + s0 + cl];
-      dv = depth[ranks_depth[start + s0 + cl]];
+  for (int s0 = 0; __any(s0 < own); s0 += kChunk * L) {
+    int rf[kChunk], rd[kChunk], cnt[kChunk];
+    float dv[kChunk];
+#pragma unroll
+    for (int b = 0; b < kChunk; ++b) {
+      cnt[b] = min(L, own - s0 - b * L);           // group-uniform, <= 0 when the group has no such batch
+      const bool live = cl < cnt[b];
+      rf[b] = live ? ranks_feat[start + s0 + b * L + cl] : 0;
+      rd[b] = live ? ranks_depth[start + s0 + b * L + cl] : -1;
     }
-    constexpr int U = L < 8 ? L : 8;
 #pragma unroll
-    for (int k0 = 0; k0 < L; k0 += U) {
-      pf4 f[U];
-      float d[U];
+    for (int b = 0; b < kChunk; ++b) dv[b] = rd[b] >= 0 ? depth[rd[b]] : 0.f;
+    acc = fwd_chunk<L>(acc, rf, dv, cnt, feat, grp, cl);
+  }
+  if (valid && !is_long && len > 0) out[(size_t)vox * L + cl] = acc;
+  if constexpr (G > 1) {
+    // the long intervals of this wave, one after the other, all 64 lanes on each
+    unsigned long long todo = __ballot(is_long && cl == 0);
+    while (todo) {
+      const int src = __builtin_ctzll(todo);       // lane 0 of the owning group
+      todo &= todo - 1;
+      const int s = __builtin_amdgcn_readlane(start, src), n = __builtin_amdgcn_readlane(len, src);
+      const int v = __builtin_amdgcn_readlane(vox, src);
+      pf4 part = {0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < n; s0 += kChunk * DHD_WAVE) {
+        int rf[kChunk], rd[kChunk], cnt[kChunk];
+        float dv[kChunk];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = k0 + u;
-        const int q = __shfl(rf, grp * L + k, DHD_WAVE);
-        d[u] = __shfl(dv, grp * L + k, DHD_WAVE);   // 0 beyond cnt
-        f[u] = k < cnt ? feat[(size_t)q * L + cl] : acc * 0.f;
+        for (int b = 0; b < kChunk; ++b) {
+          const int left = n - s0 - b * DHD_WAVE;  // points of this 64-point batch and beyond
+          cnt[b] = min(L, left - grp * L);
+          const bool live = lane < left;
+          rf[b] = live ? ranks_feat[s + s0 + b * DHD_WAVE + lane] : 0;
+          rd[b] = live ? ranks_depth[s + s0 + b * DHD_WAVE + lane] : -1;
+        }
+#pragma unroll
+        for (int b = 0; b < kChunk; ++b) dv[b] = rd[b] >= 0 ? depth[rd[b]] : 0.f;
+        part = fwd_chunk<L>(part, rf, dv, cnt, feat, grp, cl);
       }
+      // groups' partial sums, fixed order: ((g0 + g1) + (g2 + g3)) for G = 4
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc += f[u] * d[u];
+      for (int m = L; m < DHD_WAVE; m <<= 1) {
+        part.x += __shfl_xor(part.x, m, DHD_WAVE);
+        part.y += __shfl_xor(part.y, m, DHD_WAVE);
+        part.z += __shfl_xor(part.z, m, DHD_WAVE);
+        part.w += __shfl_xor(part.w, m, DHD_WAVE);
+      }
+      if (grp == 0) out[(size_t)v * L + cl] = part;
     }
   }
-  if (valid) out[(size_t)vox * L + cl] = acc;
 }
 
 template <int L>
@@ -267,38 +347,45 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_vec_kernel(int n_inter
   const int pix = valid ? ranks_feat[start] : 0;   // every point of the interval shares the pixel (bev_pool.py:47-57)
   const pf4 fv = valid ? feat[(size_t)pix * L + cl] : pf4{0.f, 0.f, 0.f, 0.f};
   pf4 facc = {0.f, 0.f, 0.f, 0.f};
-  for (int s0 = 0; __any(s0 < len); s0 += L) {
-    const int cnt = min(L, len - s0);
-    int rb = 0, rd = 0;
-    float dv = 0.f;
-    if (cl < cnt) {
-      rb = ranks_bev[start + s0 + cl];
-      rd = ranks_depth[start + s0 + cl];
-      dv = depth[rd];
+  // a pixel's points (<= D per grid slice: 44 or 88) in chunks of kChunk batches whose index words and depth values are
+  // requested together (round 2: per batch of L points, i.e. three dependent round trips per batch)
+  for (int s0 = 0; __any(s0 < len); s0 += kChunk * L) {
+    int rb[kChunk], rd[kChunk], cnt[kChunk];
+    float dv[kChunk];
+#pragma unroll
+    for (int b = 0; b < kChunk; ++b) {
+      cnt[b] = min(L, len - s0 - b * L);
+      const bool live = cl < cnt[b];
+      rb[b] = live ? ranks_bev[start + s0 + b * L + cl] : 0;
+      rd[b] = live ? ranks_depth[start + s0 + b * L + cl] : -1;
     }
-    float mine = 0.f;
-    constexpr int U = L < 8 ? L : 8;
 #pragma unroll
-    for (int k0 = 0; k0 < L; k0 += U) {
-      pf4 g[U];
-      float d[U];
+    for (int b = 0; b < kChunk; ++b) dv[b] = rd[b] >= 0 ? depth[rd[b]] : 0.f;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = k0 + u;
-        const int vox = __shfl(rb, grp * L + k, DHD_WAVE);
-        d[u] = __shfl(dv, grp * L + k, DHD_WAVE);
-        g[u] = k < cnt ? out_grad[(size_t)vox * L + cl] : facc * 0.f;
+    for (int b = 0; b < kChunk; ++b) {
+      if (!__any(cnt[b] > 0)) break;
+      float mine = 0.f;
+      constexpr int U = L < 8 ? L : 8;
+#pragma unroll
+      for (int k0 = 0; k0 < L; k0 += U) {
+        pf4 g[U];
+        float d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = k0 + u;
+          const int vox = __shfl(rb[b], grp * L + k, DHD_WAVE);
+          d[u] = __shfl(dv[b], grp * L + k, DHD_WAVE);
+          g[u] = k < cnt[b] ? out_grad[(size_t)vox * L + cl] : pf4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          facc += g[u] * d[u];
+          const float part = lanes_sum<L>((g[u].x * fv.x + g[u].y * fv.y) + (g[u].z * fv.z + g[u].w * fv.w));
+          if (cl == k0 + u) mine = part;
+        }
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        facc += g[u] * d[u];
-        float part = (g[u].x * fv.x + g[u].y * fv.y) + (g[u].z * fv.z + g[u].w * fv.w);
-#pragma unroll
-        for (int m = 1; m < L; m <<= 1) part += __shfl_xor(part, m, DHD_WAVE);   // sum over the group's L lanes
-        if (cl == k0 + u) mine = part;
-      }
+      if (rd[b] >= 0) depth_grad[rd[b]] = mine;       // one writer per point (:104-106)
     }
-    if (cl < cnt) depth_grad[rd] = mine;             // one writer per point (:104-106)
   }
   if (valid) feat_grad[(size_t)pix * L + cl] = facc;  // one writer per pixel (:120-121)
 }

@@ -87,6 +87,39 @@ def test_bev_pool_v2_operator_vs_oracle(gpu, channels):
     np.testing.assert_allclose(ft.grad.cpu().numpy(), fg, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('channels', [4, 8, 64, 128, 256, 20])
+def test_bev_pool_v2_operator_ragged_intervals(gpu, channels):
+    """Interval lengths around every branch of the sub-wave kernels (C = 4 L: a group's own walk covers 4 L points, longer
+    intervals are taken by the whole wave in 64-point batches, 256 per chunk): 1, L, 4L, 4L+1, 63..65, 255..257, 1000, in
+    shuffled order, points in scattered pixels; forward and both gradients against the oracle."""
+    from dhd_amd import bev_pool_v2
+    from oracle import mghs_oracle as O
+    rng = np.random.default_rng(channels)
+    lens = [1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1000] + [1] * 40 + [7] * 40
+    lens = np.array(lens, dtype=np.int32)[rng.permutation(len(lens) + 0)]
+    B, N, D, fh, fw = 1, 2, 44, 8, 22
+    n_pts = int(lens.sum())
+    assert n_pts <= B * N * D * fh * fw
+    rd = rng.permutation(B * N * D * fh * fw)[:n_pts].astype(np.int32)          # distinct points
+    rf = (rd // (D * fh * fw)) * (fh * fw) + rd % (fh * fw)                      # the point's pixel (b, n, h, w)
+    st = (np.cumsum(lens) - lens).astype(np.int32)
+    vox = rng.permutation(40 * 40)[:len(lens)].astype(np.int32)
+    rb = np.repeat(vox, lens).astype(np.int32)
+    depth = syn.hash_signed(70 + channels, (B, N, D, fh, fw))
+    feat = syn.hash_signed(71 + channels, (B, N, fh, fw, channels))
+    shape = (B, 1, 40, 40, channels)
+    ref = O.bev_pool_v2(depth, feat, rd, rf.astype(np.int32), rb, shape, st, lens)
+    dt, ft = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+    out = bev_pool_v2(dt, ft, T(rd, gpu), T(rf.astype(np.int32), gpu), T(rb, gpu), shape, T(st, gpu), T(lens, gpu))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=3e-5, rtol=1e-5)
+    w = syn.hash_signed(72, ref.shape)
+    (out * T(w, gpu)).sum().backward()
+    og = np.ascontiguousarray(w.transpose(0, 2, 3, 4, 1))
+    dg, fg = O.bev_pool_v2_backward(og, depth, feat, rd, rf.astype(np.int32), rb)
+    np.testing.assert_allclose(dt.grad.cpu().numpy(), dg, atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(ft.grad.cpu().numpy(), fg, atol=3e-5, rtol=1e-5)
+
+
 def test_bev_pool_v2_regroup_vs_argsort(gpu):
     """dhd_bev_pool_v2_regroup (device counting sort by feature pixel, ascending ranks_depth inside a pixel, one interval per
     pixel incl. empty ones) against the reference's formulation (bev_pool.py:47-57: argsort by ranks_feat, run-length scan) on
