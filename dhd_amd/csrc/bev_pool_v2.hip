@@ -10,6 +10,8 @@
 //   backward: one wave per pixel interval instead of one THREAD per pixel (:87-122), so the
 //             depth-gradient dot product is a wave reduction and the feature gradient a
 //             per-lane accumulator; out_grad rows are read as coalesced 4*C-byte segments.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -216,6 +218,15 @@ using pf4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kChunk = 4;   // batches of L points whose index words are in flight together
 
+// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8); the grid is padded to a multiple of 8 and
+// every XCD takes a contiguous eighth of the wave positions, so that neighbouring intervals (voxels / pixels that
+// gather the same rows) meet in one L2 instead of being fetched into all eight.
+__device__ __forceinline__ int xcd_contiguous_block() {
+  const int per = gridDim.x >> 3;
+  return (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+}
+static inline int xcd_padded_blocks(int n_blocks) { return (n_blocks + 7) / 8 * 8; }
+
 // Sum over the L lanes of a group, result in every lane.  L = 16 is one DPP row: two rotations and two quad
 // permutations on the VALU instead of four trips through the LDS crossbar.
 template <int L>
@@ -233,35 +244,62 @@ __device__ __forceinline__ float lanes_sum(float v) {
   }
 }
 
+// Value held by lane k of the caller's own group of L lanes.  L = 16 is one DPP row: row_share:k is a VALU move
+// (the general form goes through the LDS crossbar, two of them per gathered row made the kernels issue-bound).
+template <int L, int K>
+__device__ __forceinline__ int group_lane_i(int v, int grp) {
+  if constexpr (L == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, false);
+  else return __shfl(v, grp * L + K, DHD_WAVE);
+}
+template <int L, int K>
+__device__ __forceinline__ float group_lane_f(float v, int grp) {
+  return __int_as_float(group_lane_i<L, K>(__float_as_int(v), grp));
+}
+
+// compile-time loop: body(std::integral_constant<int, I>) for I in [0, N)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
 // acc += sum over the group's rows of the chunk: batch b, row k of this group sits in source lane grp * L + k of rf[b] /
-// dv[b]; rows k >= cnt[b] do not exist (cnt is uniform within the group, dv is 0 there).
-template <int L>
+// dv[b]; rows k >= cnt[b] do not exist (cnt is uniform within the group, dv is 0 there).  The rows are requested before
+// the depth values are looked at: depth[] (asked for by the caller right before) and the rows travel together.
+template <int L, int R>
 __device__ __forceinline__ pf4 fwd_chunk(pf4 acc, const int (&rf)[kChunk], const float (&dv)[kChunk], const int (&cnt)[kChunk],
                                          const pf4* __restrict__ feat, int grp, int cl) {
-  constexpr int U = L < 8 ? L : 8;
+  constexpr int U = L < R ? L : R;
 #pragma unroll
   for (int b = 0; b < kChunk; ++b) {
     if (!__any(cnt[b] > 0)) break;       // wave-uniform: batches are filled in order
-#pragma unroll
-    for (int k0 = 0; k0 < L; k0 += U) {
+    bool done = false;
+    static_for<L / U>([&](auto ks) {
+      constexpr int k0 = decltype(ks)::value * U;
+      if (done || (k0 > 0 && !__any(cnt[b] > k0))) { done = true; return; }
       pf4 f[U];
       float d[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = k0 + u;
-        const int q = __shfl(rf[b], grp * L + k, DHD_WAVE);
-        d[u] = __shfl(dv[b], grp * L + k, DHD_WAVE);
-        f[u] = k < cnt[b] ? feat[(size_t)q * L + cl] : pf4{0.f, 0.f, 0.f, 0.f};
-      }
+      static_for<U>([&](auto us) {
+        constexpr int u = decltype(us)::value;
+        const int q = group_lane_i<L, k0 + u>(rf[b], grp);
+        f[u] = k0 + u < cnt[b] ? feat[(size_t)q * L + cl] : pf4{0.f, 0.f, 0.f, 0.f};
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<U>([&](auto us) {
+        constexpr int u = decltype(us)::value;
+        d[u] = group_lane_f<L, k0 + u>(dv[b], grp);
+      });
 #pragma unroll
       for (int u = 0; u < U; ++u) acc += f[u] * d[u];
-    }
+    });
   }
   return acc;
 }
 
-template <int L>
-__global__ __launch_bounds__(kBlock) void bev_pool_v2_fwd_vec_kernel(int n_intervals, const float* __restrict__ depth,
+template <int L, int R, int WPS>
+__global__ __launch_bounds__(kBlock, WPS) void bev_pool_v2_fwd_vec_kernel(int n_intervals, const float* __restrict__ depth,
                                                                       const pf4* __restrict__ feat, const int* __restrict__ ranks_depth,
                                                                       const int* __restrict__ ranks_feat,
                                                                       const int* __restrict__ ranks_bev,
@@ -269,7 +307,17 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_fwd_vec_kernel(int n_inter
                                                                       const int* __restrict__ interval_lengths, pf4* __restrict__ out) {
   constexpr int G = DHD_WAVE / L;
   const int lane = threadIdx.x & 63, grp = lane / L, cl = lane % L;
-  const int iv = (blockIdx.x * kWaves + (threadIdx.x >> 6)) * G + grp;
+  // Interval of this group.  The lists are sorted by voxel, so long intervals (voxels next to a camera: up to ~300
+  // points against a mean of 8) come in clusters; G consecutive intervals per wave put four of them into one wave, whose
+  // serial walk then was the kernel's time.  An XCD's contiguous range of wx * G intervals is cut into G sub-ranges,
+  // group g walks sub-range g, rotated by g * (wx / 5) positions so that the same place of every sample (the rigs
+  // are alike) does not meet in one wave either.
+  const int wx = (gridDim.x >> 3) * kWaves;                        // waves per XCD
+  const int wq = xcd_contiguous_block() * kWaves + (threadIdx.x >> 6);
+  const int xcd = wq / wx, j = wq - xcd * wx;
+  int jr = j + grp * (wx / 5 + 1);
+  jr -= (jr / wx) * wx;
+  const int iv = G > 1 ? (xcd * G + grp) * wx + jr : wq;
   const bool valid = iv < n_intervals;
   const int start = valid ? interval_starts[iv] : 0;
   const int len = valid ? interval_lengths[iv] : 0;
@@ -289,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_fwd_vec_kernel(int n_inter
     }
 #pragma unroll
     for (int b = 0; b < kChunk; ++b) dv[b] = rd[b] >= 0 ? depth[rd[b]] : 0.f;
-    acc = fwd_chunk<L>(acc, rf, dv, cnt, feat, grp, cl);
+    acc = fwd_chunk<L, R>(acc, rf, dv, cnt, feat, grp, cl);
   }
   if (valid && !is_long && len > 0) out[(size_t)vox * L + cl] = acc;
   if constexpr (G > 1) {
@@ -314,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_fwd_vec_kernel(int n_inter
         }
 #pragma unroll
         for (int b = 0; b < kChunk; ++b) dv[b] = rd[b] >= 0 ? depth[rd[b]] : 0.f;
-        part = fwd_chunk<L>(part, rf, dv, cnt, feat, grp, cl);
+        part = fwd_chunk<L, R>(part, rf, dv, cnt, feat, grp, cl);
       }
       // groups' partial sums, fixed order: ((g0 + g1) + (g2 + g3)) for G = 4
 #pragma unroll
@@ -329,8 +377,8 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_fwd_vec_kernel(int n_inter
   }
 }
 
-template <int L>
-__global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_vec_kernel(int n_intervals, const pf4* __restrict__ out_grad,
+template <int L, int R, int WPS>
+__global__ __launch_bounds__(kBlock, WPS) void bev_pool_v2_bwd_vec_kernel(int n_intervals, const pf4* __restrict__ out_grad,
                                                                       const float* __restrict__ depth, const pf4* __restrict__ feat,
                                                                       const int* __restrict__ ranks_depth,
                                                                       const int* __restrict__ ranks_feat,
@@ -340,7 +388,8 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_vec_kernel(int n_inter
                                                                       float* __restrict__ depth_grad, pf4* __restrict__ feat_grad) {
   constexpr int G = DHD_WAVE / L;
   const int lane = threadIdx.x & 63, grp = lane / L, cl = lane % L;
-  const int iv = (blockIdx.x * kWaves + (threadIdx.x >> 6)) * G + grp;
+  // consecutive pixels per wave and per XCD: neighbouring pixels gather the same out_grad rows
+  const int iv = (xcd_contiguous_block() * kWaves + (threadIdx.x >> 6)) * G + grp;
   const int len = iv < n_intervals ? interval_lengths[iv] : 0;
   const bool valid = len > 0;                      // empty intervals (and the padding of the last wave) write nothing
   const int start = valid ? interval_starts[iv] : 0;
@@ -365,25 +414,30 @@ __global__ __launch_bounds__(kBlock) void bev_pool_v2_bwd_vec_kernel(int n_inter
     for (int b = 0; b < kChunk; ++b) {
       if (!__any(cnt[b] > 0)) break;
       float mine = 0.f;
-      constexpr int U = L < 8 ? L : 8;
-#pragma unroll
-      for (int k0 = 0; k0 < L; k0 += U) {
+      constexpr int U = L < R ? L : R;
+      bool done = false;
+      static_for<L / U>([&](auto ks) {
+        constexpr int k0 = decltype(ks)::value * U;
+        if (done || (k0 > 0 && !__any(cnt[b] > k0))) { done = true; return; }
         pf4 g[U];
         float d[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int k = k0 + u;
-          const int vox = __shfl(rb[b], grp * L + k, DHD_WAVE);
-          d[u] = __shfl(dv[b], grp * L + k, DHD_WAVE);
-          g[u] = k < cnt[b] ? out_grad[(size_t)vox * L + cl] : pf4{0.f, 0.f, 0.f, 0.f};
-        }
+        static_for<U>([&](auto us) {
+          constexpr int u = decltype(us)::value;
+          const int vox = group_lane_i<L, k0 + u>(rb[b], grp);
+          g[u] = k0 + u < cnt[b] ? out_grad[(size_t)vox * L + cl] : pf4{0.f, 0.f, 0.f, 0.f};
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<U>([&](auto us) {
+          constexpr int u = decltype(us)::value;
+          d[u] = group_lane_f<L, k0 + u>(dv[b], grp);
+        });
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           facc += g[u] * d[u];
           const float part = lanes_sum<L>((g[u].x * fv.x + g[u].y * fv.y) + (g[u].z * fv.z + g[u].w * fv.w));
           if (cl == k0 + u) mine = part;
         }
-      }
+      });
       if (rd[b] >= 0) depth_grad[rd[b]] = mine;       // one writer per point (:104-106)
     }
   }
@@ -488,8 +542,10 @@ int dhd_bev_pool_v2_forward(const float* depth, const float* feat, float* out, c
   if (!depth || !feat || !out || !ranks_depth || !ranks_feat || !ranks_bev || !interval_lengths || !interval_starts)
     return DHD_EINVAL;
   const int lv = (((uintptr_t)feat | (uintptr_t)out) & 15) == 0 ? vec_lanes(c) : 0;
-#define DHD_FWD_VEC(LL)                                                                                                       \
-  hipLaunchKernelGGL(bev_pool_v2_fwd_vec_kernel<LL>, dim3(dhd_cdiv(n_intervals, kWaves * (DHD_WAVE / LL))), dim3(kBlock), 0, \
+  // rows in flight per lane / waves per SIMD, measured at DHD-S B = 4: (16, 3) 28.8 us, (8, 6) 25.7, (4, 8) 26.2
+#define DHD_FWD_VEC(LL) DHD_FWD_VEC_R(LL, 8, 6)
+#define DHD_FWD_VEC_R(LL, RR, WW)                                                                                                       \
+  hipLaunchKernelGGL((bev_pool_v2_fwd_vec_kernel<LL, RR, WW>), dim3(xcd_padded_blocks(dhd_cdiv(n_intervals, kWaves * (DHD_WAVE / LL)))), dim3(kBlock), 0, \
                      dhd_stream(stream), n_intervals, depth, reinterpret_cast<const pf4*>(feat), ranks_depth, ranks_feat,    \
                      ranks_bev, interval_starts, interval_lengths, reinterpret_cast<pf4*>(out))
   switch (lv) {
@@ -505,6 +561,7 @@ int dhd_bev_pool_v2_forward(const float* depth, const float* feat, float* out, c
                          n_intervals, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, out);
   }
 #undef DHD_FWD_VEC
+#undef DHD_FWD_VEC_R
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
@@ -560,8 +617,10 @@ int dhd_bev_pool_v2_backward(const float* out_grad, float* depth_grad, float* fe
   hipLaunchKernelGGL(KERN, grid, dim3(kBlock), 0, dhd_stream(stream), c, n_intervals_bp, out_grad, depth, feat, ranks_depth, \
                      ranks_feat, ranks_bev, interval_starts_bp, interval_lengths_bp, depth_grad, feat_grad)
   const int lv = (((uintptr_t)feat | (uintptr_t)out_grad | (uintptr_t)feat_grad) & 15) == 0 ? vec_lanes(c) : 0;
-#define DHD_BWD_VEC(LL)                                                                                                       \
-  hipLaunchKernelGGL(bev_pool_v2_bwd_vec_kernel<LL>, dim3(dhd_cdiv(n_intervals_bp, kWaves * (DHD_WAVE / LL))), dim3(kBlock), 0, \
+  // (16, 3) 17.9 us, (8, 5) 16.3, (4, 6) 16.6
+#define DHD_BWD_VEC(LL) DHD_BWD_VEC_R(LL, 8, 5)
+#define DHD_BWD_VEC_R(LL, RR, WW)                                                                                                       \
+  hipLaunchKernelGGL((bev_pool_v2_bwd_vec_kernel<LL, RR, WW>), dim3(xcd_padded_blocks(dhd_cdiv(n_intervals_bp, kWaves * (DHD_WAVE / LL)))), dim3(kBlock), 0, \
                      dhd_stream(stream), n_intervals_bp, reinterpret_cast<const pf4*>(out_grad), depth,                          \
                      reinterpret_cast<const pf4*>(feat), ranks_depth, ranks_feat, ranks_bev, interval_starts_bp,                 \
                      interval_lengths_bp, depth_grad, reinterpret_cast<pf4*>(feat_grad))
@@ -579,6 +638,7 @@ int dhd_bev_pool_v2_backward(const float* out_grad, float* depth_grad, float* fe
       else DHD_BWD(bev_pool_v2_bwd_kernel);
   }
 #undef DHD_BWD_VEC
+#undef DHD_BWD_VEC_R
 #undef DHD_BWD
   DHD_LAUNCH_CHECK();
   return DHD_OK;
