@@ -110,8 +110,11 @@ __global__ __launch_bounds__(kFcBlock) void fc_forward_kernel(const float* __res
                                                               const float* __restrict__ b1, const float* __restrict__ w2,
                                                               const float* __restrict__ b2, float* __restrict__ s,
                                                               float* __restrict__ hbuf, float* __restrict__ a,
-                                                              float* __restrict__ tab, int c, int r, int hw) {
+                                                              float* __restrict__ tab, int c, int r, int hw,
+                                                              int* __restrict__ ticks, int n_ticks) {
   extern __shared__ float sh[];  // s (2c) | h (r)
+  if (blockIdx.x == 0)           // the arrival counters of this call's later kernels (SavedLayout::tick)
+    for (int i = threadIdx.x; i < n_ticks; i += kFcBlock) ticks[i] = 0;
   float* ss = sh;
   float* hh = sh + 2 * c;
   const int b = blockIdx.x, c2 = 2 * c;
@@ -221,15 +224,32 @@ __global__ __launch_bounds__(kEwBlock) void fc_backward_kernel(const float* __re
   }
 }
 
-// parameter gradients of the two Linear layers: one thread per output element
-__global__ __launch_bounds__(kEwBlock) void fc_param_grad_kernel(const float* __restrict__ dpre2, const float* __restrict__ dh,
-                                                                 const float* __restrict__ hbuf, const float* __restrict__ s,
-                                                                 float* __restrict__ gw1, float* __restrict__ gb1,
-                                                                 float* __restrict__ gw2, float* __restrict__ gb2, int nb,
-                                                                 int c, int r) {
+// parameter gradients of the two Linear layers: one thread per output element.  Runs as extra block rows of
+// stage_gx_kernel's launch (both only need fc_backward_kernel's results): one launch less on the stage's critical path.
+struct FcGradJob {
+  const float* dpre2;
+  const float* dh;
+  const float* hbuf;
+  const float* s;
+  float* gw1;
+  float* gb1;
+  float* gw2;
+  float* gb2;
+  int nb, r;
+};
+__device__ __forceinline__ void fc_param_grad_block(const FcGradJob& J, int block, int c) {
+  const float* __restrict__ dpre2 = J.dpre2;
+  const float* __restrict__ dh = J.dh;
+  const float* __restrict__ hbuf = J.hbuf;
+  const float* __restrict__ s = J.s;
+  float* __restrict__ gw1 = J.gw1;
+  float* __restrict__ gb1 = J.gb1;
+  float* __restrict__ gw2 = J.gw2;
+  float* __restrict__ gb2 = J.gb2;
+  const int nb = J.nb, r = J.r;
   const int c2 = 2 * c;
   const int n_w1 = r * c2, n_w2 = c * r;
-  int i = blockIdx.x * kEwBlock + threadIdx.x;
+  int i = block * kEwBlock + threadIdx.x;
   if (i < n_w1) {
     const int j = i / c2, k = i % c2;
     float acc = 0.f;
@@ -353,9 +373,128 @@ __global__ __launch_bounds__(kEwBlock) void bn_eval_coef_kernel(const float* __r
   }
 }
 
+// BatchNorm backward coefficients: dy = c0*g + c1*y + c2 (per channel), dgamma, dbeta, and the
+// gradient of the bias of the convolution feeding this BatchNorm (sum of dy).
+//   training: dy = gamma*rstd*(g - S1/n - (y-mu)*rstd^2*S2/n);  eval: dy = gamma*rstd*g
+// COHERENT: the partial sums were written by other workgroups of the SAME launch (see BnTail): read them past the
+// non-coherent cache levels.
+template <bool COHERENT>
+__device__ __forceinline__ void bn_backward_coef_channel(const float* __restrict__ part, int ch, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         int training, float* __restrict__ tab, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, float* __restrict__ dbias, int nb, int c, int hw,
+                                                         double* __restrict__ sums_out, const double* __restrict__ sums_in,
+                                                         const double* __restrict__ loc_fwd, const float* __restrict__ shift) {
+  // Cross-rank statistics (nn.SyncBatchNorm): with `sums_out` only this rank's sums are written, [sum g][C] |
+  // [sum g (y - mu)][C] | count, as doubles; with `sums_in` (their all-reduced values) the input-gradient coefficients use
+  // the global sums and count, while dgamma / dbeta stay this rank's sums (the caller's DDP averages parameter gradients),
+  // and the convolution-bias gradient is this rank's sum of dy, which no longer vanishes rank by rank:
+  //   sum_local dy = c0 S1_local + c1 sum_local y + n_local c2,   sum_local y = loc_fwd[ch] + n_local shift[ch]  (the forward
+  //   sums are those of y - shift).
+  double s1 = 0.0, s2 = 0.0;
+  if (COHERENT) {
+    float v1[16], v2[16];   // in flight together; the sum keeps the order of the plain loop
+    for (int q0 = 0; q0 < nb * kPlaneChunks; q0 += 16) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int q = min(q0 + u, nb * kPlaneChunks - 1);
+        v1[u] = __hip_atomic_load(part + ((size_t)q * 2) * c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v2[u] = __hip_atomic_load(part + ((size_t)q * 2 + 1) * c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (q0 + u < nb * kPlaneChunks) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
+    }
+  } else {
+    for (int q = 0; q < nb * kPlaneChunks; ++q) {
+      s1 += (double)part[((size_t)q * 2) * c + ch];
+      s2 += (double)part[((size_t)q * 2 + 1) * c + ch];
+    }
+  }
+  const double n_loc = (double)nb * (double)hw;
+  if (sums_out) {
+    sums_out[ch] = s1; sums_out[c + ch] = s2;
+    if (ch == 0) sums_out[2 * c] = n_loc;
+    return;
+  }
+  const double n = sums_in ? sums_in[2 * c] : n_loc;
+  const double g1 = sums_in ? sums_in[ch] : s1, g2 = sums_in ? sums_in[c + ch] : s2;
+  const double rs = (double)rstd[ch], mu = (double)mean[ch], ga = (double)gamma[ch];
+  if (dgamma) dgamma[ch] = (float)(rs * s2);
+  if (dbeta) dbeta[ch] = (float)s1;
+  double c0 = ga * rs, c1 = 0.0, c2 = 0.0, db = c0 * s1;
+  if (training) {
+    c1 = -ga * rs * rs * rs * g2 / n;
+    c2 = -ga * rs * g1 / n - c1 * mu;
+    db = 0.0;  // sum of dy over the (whole) batch vanishes identically
+    if (sums_in) db = c0 * s1 + c1 * (loc_fwd[ch] + n_loc * (double)shift[ch]) + n_loc * c2;
+  }
+  if (dbias) dbias[ch] = (float)db;
+  for (int b = 0; b < nb; ++b) {
+    float* t = tab + (size_t)b * 3 * c;
+    t[ch] = (float)c0;
+    t[c + ch] = (float)c1;
+    t[2 * c + ch] = (float)c2;
+  }
+}
+
+__global__ __launch_bounds__(kEwBlock) void bn_backward_coef_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                    int training, float* __restrict__ tab, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, float* __restrict__ dbias, int nb,
+                                                                    int c, int hw, double* __restrict__ sums_out,
+                                                                    const double* __restrict__ sums_in, const double* __restrict__ loc_fwd,
+                                                                    const float* __restrict__ shift) {
+  const int ch = blockIdx.x * kEwBlock + threadIdx.x;
+  if (ch >= c) return;
+  bn_backward_coef_channel<false>(part, ch, gamma, mean, rstd, training, tab, dgamma, dbeta, dbias, nb, c, hw, sums_out, sums_in,
+                                  loc_fwd, shift);
+}
+
+// The coefficient kernel above as the TAIL of the pass that produces its sums (one launch and ~7 us of latency chain less
+// per BatchNorm backward).  The nb * kPlaneChunks workgroups of a channel count themselves in ticket[ch]; the one that
+// arrives last computes the channel's coefficients in the plain kernel's summation order (bit-identical results) and leaves
+// the counter at zero for the next launch.  Visibility across the eight XCDs (their L2s are not coherent with each other
+// inside a kernel): the partial sums are written with agent-scope atomic stores (write-through), their acknowledgement is
+// awaited (s_waitcnt) before the agent-scope ticket, and the last workgroup reads them with agent-scope atomic loads.  NOT
+// with __threadfence(): an agent-scope release writes back the XCD's whole L2, and in a pass that is streaming 160 MB of
+// results through it that made the pass 2.8x (blend2_bn_bwd 134 -> 375 us) and 4.7x (pair_sums 56 -> 262 us) slower.
+// The counters live in the forward's `saved` block, which the forward zeroes.  ticket == nullptr (cross-rank statistics:
+// the sums go through an all-reduce first): plain stores, no tail.
+struct BnTail {
+  int* ticket;
+  const float* gamma;
+  const float* mean;
+  const float* rstd;
+  float* tab;
+  float* dgamma;
+  float* dbeta;
+  float* dbias;
+  int training, nb, hw;
+};
+// thread 0 of a workgroup: its partial sums (row q of `part`) and, if it was the channel's last, the coefficients
+__device__ __forceinline__ void bn_backward_publish(const BnTail& t, float* __restrict__ part, size_t q, int ch, int c, float s1,
+                                                    float s2) {
+  float* p1 = part + (q * 2) * c + ch;
+  float* p2 = part + (q * 2 + 1) * c + ch;
+  if (t.ticket == nullptr) {
+    *p1 = s1;
+    *p2 = s2;
+    return;
+  }
+  __hip_atomic_store(p1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (__hip_atomic_fetch_add(t.ticket + ch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != t.nb * kPlaneChunks - 1) return;
+  __hip_atomic_store(t.ticket + ch, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bn_backward_coef_channel<true>(part, ch, t.gamma, t.mean, t.rstd, t.training, t.tab, t.dgamma, t.dbeta, t.dbias, t.nb, c, t.hw,
+                                 nullptr, nullptr, nullptr, nullptr);
+}
+
 // sums for BatchNorm backward: S1 = sum g, S2 = sum g*(y - mean).  part: [(b*chunks+chunk)][2][c]
 __global__ __launch_bounds__(kEwBlock) void pair_sums_kernel(const float* __restrict__ g, const float* __restrict__ y,
-                                                             const float* __restrict__ mean, float* __restrict__ part, int c, int hw) {
+                                                             const float* __restrict__ mean, float* __restrict__ part, int c, int hw,
+                                                             BnTail tail) {
   __shared__ float sm[kEwBlock / DHD_WAVE];
   const int plane = blockIdx.y, b = plane / c, ch = plane % c;
   const float mu = mean[ch];
@@ -384,59 +523,7 @@ __global__ __launch_bounds__(kEwBlock) void pair_sums_kernel(const float* __rest
   s1 = block_sum(s1, sm);
   s2 = block_sum(s2, sm);
   if (threadIdx.x == 0) {
-    float* q = part + ((size_t)(b * kPlaneChunks + blockIdx.x) * 2) * c;
-    q[ch] = s1;
-    q[c + ch] = s2;
-  }
-}
-
-// BatchNorm backward coefficients: dy = c0*g + c1*y + c2 (per channel), dgamma, dbeta, and the
-// gradient of the bias of the convolution feeding this BatchNorm (sum of dy).
-//   training: dy = gamma*rstd*(g - S1/n - (y-mu)*rstd^2*S2/n);  eval: dy = gamma*rstd*g
-__global__ __launch_bounds__(kEwBlock) void bn_backward_coef_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
-                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                    int training, float* __restrict__ tab, float* __restrict__ dgamma,
-                                                                    float* __restrict__ dbeta, float* __restrict__ dbias, int nb,
-                                                                    int c, int hw, double* __restrict__ sums_out,
-                                                                    const double* __restrict__ sums_in, const double* __restrict__ loc_fwd,
-                                                                    const float* __restrict__ shift) {
-  // Cross-rank statistics (nn.SyncBatchNorm): with `sums_out` only this rank's sums are written, [sum g][C] |
-  // [sum g (y - mu)][C] | count, as doubles; with `sums_in` (their all-reduced values) the input-gradient coefficients use
-  // the global sums and count, while dgamma / dbeta stay this rank's sums (the caller's DDP averages parameter gradients),
-  // and the convolution-bias gradient is this rank's sum of dy, which no longer vanishes rank by rank:
-  //   sum_local dy = c0 S1_local + c1 sum_local y + n_local c2,   sum_local y = loc_fwd[ch] + n_local shift[ch]  (the forward
-  //   sums are those of y - shift).
-  const int ch = blockIdx.x * kEwBlock + threadIdx.x;
-  if (ch >= c) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int q = 0; q < nb * kPlaneChunks; ++q) {
-    s1 += (double)part[((size_t)q * 2) * c + ch];
-    s2 += (double)part[((size_t)q * 2 + 1) * c + ch];
-  }
-  const double n_loc = (double)nb * (double)hw;
-  if (sums_out) {
-    sums_out[ch] = s1; sums_out[c + ch] = s2;
-    if (ch == 0) sums_out[2 * c] = n_loc;
-    return;
-  }
-  const double n = sums_in ? sums_in[2 * c] : n_loc;
-  const double g1 = sums_in ? sums_in[ch] : s1, g2 = sums_in ? sums_in[c + ch] : s2;
-  const double rs = (double)rstd[ch], mu = (double)mean[ch], ga = (double)gamma[ch];
-  if (dgamma) dgamma[ch] = (float)(rs * s2);
-  if (dbeta) dbeta[ch] = (float)s1;
-  double c0 = ga * rs, c1 = 0.0, c2 = 0.0, db = c0 * s1;
-  if (training) {
-    c1 = -ga * rs * rs * rs * g2 / n;
-    c2 = -ga * rs * g1 / n - c1 * mu;
-    db = 0.0;  // sum of dy over the (whole) batch vanishes identically
-    if (sums_in) db = c0 * s1 + c1 * (loc_fwd[ch] + n_loc * (double)shift[ch]) + n_loc * c2;
-  }
-  if (dbias) dbias[ch] = (float)db;
-  for (int b = 0; b < nb; ++b) {
-    float* t = tab + (size_t)b * 3 * c;
-    t[ch] = (float)c0;
-    t[c + ch] = (float)c1;
-    t[2 * c + ch] = (float)c2;
+    bn_backward_publish(tail, part, (size_t)(b * kPlaneChunks + blockIdx.x), ch, c, s1, s2);
   }
 }
 
@@ -473,7 +560,7 @@ __global__ __launch_bounds__(kEwBlock) void blend2_bn_bwd_kernel(const float* __
                                                                  const float* __restrict__ y2, const float* __restrict__ scsh,
                                                                  const float* __restrict__ mean, const float* __restrict__ go,
                                                                  float* __restrict__ g2, float* __restrict__ part,
-                                                                 float* __restrict__ da_p1, int c, int hw) {
+                                                                 float* __restrict__ da_p1, int c, int hw, BnTail tail) {
   __shared__ float sm[kEwBlock / DHD_WAVE];
   const int plane = blockIdx.y, b = plane / c, ch = plane % c;
   const float a = a1[plane], na = 1.0f - a, sc = scsh[ch], sh = scsh[c + ch], mu = mean[ch];
@@ -503,9 +590,8 @@ __global__ __launch_bounds__(kEwBlock) void blend2_bn_bwd_kernel(const float* __
   sa = block_sum(sa, sm);
   if (threadIdx.x == 0) {
     const size_t q = (size_t)(b * kPlaneChunks + blockIdx.x);
-    part[(q * 2) * c + ch] = s1;
-    part[(q * 2 + 1) * c + ch] = s2;
     da_p1[q * c + ch] = sa;
+    bn_backward_publish(tail, part, q, ch, c, s1, s2);
   }
 }
 
@@ -532,8 +618,12 @@ __global__ __launch_bounds__(kEwBlock) void blend1_da_kernel(const float* __rest
 __global__ __launch_bounds__(kEwBlock) void stage_gx_kernel(const float* __restrict__ a1, const float* __restrict__ y2,
                                                             const float* __restrict__ scsh, const float* __restrict__ go,
                                                             const float* __restrict__ du, const float* __restrict__ ds,
-                                                            float* __restrict__ gx, int c, int hw) {
-  const int plane = blockIdx.y, b = plane / c, ch = plane % c;
+                                                            float* __restrict__ gx, int c, int hw, int fc_rows, FcGradJob fc) {
+  if ((int)blockIdx.y < fc_rows) {   // the first block rows: the Linear layers' parameter gradients (dispatched first, no tail)
+    fc_param_grad_block(fc, (int)blockIdx.y * kPlaneChunks + (int)blockIdx.x, c);
+    return;
+  }
+  const int plane = (int)blockIdx.y - fc_rows, b = plane / c, ch = plane % c;
   const float a = a1[plane], na = 1.0f - a, sc = scsh[ch], sh = scsh[c + ch];
   const float kb = ds[(size_t)b * 2 * c + ch] / (float)hw, kv = ds[(size_t)b * 2 * c + c + ch] / (float)hw;
   const f32x4* y4 = reinterpret_cast<const f32x4*>(y2 + (size_t)plane * hw);
@@ -1968,8 +2058,9 @@ __global__ __launch_bounds__(kEwBlock) void wgrad_reduce_kernel(const float* __r
 inline size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }  // in floats: 256-byte sections
 
 struct SavedLayout {
-  size_t s, h, a1, tab_a, mean1, rstd1, scsh1, tab1, mean2, rstd2, scsh2, loc1, loc2, wp1t, wp2t, mask, y1, y2, total;
+  size_t s, h, a1, tab_a, mean1, rstd1, scsh1, tab1, mean2, rstd2, scsh2, loc1, loc2, tick, wp1t, wp2t, mask, y1, y2, total;
 };
+constexpr int kTickWords = 64;   // arrival counters besides the per-channel ones (see saved_layout)
 SavedLayout saved_layout(int b, int c, int hw, int r) {
   SavedLayout L;
   size_t o = 0;
@@ -1981,6 +2072,9 @@ SavedLayout saved_layout(int b, int c, int hw, int r) {
   L.mean1 = take(c); L.rstd1 = take(c); L.scsh1 = take(2 * c); L.tab1 = take((size_t)b * 3 * c);
   L.mean2 = take(c); L.rstd2 = take(c); L.scsh2 = take(2 * c);
   L.loc1 = take(2 * (2 * (size_t)c + 1)); L.loc2 = take(2 * (2 * (size_t)c + 1));   // (2C + 1) doubles each: this rank's shifted sums + count (phased calls)
+  // arrival counters of the kernels that finish their own reductions (BnTail): [c] BatchNorm-2 backward | [c] BatchNorm-1
+  // backward | kTickWords others; zeroed by the forward (fc_forward_kernel), left at zero by every kernel that uses them
+  L.tick = take(2 * (size_t)c + kTickWords);
   L.wp1t = take(2 * (size_t)c * c); L.wp2t = take(2 * (size_t)c * c);   // transposed weight images, packed by the forward for the backward
   L.mask = take((size_t)b * c * ((hw + 31) / 32));  // ReLU pass bits, one word per (32 pixels, channel): [sample][wave tile][channel]
   L.y1 = take((size_t)b * c * hw);
@@ -2378,7 +2472,8 @@ static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, float* o
       if (rc != DHD_OK) return rc;
     }
     hipLaunchKernelGGL(fc_forward_kernel, dim3(b), dim3(kFcBlock), (size_t)(2 * c + r) * sizeof(float), st, sc + T.mean_part,
-                       w->fc1_w, w->fc1_b, w->fc2_w, w->fc2_b, sv + S.s, sv + S.h, sv + S.a1, sv + S.tab_a, c, r, hw);
+                       w->fc1_w, w->fc1_b, w->fc2_w, w->fc2_b, sv + S.s, sv + S.h, sv + S.a1, sv + S.tab_a, c, r, hw,
+                       reinterpret_cast<int*>(sv + S.tick), 2 * c + kTickWords);
     DHD_LAUNCH_CHECK();
     // y1 = conv1(blend1(x))
     rc = launch_pw_gemm(x, x + (size_t)c * hw, (size_t)2 * c * hw, c, sv + S.tab_a, false, sc + T.wp1, w->conv1_b, nullptr, nullptr,
@@ -2468,8 +2563,12 @@ static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const v
 
   if (lo <= 0) {
     // g2 = dL/ds2, BatchNorm-2 sums, go-part of dL/da
+    // without cross-rank statistics the pass finishes its own reduction (BnTail): no bn_backward_coef launch
+    int* tick = reinterpret_cast<int*>(const_cast<float*>(sv + S.tick));
+    const BnTail tail2 = {sync ? nullptr : tick, w->bn2_w, sv + S.mean2, sv + S.rstd2, sc + T.tab_g2, grads->bn2_w, grads->bn2_b,
+                          grads->conv2_b, w->training, b, hw};
     hipLaunchKernelGGL(blend2_bn_bwd_kernel, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, sv + S.mean2, gout,
-                       sc + T.g2, sc + T.part, sc + T.da1, c, hw);
+                       sc + T.g2, sc + T.part, sc + T.da1, c, hw, tail2);
     if (sync)
       hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn2_w, sv + S.mean2, sv + S.rstd2,
                          w->training, sc + T.tab_g2, grads->bn2_w, grads->bn2_b, grads->conv2_b, b, c, hw, sync, nullptr, nullptr, nullptr);
@@ -2477,9 +2576,10 @@ static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const v
   }
   if (hi <= 0) return DHD_OK;
   if (lo <= 1) {
-    hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn2_w, sv + S.mean2, sv + S.rstd2,
-                       w->training, sc + T.tab_g2, grads->bn2_w, grads->bn2_b, grads->conv2_b, b, c, hw, nullptr, sync,
-                       reinterpret_cast<const double*>(sv + S.loc2), w->conv2_b);
+    if (sync)
+      hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn2_w, sv + S.mean2, sv + S.rstd2,
+                         w->training, sc + T.tab_g2, grads->bn2_w, grads->bn2_b, grads->conv2_b, b, c, hw, nullptr, sync,
+                         reinterpret_cast<const double*>(sv + S.loc2), w->conv2_b);
     DHD_LAUNCH_CHECK();
     // dW2 = dy2 . z1^T
     rc = launch_pw_wgrad(sc + T.g2, sv + S.y2, sc + T.tab_g2, cs, sv + S.y1, nullptr, sv + S.tab1, cs, true, sc + T.wpart,
@@ -2490,16 +2590,20 @@ static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const v
                         reinterpret_cast<unsigned*>(const_cast<float*>(sv + S.mask)), nullptr, sc + T.g1, 1, b,
                         c, hw, st);
     if (rc != DHD_OK) return rc;
-    hipLaunchKernelGGL(pair_sums_kernel, planes, dim3(kEwBlock), 0, st, sc + T.g1, sv + S.y1, sv + S.mean1, sc + T.part, c, hw);
+    int* tick = reinterpret_cast<int*>(const_cast<float*>(sv + S.tick)) + c;
+    const BnTail tail1 = {sync ? nullptr : tick, w->bn1_w, sv + S.mean1, sv + S.rstd1, sc + T.tab_g1, grads->bn1_w, grads->bn1_b,
+                          grads->conv1_b, w->training, b, hw};
+    hipLaunchKernelGGL(pair_sums_kernel, planes, dim3(kEwBlock), 0, st, sc + T.g1, sv + S.y1, sv + S.mean1, sc + T.part, c, hw, tail1);
     if (sync)
       hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn1_w, sv + S.mean1, sv + S.rstd1,
                          w->training, sc + T.tab_g1, grads->bn1_w, grads->bn1_b, grads->conv1_b, b, c, hw, sync, nullptr, nullptr, nullptr);
     DHD_LAUNCH_CHECK();
   }
   if (hi <= 1) return DHD_OK;
-  hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn1_w, sv + S.mean1, sv + S.rstd1,
-                     w->training, sc + T.tab_g1, grads->bn1_w, grads->bn1_b, grads->conv1_b, b, c, hw, nullptr, sync,
-                     reinterpret_cast<const double*>(sv + S.loc1), w->conv1_b);
+  if (sync)
+    hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn1_w, sv + S.mean1, sv + S.rstd1,
+                       w->training, sc + T.tab_g1, grads->bn1_w, grads->bn1_b, grads->conv1_b, b, c, hw, nullptr, sync,
+                       reinterpret_cast<const double*>(sv + S.loc1), w->conv1_b);
   DHD_LAUNCH_CHECK();
   // dW1 = dy1 . u^T
   rc = launch_pw_wgrad(sc + T.g1, sv + S.y1, sc + T.tab_g1, cs, x, x + cs, sv + S.tab_a, 2 * cs, false, sc + T.wpart, grads->conv1_w,
@@ -2513,10 +2617,11 @@ static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const v
   hipLaunchKernelGGL(fc_backward_kernel, dim3(b), dim3(kEwBlock), (size_t)(c + r + kEwBlock) * sizeof(float), st, sc + T.da1, sc + T.da2,
                      sv + S.a1, sv + S.h, w->fc1_w, w->fc2_w, sc + T.dpre2, sc + T.dh, sc + T.ds, c, r);
   const int n_fc = r * 2 * c + c * r + r + c;
-  hipLaunchKernelGGL(fc_param_grad_kernel, dim3(dhd_cdiv(n_fc, kEwBlock)), dim3(kEwBlock), 0, st, sc + T.dpre2, sc + T.dh, sv + S.h,
-                     sv + S.s, grads->fc1_w, grads->fc1_b, grads->fc2_w, grads->fc2_b, b, c, r);
-  hipLaunchKernelGGL(stage_gx_kernel, planes, dim3(kEwBlock), 0, st, sv + S.a1, sv + S.y2, sv + S.scsh2, gout, sc + T.du, sc + T.ds, gx,
-                     c, hw);
+  const FcGradJob fcj = {sc + T.dpre2, sc + T.dh, sv + S.h, sv + S.s, grads->fc1_w, grads->fc1_b, grads->fc2_w, grads->fc2_b, b, r};
+  const int fc_rows = dhd_cdiv(dhd_cdiv(n_fc, kEwBlock), kPlaneChunks);
+  const dim3 planes_fc(kPlaneChunks, b * c + fc_rows);
+  hipLaunchKernelGGL(stage_gx_kernel, planes_fc, dim3(kEwBlock), 0, st, sv + S.a1, sv + S.y2, sv + S.scsh2, gout, sc + T.du, sc + T.ds, gx,
+                     c, hw, fc_rows, fcj);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
