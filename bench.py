@@ -39,6 +39,34 @@ sys.path.insert(0, ROOT)
 from dhd_amd import _lib, dist as ddist, mghs_op, synthetic as syn  # noqa: E402
 from dhd_amd.mix import channel_spatial_stage  # noqa: E402
 
+
+def event_mean(pairs):
+    """Mean of HIP-event intervals in ms, without the samples a host stall inflated.  An event pair brackets asynchronous
+    launches: when the host pauses between recording the first event and issuing the kernel (a Python garbage collection took
+    36-39 ms at that exact place in two runs of three, turning a 26 us average into 1.9 ms), the stream idles and the interval
+    shows the pause, not the kernel.  Samples above three times the median are such pauses and are left out (the timed
+    regions also run with the collector off, see `no_gc`)."""
+    v = np.array([a.elapsed_time(b) for a, b in pairs], dtype=np.float64)
+    if v.size == 0:
+        return float('nan')
+    keep = v <= 3.0 * np.median(v)
+    return float(v[keep].mean())
+
+
+class no_gc:
+    """Python's cyclic collector off inside a timed region (collected once on entry), restored on exit."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+
+    def __exit__(self, *a):
+        import gc
+        if self.was:
+            gc.enable()
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 
@@ -378,7 +406,7 @@ def hbm_calibration(dev, nbytes, reps=20, warmup=3):
             if it >= warmup:
                 ev.append((e0, e1))
         torch.cuda.synchronize()
-        out[name] = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        out[name] = event_mean(ev)
     del buf
     return out, nbytes
 
@@ -400,7 +428,7 @@ def lift_timing(hp, reps=20, warmup=3):
             if it >= warmup:
                 ev.append((e0, e1))
         torch.cuda.synchronize()
-        out[name] = 1e3 * float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        out[name] = 1e3 * event_mean(ev)
     return out
 
 
@@ -482,8 +510,8 @@ def operator_roofline(hp, steps, warmup):
         bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln).backward(ogp)
     torch.cuda.synchronize()
     py_uncached_ms = (time.perf_counter() - t0) / steps * 1e3
-    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    fwd_ms = event_mean([(e[0], e[1]) for e in ev])
+    bwd_ms = event_mean([(e[1], e[2]) for e in ev])
     n_kept = int(rb.numel())
     plane = B * 4 * Cc * 200 * 200
     small = B * (4 * N * D * fh * fw + 4 * N * fh * fw * Cc)
@@ -702,7 +730,7 @@ def run_occ_loss(a, rank, world, dev):
     torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
     elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
-        kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+        kern_ms = event_mean(ev)
         grad_bytes = m * (2 * 18 * 4 + 2)  # logits read + gradient written + label and mask bytes
         achieved = grad_bytes / (kern_ms * 1e-3) / 1e9
         line = dict(metric='samples/sec (fwd+bwd) DHD-S occupancy-head losses', value=a.batch * world * a.steps / elapsed, unit='samples/s',
@@ -771,7 +799,7 @@ def run_ema(a, rank, world, dev):
     torch.cuda.synchronize()
     eager_ms = (time.perf_counter() - t0) / 5 * 1e3
     if rank == 0:
-        kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+        kern_ms = event_mean(ev)
         achieved = 12 * n_val / (kern_ms * 1e-3) / 1e9
         print(json.dumps(dict(
             metric='EMA updates/sec, DHD-S state dict', value=world * a.steps / elapsed, unit='updates/s', n_gpus=world, steps=a.steps,
@@ -828,14 +856,15 @@ def main():
         torch.cuda.synchronize()
 
     hp.make_events((a.steps + 3) // 4)
-    fence()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        # HIP events around the dominant kernel / the backward / the SFA stage on every 4th timed step (and the first): each
-        # recorded step carries seven extra marker packets and host calls, 35 us on a 0.34 ms MGHS-only step
-        hp.step(k % 4 == 0)
-    fence()
-    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+    with no_gc():   # a cyclic collection inside the timed steps is a 30-40 ms host pause in a 0.1 s region
+        fence()
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            # HIP events around the dominant kernel / the backward / the SFA stage on every 4th timed step (and the first): each
+            # recorded step carries seven extra marker packets and host calls, 35 us on a 0.34 ms MGHS-only step
+            hp.step(k % 4 == 0)
+        fence()
+        elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
 
     # the same step with float32-level GEMM products in the SFA stage (bf16x6), W warm-ups + K timed steps
     elapsed_x6 = None
@@ -843,19 +872,20 @@ def main():
         main_gemm, hp.stage.gemm = hp.stage.gemm, 'bf16x6'
         for _ in range(a.warmup):
             hp.step(False)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            hp.step(False)
-        fence()
-        elapsed_x6 = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+        with no_gc():
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                hp.step(False)
+            fence()
+            elapsed_x6 = ddist.max_over_ranks(time.perf_counter() - t0, dev)
         hp.stage.gemm = main_gemm
     cal_ms, cal_bytes = hbm_calibration(dev, hp.pool_fwd_bytes)   # every rank runs it, rank 0 reports
     lift_us = lift_timing(hp)
 
     line = None
     if rank == 0:
-        kern_ms = float(np.mean([s.elapsed_time(e) for s, e in hp.ev]))
+        kern_ms = event_mean(hp.ev)
         achieved = hp.pool_fwd_bytes / (kern_ms * 1e-3) / 1e9
         line = dict(
             metric=f'samples/sec (6-cam fwd+bwd) {a.geometry.upper()} view-transform hot path', value=a.batch * world * a.steps / elapsed,
@@ -883,7 +913,7 @@ def main():
         if elapsed_x6 is not None:
             line['ms_per_step_bf16x6'] = 1e3 * elapsed_x6 / a.steps
             line['value_bf16x6'] = a.batch * world * a.steps / elapsed_x6
-        bwd_ms = float(np.mean([s.elapsed_time(e) for s, e in hp.ev_bwd]))
+        bwd_ms = event_mean(hp.ev_bwd)
         bwd_ach = hp.pool_bwd_bytes / (bwd_ms * 1e-3) / 1e9
         line['roofline_bwd'] = dict(bound='hbm', kernel='mghs_stream_bwd + mghs_pixel_bwd (dhd_mghs_backward)', achieved=bwd_ach,
                                     peak=HBM_PEAK_GBPS, unit='GB/s', frac=bwd_ach / HBM_PEAK_GBPS,
@@ -892,8 +922,8 @@ def main():
         if hp.ev_sfa:
             # second roofline, for the SFA stage operator as a whole (a dozen kernels per call): SURVEY 8(d) gives its forward
             # algorithmic traffic as x read twice + u/out written + the two 1x1 convs reading and writing (B,C,H,W) once each
-            fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in hp.ev_sfa]))
-            bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in hp.ev_sfa]))
+            fwd_ms = event_mean([(e[0], e[1]) for e in hp.ev_sfa])
+            bwd_ms = event_mean([(e[1], e[2]) for e in hp.ev_sfa])
             c, hw = 256, 200 * 200
             fwd_bytes = a.batch * 4 * hw * (2 * 2 * c + 4 * c)   # 2 reads of (2C,H,W) + 4 passes over (C,H,W) = 328 MB/sample
             gemm_flop = 2.0 * c * c * hw * a.batch
@@ -907,7 +937,8 @@ def main():
                      'f32-MFMA peak is 157 TFLOP/s')
     t_stage = time.perf_counter()
     if a.geometry == 'dhd-s' and not a.no_operator:
-        op_roof = operator_roofline(hp, max(5, min(a.steps, 20)), 3)   # every rank runs it, rank 0 reports
+        with no_gc():
+            op_roof = operator_roofline(hp, max(5, min(a.steps, 20)), 3)   # every rank runs it, rank 0 reports
         if rank == 0:
             line['roofline_operator'] = op_roof
     if rank == 0 and world == 1 and a.cpu_samples > 0:

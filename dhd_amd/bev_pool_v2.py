@@ -13,6 +13,27 @@ from . import _lib
 __all__ = ['bev_pool_v2', 'QuickCumsumCuda']
 
 
+def _as(t, dtype):
+    """`t.contiguous().to(dtype)` of the reference wrapper (bev_pool.py:20-25,59-69) without the Python cost of two no-op calls
+    when the tensor already is what the kernel needs (the operator's time through this surface is mostly host time)."""
+    return t if (t.dtype == dtype and t.is_contiguous()) else t.contiguous().to(dtype)
+
+
+class _on:
+    """`with torch.cuda.device(dev)` only when `dev` is not the current device (the context manager costs ~10 us per use)."""
+
+    def __init__(self, dev):
+        self.ctx = None if dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
 class QuickCumsumCuda(torch.autograd.Function):
     """Name kept from the reference (bev_pool.py:11)."""
 
@@ -22,20 +43,22 @@ class QuickCumsumCuda(torch.autograd.Function):
         lib = _lib.load()
         if not depth.is_cuda:
             raise _lib.DhdError('bev_pool_v2 runs only on the GPU (no CPU path, as in the reference)')
-        ranks_bev = ranks_bev.int().contiguous()
-        depth = depth.contiguous().float()
-        feat = feat.contiguous().float()
-        ranks_depth = ranks_depth.contiguous().int()
-        ranks_feat = ranks_feat.contiguous().int()
-        interval_lengths = interval_lengths.contiguous().int()
-        interval_starts = interval_starts.contiguous().int()
+        i32, f32 = torch.int32, torch.float32
+        ranks_bev = _as(ranks_bev, i32)
+        depth = _as(depth, f32)
+        feat = _as(feat, f32)
+        ranks_depth = _as(ranks_depth, i32)
+        ranks_feat = _as(ranks_feat, i32)
+        interval_lengths = _as(interval_lengths, i32)
+        interval_starts = _as(interval_starts, i32)
         out = feat.new_zeros(bev_feat_shape)  # (B, Dz, Dy, Dx, C)
-        with torch.cuda.device(depth.device):
+        with _on(depth.device):
             rc = lib.dhd_bev_pool_v2_forward(
-                _lib.ptr(depth), _lib.ptr(feat), _lib.ptr(out), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
-                _lib.ptr(ranks_bev), _lib.ptr(interval_lengths), _lib.ptr(interval_starts),
-                int(feat.shape[-1]), int(interval_lengths.numel()), _lib.stream_ptr(depth.device))
-        _lib.check(rc, 'dhd_bev_pool_v2_forward')
+                depth.data_ptr(), feat.data_ptr(), out.data_ptr(), ranks_depth.data_ptr(), ranks_feat.data_ptr(),
+                ranks_bev.data_ptr(), interval_lengths.data_ptr(), interval_starts.data_ptr(),
+                feat.shape[-1], interval_lengths.numel(), torch.cuda.current_stream(depth.device).cuda_stream)
+        if rc:
+            _lib.check(rc, 'dhd_bev_pool_v2_forward')
         ctx.save_for_backward(ranks_bev, depth, feat, ranks_feat, ranks_depth)
         return out
 
@@ -47,16 +70,18 @@ class QuickCumsumCuda(torch.autograd.Function):
         # what bev_pool.py:47-57 does with an argsort, three gathers and a run-length scan on EVERY call.  Here: a device
         # counting sort (dhd_bev_pool_v2_regroup, no host synchronisation), kept while the same rank tensors come back
         # unmodified (index lists of a static rig; voxel_pooling_v2 rebuilds them per call in training).
-        rd, rf, rb, starts, lengths = _regrouped(lib, ranks_depth, ranks_feat, ranks_bev, feat.numel() // int(feat.shape[-1]))
-        depth_grad = depth.new_zeros(depth.shape)
-        feat_grad = feat.new_zeros(feat.shape)
-        out_grad = out_grad.contiguous().float()
-        with torch.cuda.device(depth.device):
+        c = feat.shape[-1]
+        rd, rf, rb, starts, lengths = _regrouped(lib, ranks_depth, ranks_feat, ranks_bev, feat.numel() // c)
+        depth_grad = torch.zeros_like(depth)
+        feat_grad = torch.zeros_like(feat)
+        out_grad = _as(out_grad, torch.float32)
+        with _on(depth.device):
             rc = lib.dhd_bev_pool_v2_backward(
-                _lib.ptr(out_grad), _lib.ptr(depth_grad), _lib.ptr(feat_grad), _lib.ptr(depth), _lib.ptr(feat),
-                _lib.ptr(rd), _lib.ptr(rf), _lib.ptr(rb), _lib.ptr(lengths),
-                _lib.ptr(starts), int(feat.shape[-1]), int(lengths.numel()), _lib.stream_ptr(depth.device))
-        _lib.check(rc, 'dhd_bev_pool_v2_backward')
+                out_grad.data_ptr(), depth_grad.data_ptr(), feat_grad.data_ptr(), depth.data_ptr(), feat.data_ptr(),
+                rd.data_ptr(), rf.data_ptr(), rb.data_ptr(), lengths.data_ptr(), starts.data_ptr(), c, lengths.numel(),
+                torch.cuda.current_stream(depth.device).cuda_stream)
+        if rc:
+            _lib.check(rc, 'dhd_bev_pool_v2_backward')
         return depth_grad, feat_grad, None, None, None, None, None, None
 
 

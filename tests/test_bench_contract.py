@@ -54,3 +54,28 @@ def test_committed_pmc_summary_belongs_to_the_current_kernel_sources():
     assert None not in both
     fwd = bench.sfa_forward_traffic(4)
     assert fwd is not None and 4 * 328e6 < fwd < 2 * 4 * 328e6     # algorithmic 328 MB per sample
+
+
+def test_event_mean_leaves_out_host_stalls():
+    """bench.event_mean: an interval between two HIP events also contains the time the stream sat idle while the host was
+    paused (a 36-39 ms garbage collection between an event and the next launch made a 26 us kernel read 1.9 ms); samples above
+    three times the median are dropped, everything else is a plain mean."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    pairs = [(Ev(0.0), Ev(0.026)) for _ in range(19)] + [(Ev(0.0), Ev(38.0))]
+    assert abs(bench.event_mean(pairs) - 0.026) < 1e-12
+    pairs = [(Ev(0.0), Ev(t)) for t in (0.10, 0.12, 0.14, 0.29)]      # ordinary spread: nothing dropped
+    assert abs(bench.event_mean(pairs) - 0.1625) < 1e-12
+    import gc
+    was = gc.isenabled()
+    with bench.no_gc():
+        assert not gc.isenabled()
+    assert gc.isenabled() == was
