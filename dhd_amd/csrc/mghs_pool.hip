@@ -199,14 +199,26 @@ __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float
 // ---------------------------------------------------------------------------------------
 constexpr size_t kStreamLds = (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2 + 16;
 
-__global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtrs out) {
+// Workgroups [0, n_whole) write one whole segment each (all kTileC channels); the segments beyond n_whole are written by
+// `split` workgroups each, a contiguous 1/split of the channels per workgroup.  The host (stream_tail_split) cuts the LAST,
+// partly filled round of resident workgroups this way: four workgroups of 512 threads fit a CU, the 3 400 segments of a
+// DHD-S batch of four are 3.32 rounds of 1 024, and during the last third of a round the chip ran at a third of its
+// occupancy -- per sample the writer took 33.8 us at B = 4 against 30.7 us at B = 6 (4.98 rounds) and 31.1 us at B = 3.
+__global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtrs out, int n_whole, int split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* table = reinterpret_cast<float*>(smem);
   unsigned short* slot_of = reinterpret_cast<unsigned short*>(smem + (size_t)kTableFloats * 4);
   int* ctl = reinterpret_cast<int*>(smem + (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2);
 
+  int seg = blockIdx.x, c_begin = 0, c_end = kTileC;
+  if (seg >= n_whole) {                      // block-uniform
+    const int j = seg - n_whole, pw = kTileC / split;
+    seg = n_whole + j / split;
+    c_begin = (j % split) * pw;
+    c_end = c_begin + pw;
+  }
   Segment sg;
-  if (!decode_segment(L, blockIdx.x, &sg)) return;
+  if (!decode_segment(L, seg, &sg)) return;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   if (t == 0) ctl[0] = L.nzoff[sg.v0];
   if (t == 1) ctl[1] = L.nzoff[sg.v0 + sg.nvox];
@@ -214,11 +226,11 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
   __syncthreads();
   const int k0 = rfl(ctl[0]), nnz = rfl(ctl[1]) - k0;
   for (int j = t; j < nnz; j += kStreamBlock) slot_of[L.nzvox[k0 + j] - sg.v0] = (unsigned short)(j + 1);
-  const int cp = channels_per_pass(nnz);
+  const int cp = min(channels_per_pass(nnz), c_end - c_begin);
   const int nvec = sg.nvox / 4;
   float* og = out.p[sg.g];
   const long sb = out.sb[sg.g], sz = out.sz[sg.g], sc = out.sc[sg.g];
-  for (int c_lo = 0; c_lo < kTileC; c_lo += cp) {
+  for (int c_lo = c_begin; c_lo < c_end; c_lo += cp) {
     __syncthreads();  // slot_of complete / previous pass done with the table
     // table[j*cp + cc] = vsum[(k0+j)*64 + c_lo + cc]: runs of cp floats, coalesced
     for (int i = t; i < nnz * cp; i += kStreamBlock) {
@@ -661,6 +673,27 @@ void rows_launch_shape(const Layout& L, int* stride, size_t* smem, dim3* grid) {
 
 using namespace dhd;
 
+// How many of the streaming kernels' segments are written by one workgroup each, and into how many channel parts the others
+// are split (see mghs_stream_fwd): the whole rounds of resident workgroups (kStreamBlock threads: 2048 / kStreamBlock per
+// CU) stay whole, the remainder is split 4- or 2-fold if the parts still fit one round.
+static void stream_tail_split(int n_segs, int* n_whole, int* split) {
+  static int cus[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (cus[dev] == 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = -1;
+  *n_whole = n_segs;
+  *split = 1;
+  if (cus[dev] <= 0) return;
+  const int slots = cus[dev] * (2048 / kStreamBlock);
+  const int rem = n_segs % slots;
+  if (rem == 0 || n_segs < slots) return;      // whole rounds only, or less than one round of work
+  const int k = rem * 4 <= slots ? 4 : (rem * 2 <= slots ? 2 : 1);
+  if (k == 1) return;
+  *n_whole = n_segs - rem;
+  *split = k;
+}
+
 extern "C" {
 
 int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc, const dhd_mghs_workspace* workspace,
@@ -688,7 +721,10 @@ static int forward_stream_impl(const dhd_mghs_desc* desc, const float* depth, co
   if ((rc = make_views<OutPtrs, float>(L, out, views, &o))) return rc;
   hipStream_t st = dhd_stream(stream);
   if (L.compact) {
-    hipLaunchKernelGGL(mghs_stream_fwd, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, o);
+    int n_whole, split;
+    stream_tail_split(L.n_segs, &n_whole, &split);
+    hipLaunchKernelGGL(mghs_stream_fwd, dim3(n_whole + (L.n_segs - n_whole) * split), dim3(kStreamBlock), kStreamLds, st, L, o, n_whole,
+                       split);
     DHD_LAUNCH_CHECK();
   } else {
     int stride; size_t smem; dim3 grid;

@@ -836,6 +836,29 @@ def test_batch_of_eight_equals_two_batches_of_four(gpu):
     assert np.count_nonzero(outs8[0]) > 1000000
 
 
+@pytest.mark.parametrize('batch, split', [(3, 2), (5, 4)])
+def test_writer_tail_split_batches_equal_single_samples(gpu, batch, split):
+    """The streaming writer cuts the segments of its last, partly filled round of workgroups into channel parts
+    (mghs_stream_fwd: 850 segments per sample, 1 024 resident workgroups: B = 3 -> 502 segments in halves, B = 5 -> 154 in
+    quarters, B = 4 -> 328 in halves is what every full-size test runs).  In deterministic mode the batch's pooled
+    tensors are bit-identical to those of its samples run one by one (850 segments: one round, nothing split)."""
+    from dhd_amd import mghs_op
+    cfg = syn.dhd_s_config()
+    assert (850 * batch) % 1024 * split <= 1024 < (850 * batch) % 1024 * split * 2
+    calib_np = syn.make_calibration(511, batch, 6, cfg['input_size'])
+    depth, feat, hidx = syn.lift_inputs(512, batch, 6, 44, 16, 44, 64, 65)
+    mghs_op.set_deterministic(True)
+    try:
+        outs, _, _ = run_fused(gpu, cfg, calib_np, depth, feat, hidx, weights_seed=None)
+        for b in range(batch):
+            bn = slice(6 * b, 6 * b + 6)
+            o, _, _ = run_fused(gpu, cfg, [a[b:b + 1] for a in calib_np], depth[bn], feat[bn], hidx[bn])
+            for k in range(4):
+                assert np.array_equal(outs[k][b:b + 1], o[k]), (b, k)
+    finally:
+        mghs_op.set_deterministic(False)
+
+
 def test_static_lift_full_size_is_bit_identical_to_a_full_lift(gpu):
     """dhd_mghs_lift_static at the full DHD-S size, B = 4: after one full lift, three frames with new height maps (new
     bands) and new depth / context values each redo only the band grids' grouping; in deterministic mode the four pooled
