@@ -199,24 +199,25 @@ __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float
 // ---------------------------------------------------------------------------------------
 constexpr size_t kStreamLds = (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2 + 16;
 
-// Workgroups [0, n_whole) write one whole segment each (all kTileC channels); the segments beyond n_whole are written by
-// `split` workgroups each, a contiguous 1/split of the channels per workgroup.  The host (stream_tail_split) cuts the LAST,
-// partly filled round of resident workgroups this way: four workgroups of 512 threads fit a CU, the 3 400 segments of a
-// DHD-S batch of four are 3.32 rounds of 1 024, and during the last third of a round the chip ran at a third of its
-// occupancy -- per sample the writer took 33.8 us at B = 4 against 30.7 us at B = 6 (4.98 rounds) and 31.1 us at B = 3.
-__global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtrs out, int n_whole, int split) {
+// Every segment is written by `split` workgroups, a contiguous 1/split of the kTileC channels each (workgroup = (segment,
+// part)).  Measured on the writer alone, three alternating runs per variant on one box (experiments/ab/run_split.sh):
+//   DHD-S, B = 4 (3 400 segments):  1 / 2 / 4 / 8 / 16 parts: 139.7 / 137.9 / 130.8 / 144.4 / 237 us
+//   DHD-S, B = 1 / 2 / 8:            44.0 -> 37.1 (4 parts) / 66 -> 66 / 254 -> 247 us
+//   DHD-L geometry, B = 2:           86.3 / 77.9 / 87.7 us  (1 / 2 / 4 parts);  DHD-M, B = 3: 95.0 / 94.8 / 99.5 us
+// More, shorter workgroups fill the chip more evenly (four 512-thread workgroups fit a CU: the 3 400 whole segments of a
+// DHD-S batch of four are 3.3 rounds of 1 024) and their prologues (slot map, table) overlap other workgroups' streaming;
+// the price is that the slot map of a segment is built once per part.  Where segments are sparse that is cheap and 16
+// channels per workgroup are best; where they are dense (D = 88: twice the points, or the 32 x 88 feature maps of
+// DHD-L) the table holds 32 channels per pass anyway and halves are best.  The host picks by points per segment
+// (stream_split).  mghs_stream_bwd gains nothing from 2 parts (134 us) and loses with 4 (147 us): it stays whole.
+__global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtrs out, int split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* table = reinterpret_cast<float*>(smem);
   unsigned short* slot_of = reinterpret_cast<unsigned short*>(smem + (size_t)kTableFloats * 4);
   int* ctl = reinterpret_cast<int*>(smem + (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2);
 
-  int seg = blockIdx.x, c_begin = 0, c_end = kTileC;
-  if (seg >= n_whole) {                      // block-uniform
-    const int j = seg - n_whole, pw = kTileC / split;
-    seg = n_whole + j / split;
-    c_begin = (j % split) * pw;
-    c_end = c_begin + pw;
-  }
+  const int seg = blockIdx.x / split, pw = kTileC / split;
+  const int c_begin = (blockIdx.x % split) * pw, c_end = c_begin + pw;
   Segment sg;
   if (!decode_segment(L, seg, &sg)) return;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -673,25 +674,10 @@ void rows_launch_shape(const Layout& L, int* stride, size_t* smem, dim3* grid) {
 
 using namespace dhd;
 
-// How many of the streaming kernels' segments are written by one workgroup each, and into how many channel parts the others
-// are split (see mghs_stream_fwd): the whole rounds of resident workgroups (kStreamBlock threads: 2048 / kStreamBlock per
-// CU) stay whole, the remainder is split 4- or 2-fold if the parts still fit one round.
-static void stream_tail_split(int n_segs, int* n_whole, int* split) {
-  static int cus[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64) dev = 0;
-  if (cus[dev] == 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = -1;
-  *n_whole = n_segs;
-  *split = 1;
-  if (cus[dev] <= 0) return;
-  const int slots = cus[dev] * (2048 / kStreamBlock);
-  const int rem = n_segs % slots;
-  if (rem == 0 || n_segs < slots) return;      // whole rounds only, or less than one round of work
-  const int k = rem * 4 <= slots ? 4 : (rem * 2 <= slots ? 2 : 1);
-  if (k == 1) return;
-  *n_whole = n_segs - rem;
-  *split = k;
+// Channel parts per segment of the streaming writer (see mghs_stream_fwd): 4 where a segment holds few points (DHD-S: 218
+// per segment), 2 where it holds many (D = 88: 437; the DHD-L feature maps: 1 750).
+static int stream_split(const Layout& L) {
+  return (long)L.P < 300L * L.n_segs ? 4 : 2;
 }
 
 extern "C" {
@@ -721,10 +707,8 @@ static int forward_stream_impl(const dhd_mghs_desc* desc, const float* depth, co
   if ((rc = make_views<OutPtrs, float>(L, out, views, &o))) return rc;
   hipStream_t st = dhd_stream(stream);
   if (L.compact) {
-    int n_whole, split;
-    stream_tail_split(L.n_segs, &n_whole, &split);
-    hipLaunchKernelGGL(mghs_stream_fwd, dim3(n_whole + (L.n_segs - n_whole) * split), dim3(kStreamBlock), kStreamLds, st, L, o, n_whole,
-                       split);
+    const int split = stream_split(L);
+    hipLaunchKernelGGL(mghs_stream_fwd, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
     DHD_LAUNCH_CHECK();
   } else {
     int stride; size_t smem; dim3 grid;
