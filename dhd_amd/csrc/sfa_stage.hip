@@ -1310,7 +1310,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  int wtg = team * WAVES + wv;
+  // bf16x3: a wave takes a CONTIGUOUS range of tiles (its team partner's waves the same one); bf16x6 every stride-th tile, as
+  // the streamed kernels whose results it reproduces.  Measured, three alternating runs each (experiments/ab/run.sh): stage
+  // forward 0.387 -> 0.383 ms, backward 0.928 -> 0.920 ms with contiguous ranges in bf16x3; the bf16x6 step 1.950 -> 1.960 ms.
+  constexpr bool kContig = NT == 2;
+  const int per_wave = (total + stride - 1) / stride;
+  int wtg = kContig ? (team * WAVES + wv) * per_wave : team * WAVES + wv;
+  const int wtg_end = kContig ? min(total, wtg + per_wave) : total;
+  const int wtg_step = kContig ? 1 : stride;
   // BatchNorm statistics of the output (EPI 0): bf16x3 keeps them per lane over all of the wave's tiles; at the end the
   // workgroup's eight waves meet in LDS and ONE row per workgroup is written, stat_part[team][2][c] (each member of a team
   // its own channels): 128 rows at B = 4, where round 2 wrote a row per wave (1 024) and round 1 one per (sample, wave
@@ -1342,7 +1349,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
       }
     }
   };
-  if (wtg >= total) {                              // wave-uniform
+  if (wtg >= wtg_end) {                            // wave-uniform
     flush_stats();                                 // zeros into the workgroup's sum
     return;
   }
@@ -1353,8 +1360,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
   for (int t = 0; t < COB; ++t) bias_r[t] = EPI == 0 ? bias[g * 32 * COB + 32 * t + r] : 0.f;
   Tile cur = make_tile(wtg);
   static_for<D>([&](auto sc) { issue(sc, cur, decltype(sc)::value); });
-  for (; wtg < total; wtg += stride) {
-    const Tile nxt = make_tile(wtg + stride);
+  for (; wtg < wtg_end; wtg += wtg_step) {
+    const Tile nxt = make_tile(wtg + wtg_step < wtg_end ? wtg + wtg_step : wtg);   // past the wave's range: a harmless re-read
     // The K loop is fully unrolled (straight-line code per tile): with an inner loop the register allocator
     // copied every prefetch register and every accumulator at the loop header (and a copy of a loaded register
     // waits for its load: no lookahead left).  Steps kc >= KCN - D prefetch the first steps of the next tile.
