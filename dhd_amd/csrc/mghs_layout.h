@@ -46,9 +46,10 @@ struct Layout {
   int* offset;     // [V+1]   exclusive prefix of count            (entry index space)
   int* key;        // [2P]    voxel id of point p in grid 0 ([p]) and in its band grid ([P+p]); -1 = dropped
   int* rnk;        // [2P]    arrival rank of the point inside its voxel
-  int* s_pid;      // [2P]    point id of every entry, entries grouped by voxel (index into depth)
-  int* s_pix;      // [2P]    pixel id of every entry (row of feat_nhwc)
-  int* s_slot;     // [2P]    slot (non-empty voxel ordinal) of every entry, non-decreasing
+  // [2P] entries grouped by voxel, ONE 16-byte record each: x = point id (index into depth), y = pixel id (row of
+  // feat_nhwc), z = slot (non-empty voxel ordinal, non-decreasing), w unused.  (Three int arrays before: the scatter wrote
+  // three 4-byte words per entry into three different cache lines.)
+  int4* s_ent;
   float* cam;      // [B*N*kCamFloats] per-camera matrices
   float* dg_part;  // [2P]    backward scratch of the generic path: depth-gradient parts of grid 0 / band grid
   float* fg_stage; // [B*N*hw*C] generic path with DHD_MGHS_FEAT_GRAD_NCHW: the (B*N,fH,fW,C) gradient before its transposition
@@ -137,9 +138,7 @@ inline int make_layout(const dhd_mghs_desc* d, const dhd_mghs_workspace* ws, Lay
   L->offset = carve((size_t)L->V + 1);
   L->key = carve(P2);
   L->rnk = carve(P2);
-  L->s_pid = carve(P2);
-  L->s_pix = carve(P2);
-  L->s_slot = carve(P2);
+  L->s_ent = reinterpret_cast<int4*>(carve(4 * P2));
   L->cam = reinterpret_cast<float*>(carve((size_t)L->B * L->N * kCamFloats));
   L->dg_part = reinterpret_cast<float*>(carve(compact ? 0 : P2));
   L->fg_stage = reinterpret_cast<float*>(carve(compact ? 0 : (size_t)L->B * L->N * L->hw * L->C));

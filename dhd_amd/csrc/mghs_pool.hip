@@ -142,10 +142,11 @@ __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float
   int slot_n = -1, prev_n = -2, pix_n = 0, pid_n = 0;
   float dv_n = 0.f;
   if (idx < T) {
-    slot_n = L.s_slot[idx];
-    pix_n = L.s_pix[idx];
-    pid_n = L.s_pid[idx];
-    if (idx > 0) prev_n = L.s_slot[idx - 1];
+    const int4 en = L.s_ent[idx];
+    slot_n = en.z;
+    pix_n = en.y;
+    pid_n = en.x;
+    if (idx > 0) prev_n = L.s_ent[idx - 1].z;
   }
   if (idx < T) dv_n = depth[pid_n];
   for (int a0 = a; a0 < T; a0 += DHD_WAVE) {
@@ -175,10 +176,11 @@ __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float
     idx = a0 + DHD_WAVE + lane;
     slot_n = -1; pix_n = 0; pid_n = 0;
     if (!last && idx < T) {  // next batch: its index words travel while this batch is processed
-      slot_n = L.s_slot[idx];
-      pix_n = L.s_pix[idx];
-      pid_n = L.s_pid[idx];
-      prev_n = L.s_slot[idx - 1];
+      const int4 en = L.s_ent[idx];
+      slot_n = en.z;
+      pix_n = en.y;
+      pid_n = en.x;
+      prev_n = L.s_ent[idx - 1].z;
     }
     if (lo < nb) {
       const int jmax = last ? term : DHD_WAVE - 1;
@@ -537,8 +539,9 @@ __global__ __launch_bounds__(kRowBlock) void mghs_rows_fwd(Layout L, const float
         int pix = 0;
         float dv = 0.f;
         if (lane < nb) {
-          pix = L.s_pix[s0 + lane];
-          dv = depth[L.s_pid[s0 + lane]];
+          const int4 en = L.s_ent[s0 + lane];
+          pix = en.y;
+          dv = depth[en.x];
         }
         // uniform trip count: the cross-lane reads below must be executed by every lane
         const int steps = (nb + nsub - 1) / nsub;
@@ -630,8 +633,9 @@ __global__ __launch_bounds__(kRowBlock) void mghs_rows_bwd(Layout L, const float
       int pix = 0, pid = 0;
       float dv = 0.f;
       if (lane < nb) {
-        pix = L.s_pix[s0 + lane];
-        pid = L.s_pid[s0 + lane];
+        const int4 en = L.s_ent[s0 + lane];
+        pix = en.y;
+        pid = en.x;
         dv = depth[pid];
       }
       float mine = 0.f;  // depth-gradient contribution of the point this lane loaded

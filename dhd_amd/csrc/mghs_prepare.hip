@@ -398,9 +398,7 @@ __global__ __launch_bounds__(kBlock) void mghs_scatter(Layout L, int blocks_per_
     if (k >= 0) {
       int pos = L.offset[k] + L.rnk[j * L.P + pid];
       slot = L.nzoff[k];
-      L.s_pid[pos] = pid;
-      L.s_pix[pos] = pix;
-      L.s_slot[pos] = slot;
+      L.s_ent[pos] = make_int4(pid, pix, slot, 0);
     }
     L.p_slot[j * L.P + pid] = slot;
   }
@@ -419,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void mghs_rank_by_pid(Layout L, int t0) {
   const int pid = t < L.P ? t : t - L.P;
   const int lo = L.offset[k], hi = L.offset[k + 1];
   int r = 0;
-  for (int e = lo; e < hi; ++e) r += L.s_pid[e] < pid;
+  for (int e = lo; e < hi; ++e) r += L.s_ent[e].x < pid;
   L.rnk[t] = r;
 }
 
