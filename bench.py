@@ -50,7 +50,13 @@ def event_mean(pairs):
     if v.size == 0:
         return float('nan')
     keep = v <= 3.0 * np.median(v)
+    EVENT_DROPS['dropped'] += int((~keep).sum())
+    EVENT_DROPS['total'] += int(v.size)
     return float(v[keep].mean())
+
+
+# how many event samples event_mean() has left out in this process (reported in the JSON line as `event_samples_dropped`)
+EVENT_DROPS = {'dropped': 0, 'total': 0}
 
 
 class no_gc:

@@ -17,7 +17,7 @@ import torch
 __all__ = ['load_checkpoint', 'load_state_dict', 'save_checkpoint']
 
 
-def _read(filename, map_location='cpu'):
+def _read(filename, map_location='cpu', trusted=False):
     if not isinstance(filename, (str, os.PathLike)):
         raise TypeError('checkpoint must be a path')
     name = str(filename)
@@ -25,9 +25,17 @@ def _read(filename, map_location='cpu'):
         raise IOError(f'{name}: only local checkpoint files can be loaded here (no network, no torchvision); download the file and pass its path')
     if not os.path.isfile(name):
         raise IOError(f'{name} is not a checkpoint file')
+    import pickle
     try:
         return torch.load(name, map_location=map_location, weights_only=True)
-    except Exception:   # checkpoints written by mmcv carry a `meta` dict with plain python objects
+    except pickle.UnpicklingError as err:
+        # checkpoints written by mmcv carry a `meta` dict that may hold python objects the safe unpickler refuses.  Running
+        # the full unpickler executes whatever the file says, so it is the caller's explicit decision (`trusted=True`), never
+        # a silent retry: `load_from` / `pretrained` files are third-party downloads.
+        if not trusted:
+            raise RuntimeError(f'{name}: refused by the weights-only unpickler ({err}); if the file comes from a source you trust, '
+                               'pass trusted=True to load it with the full (code-executing) unpickler') from err
+        warnings.warn(f'{name}: loading with the full unpickler (trusted=True)', stacklevel=3)
         return torch.load(name, map_location=map_location, weights_only=False)
 
 
@@ -52,10 +60,12 @@ def load_state_dict(module, state_dict, strict=False, revise_keys=((r'^module\.'
     return missing, unexpected, mismatched
 
 
-def load_checkpoint(model, filename, map_location='cpu', strict=False, revise_keys=((r'^module\.', ''),), prefix=None, quiet=False):
+def load_checkpoint(model, filename, map_location='cpu', strict=False, revise_keys=((r'^module\.', ''),), prefix=None, quiet=False,
+                    trusted=False):
     """mmcv.runner.load_checkpoint for a local file.  `prefix`: load only the entries under `prefix.` with the prefix removed
-    (e.g. 'img_backbone' to initialise a backbone from a detector checkpoint).  Returns the checkpoint dict."""
-    ckpt = _read(filename, map_location)
+    (e.g. 'img_backbone' to initialise a backbone from a detector checkpoint).  `trusted`: allow the full unpickler for files
+    the weights-only one refuses (see _read).  Returns the checkpoint dict; `ckpt['_load_report']` says what matched."""
+    ckpt = _read(filename, map_location, trusted)
     if not isinstance(ckpt, dict):
         raise RuntimeError(f'No state_dict found in checkpoint file {filename}')
     state = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
@@ -69,7 +79,8 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False, revise_ke
     if not quiet and (missing or unexpected or mismatched):
         warnings.warn(f'load_checkpoint({filename}): {len(missing)} missing, {len(unexpected)} unexpected, {len(mismatched)} size-mismatched '
                       f'entries; missing e.g. {missing[:3]}, unexpected e.g. {unexpected[:3]}', stacklevel=2)
-    ckpt['_load_report'] = dict(missing=missing, unexpected=unexpected, mismatched=mismatched)
+    ckpt['_load_report'] = dict(missing=missing, unexpected=unexpected, mismatched=mismatched,
+                                loaded=len(state) - len(unexpected) - len(mismatched), model_entries=len(target.state_dict()))
     return ckpt
 
 

@@ -40,7 +40,8 @@ struct Layout {
   int nxc;                        // x chunks per row
   int sched_heavy, sched_ratio;   // grid-0 row groups front-loaded 1:ratio among the others
   int flags;       // dhd_mghs_desc.flags
-  // scratch carve (device pointers): valid from prepare to the forward after it
+  // scratch carve (device pointers): valid from prepare to the forward after it (offset / s_ent: state carve when
+  // !compact, see make_layout)
   int* count;      // [V]     entries per voxel                      } one contiguous, zero-filled range per prepare:
   unsigned long long* scan_state;  // [n_chunks] chunk aggregates      } count | scan_state
   int* offset;     // [V+1]   exclusive prefix of count            (entry index space)
@@ -135,10 +136,12 @@ inline int make_layout(const dhd_mghs_desc* d, const dhd_mghs_workspace* ws, Lay
   L->count = carve((size_t)L->V);
   L->scan_state = reinterpret_cast<unsigned long long*>(carve(2 * (size_t)L->n_chunks));
   L->zero_bytes = off;
-  L->offset = carve((size_t)L->V + 1);
+  // generic (non-compact) path: its backward walks the grouped entry lists again (mghs_rows_bwd), so `offset` and
+  // `s_ent` belong to the STATE there (carved below); the compact backward needs neither
+  if (compact) L->offset = carve((size_t)L->V + 1);
   L->key = carve(P2);
   L->rnk = carve(P2);
-  L->s_ent = reinterpret_cast<int4*>(carve(4 * P2));
+  if (compact) L->s_ent = reinterpret_cast<int4*>(carve(4 * P2));
   L->cam = reinterpret_cast<float*>(carve((size_t)L->B * L->N * kCamFloats));
   L->dg_part = reinterpret_cast<float*>(carve(compact ? 0 : P2));
   L->fg_stage = reinterpret_cast<float*>(carve(compact ? 0 : (size_t)L->B * L->N * L->hw * L->C));
@@ -149,6 +152,10 @@ inline int make_layout(const dhd_mghs_desc* d, const dhd_mghs_workspace* ws, Lay
   L->nzoff = carve((size_t)L->V + 1);
   L->nzvox = carve(max_slots);
   L->p_slot = carve(P2);
+  if (!compact) {
+    L->offset = carve((size_t)L->V + 1);
+    L->s_ent = reinterpret_cast<int4*>(carve(4 * P2));
+  }
   const size_t state_need = off;
   if (state_bytes) *state_bytes = state_need;
   if (scratch_bytes) *scratch_bytes = scratch_need;

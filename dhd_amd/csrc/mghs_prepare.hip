@@ -464,14 +464,12 @@ int lift_impl(const dhd_mghs_desc* desc, const dhd_calib* calib, const float* he
     a.tr_vec = transpose_vectorisable(feat_nchw, feat_nhwc, L.C, L.hw) ? 1 : 0;
     a.n_tr = a.tr_cols_tiles * a.tr_rows_tiles * L.B * L.N;
   }
-  // static rig: grid 0's counters stay (up to the last whole 256-byte block of them: the few counters of grid 0 in the
-  // block shared with grid 1 are re-counted... they are not -- so the boundary must be aligned); the band grids'
-  // counters and the scan's chunk aggregates are cleared
+  // static rig: grid 0's counters stay, the band grids' counters and the scan's chunk aggregates are cleared.  The zero-fill
+  // works in 256-byte blocks, so the B * nz0 * ny0 * nx0 counters of grid 0 must end on a 256-byte boundary; where they do
+  // not (e.g. a 100 x 100 x 1 grid at B = 1) the call runs as a full lift, whose results are identical by contract.
   size_t keep = 0;
-  if (static_rig) {
-    keep = (size_t)L.vox_base[1] * 4;
-    if (keep & 255) return DHD_EUNSUPPORTED;   // B * nz0 * ny0 * nx0 counters of grid 0 must end on a 256-byte boundary
-  }
+  if (static_rig && (((size_t)L.vox_base[1] * 4) & 255)) static_rig = false;
+  if (static_rig) keep = (size_t)L.vox_base[1] * 4;
   a.zero_ptr = reinterpret_cast<char*>(L.count) + keep;
   a.zero_bytes = L.zero_bytes - keep;
   a.n_zero = dhd_cdiv((long)a.zero_bytes, kZeroBytesPerBlock);

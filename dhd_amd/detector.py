@@ -91,7 +91,17 @@ class ResNet(nn.Module):
             import warnings
             if os.path.isfile(str(pretrained)):
                 from .checkpoint import load_checkpoint
-                load_checkpoint(self, pretrained, strict=False, quiet=True)
+                rep = load_checkpoint(self, pretrained, strict=False, quiet=True)['_load_report']
+                # expected leftovers: torchvision's `fc.*` (unexpected) and `num_batches_tracked` (already filtered).  A file with
+                # other key prefixes (a detector checkpoint: `img_backbone.*`) matches nothing and would leave the backbone at
+                # its random initialisation without a word
+                missing = [k for k in rep['missing']]
+                if rep['loaded'] == 0:
+                    raise RuntimeError(f'ResNet(pretrained={pretrained!r}): no entry of the file matches this backbone (keys such as '
+                                       f'{rep["unexpected"][:3]}); for a detector checkpoint use load_checkpoint(..., prefix="img_backbone")')
+                if missing or rep['mismatched']:
+                    warnings.warn(f'ResNet(pretrained={pretrained!r}): {len(missing)} backbone entries not in the file (e.g. {missing[:3]}), '
+                                  f'{len(rep["mismatched"])} with another shape; they keep their random initialisation', stacklevel=2)
             else:
                 warnings.warn(f'ResNet(pretrained={pretrained!r}): checkpoint loading is not implemented for this scheme (no network, no '
                               'torchvision), weights stay at their random initialisation; pass a local file or load a state dict explicitly',

@@ -137,7 +137,9 @@ typedef struct dhd_calib {
 
 /* Device memory of a view transform, in two caller-owned parts (both 256-byte aligned, DHD_EINVAL otherwise):
  *   state   : what dhd_mghs_backward needs from dhd_mghs_prepare -- per-voxel slot prefix, voxel id of every slot, per-point
- *             slots (about 28 MB at DHD-S, B = 4).  One per prepare whose backward is still to come.
+ *             slots (about 28 MB at DHD-S, B = 4); for layouts off the compact path (C != 64 or grid shapes the segment
+ *             writer does not cover) also the grouped entry lists and their per-voxel offsets, which that backward walks
+ *             again.  One per prepare whose backward is still to come.
  *   scratch : everything else (counters, sort keys, the grouped entry lists, the compact per-voxel table: about 0.45 GB at
  *             DHD-S, B = 4).  Valid from a prepare to the forward that follows it; dhd_mghs_backward uses it as plain scratch.
  *             Calls that share a scratch must be ordered on one stream; any number of states may share it. */

@@ -504,7 +504,9 @@ def test_checkpoint_ingestion_for_the_reference_key_names(tmp_path):
     dst = dhd_amd.build_detector(cfg)
     assert not torch.equal(dst.state_dict()[ref_keys[0]], sd[ref_keys[0]])
     ckpt = dhd_amd.load_checkpoint(dst, str(path), strict=True)
-    assert ckpt['meta']['epoch'] == 24 and ckpt['_load_report'] == dict(missing=[], unexpected=[], mismatched=[])
+    rep = ckpt['_load_report']
+    assert ckpt['meta']['epoch'] == 24 and (rep['missing'], rep['unexpected'], rep['mismatched']) == ([], [], [])
+    assert rep['loaded'] == rep['model_entries'] == len(sd)
     for k, v in dst.state_dict().items():
         assert torch.equal(v, sd[k]), k
     # a backbone-only file in torchvision's layout (its classifier `fc` is not part of the trunk)
@@ -516,6 +518,20 @@ def test_checkpoint_ingestion_for_the_reference_key_names(tmp_path):
         warnings.simplefilter('error')            # a local file loads without the "not implemented" warning
         net = ResNet(depth=50, out_indices=(2, 3), pretrained=str(tv_path))
     assert torch.equal(net.layer3[5].conv2.weight, sd['img_backbone.layer3.5.conv2.weight'])
+    # a detector checkpoint handed to the backbone matches nothing: an error, not a silent random initialisation
+    with pytest.raises(RuntimeError, match='no entry of the file matches'):
+        ResNet(depth=50, out_indices=(2, 3), pretrained=str(path))
+    # a file the weights-only unpickler refuses is not retried with the code-executing one unless the caller says so
+    import pickle
+
+    class _Payload:
+        def __reduce__(self):
+            return (print, ('unpickled',))
+    torch.save(dict(meta=dict(env=_Payload()), state_dict=tv), tmp_path / 'odd.pth')
+    with pytest.raises((RuntimeError, pickle.UnpicklingError)):
+        dhd_amd.load_checkpoint(net, str(tmp_path / 'odd.pth'), quiet=True)
+    with pytest.warns(UserWarning, match='full unpickler'):
+        dhd_amd.load_checkpoint(net, str(tmp_path / 'odd.pth'), quiet=True, trusted=True)
     # prefix selection, size mismatch reporting, and the schemes that cannot be served
     net2 = ResNet(depth=50, out_indices=(2, 3))
     rep = dhd_amd.load_checkpoint(net2, str(path), prefix='img_backbone', quiet=True)['_load_report']

@@ -286,6 +286,34 @@ def test_view_transform_channel_counts_vs_oracle(gpu, channels):
     np.testing.assert_allclose(grads[1], fg, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('channels', [24, 64])
+def test_backward_after_another_prepare_on_the_shared_scratch(gpu, channels):
+    """fwd(plan A), fwd(plan B), bwd(plan A) with both plans on the stream's shared scratch: the backward of A may only
+    depend on A's STATE (include/dhd_amd.h: the scratch is valid from a prepare to the forward after it).  channels = 24
+    takes the generic (non-compact) path, whose backward walks the grouped entry lists again; 64 the compact one."""
+    from oracle import mghs_oracle as O
+    from dhd_amd import mghs_op
+    cfg = small_dhds_cfg()
+    runs = []
+    for k in range(2):   # A, then B with another calibration and other inputs (same sizes: the same shared scratch)
+        calib_np = syn.make_calibration(170 + k, 1, 3, cfg['input_size'])
+        depth, feat, hidx = syn.lift_inputs(180 + k, 1, 3, 44, 4, 11, channels, 65)
+        plan, axes = make_plan(cfg, 1, 3, channels=channels)
+        calib, keep = device_calib(calib_np, axes, gpu)
+        height = T(syn.height_probs_from_index(hidx, len(cfg['height_range'])), gpu)
+        dt, ft = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+        outs = mghs_op.mghs_lift_pool(plan, calib, height, cfg['height_range'], cfg['mask_range'], dt, ft)   # shared scratch
+        runs.append((calib_np, depth, feat, hidx, dt, ft, outs, keep))
+    assert runs[0][6][0].grad_fn is not None
+    for k in (0, 1):     # A's backward comes after B's prepare + forward
+        calib_np, depth, feat, hidx, dt, ft, outs, _ = runs[k]
+        ws = [syn.hash_signed(700 + 10 * k + i, tuple(o.shape)) for i, o in enumerate(outs)]
+        sum((o * T(w, gpu)).sum() for o, w in zip(outs, ws)).backward()
+        dg, fg = O.view_transform_backward(cfg, calib_np, depth, feat, hidx, ws)
+        np.testing.assert_allclose(dt.grad.cpu().numpy(), dg, atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(ft.grad.cpu().numpy(), fg, atol=2e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize('name,input_size', [('DHD-M', (256, 704)), ('DHD-L', (512, 1408))])
 def test_dhd_m_and_l_geometry_vs_oracle(gpu, name, input_size):
     """BASELINE configs 4/5 geometry (DHD-M.py / DHD-L.py: depth bins 0.5 m -> D = 88; L: 512x1408 images ->
@@ -888,6 +916,31 @@ def test_static_lift_full_size_is_bit_identical_to_a_full_lift(gpu):
                 assert kept[0] > 400000
             else:
                 assert k_now[0] == kept[0] and k_now[1:] != kept[1:]      # grid 0's grouping is the static part, the bands moved
+
+
+def test_static_lift_with_unaligned_grid0_counters_equals_a_full_lift(gpu):
+    """SURVEY 8(d) config 1 (50 x 50 x 1 full-height grid, B = 1): grid 0's 2 500 counters do not end on a 256-byte
+    boundary, which the static lift's block-wise zero-fill needs -- dhd_mghs_lift_static must then run as a full lift
+    (identical results by contract) instead of refusing the second frame of an accelerate=True module."""
+    from dhd_amd import mghs_op
+    cfg = syn.smoke_config()
+    calib_np = syn.make_calibration(421, 1, 1, cfg['input_size'])
+    plan, axes = make_plan(cfg, 1, 1, channels=16)
+    assert (plan.grids[0].n[0] * plan.grids[0].n[1] * plan.grids[0].n[2] * 4) % 256 != 0
+    calib, keep = device_calib(calib_np, axes, gpu)
+    ws_static = plan.new_workspace(gpu, private_scratch=True)
+    nh = len(cfg['height_range'])
+    with torch.no_grad():
+        for frame in range(3):
+            depth, feat, hidx = syn.lift_inputs(430 + 5 * frame, 1, 1, 44, 4, 11, 16, nh)
+            height = T(syn.height_probs_from_index(hidx, nh), gpu)
+            a = mghs_op.mghs_lift_pool(plan, calib, height, cfg['height_range'], cfg['mask_range'], T(depth, gpu), T(feat, gpu),
+                                       ws_static, static=frame > 0)
+            b = mghs_op.mghs_lift_pool(plan, calib, height, cfg['height_range'], cfg['mask_range'], T(depth, gpu), T(feat, gpu),
+                                       plan.new_workspace(gpu, private_scratch=True))
+            for k, (x, y) in enumerate(zip(a, b)):
+                np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), atol=1e-6, rtol=1e-6, err_msg=str((frame, k)))
+            assert a[0].abs().sum() > 0
 
 
 def test_mghs_step_is_graph_capturable(gpu):
