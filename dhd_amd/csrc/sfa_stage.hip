@@ -31,15 +31,12 @@
 // Forward reads x three times and y1/y2 twice; nothing is transposed, there is no NHWC detour.
 #include <stdlib.h>
 
-#include <type_traits>
-#include <utility>
+#include "sfa_gemm_cu.h"
+#include "sfa_mfma.h"
 
-#include "common.h"
+using namespace dhd_sfa;
 
 namespace {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kEwBlock = 256;     // element-wise / reduction kernels
 constexpr int kPlaneChunks = 4;   // blocks per (b, c) plane
@@ -799,38 +796,7 @@ __global__ __launch_bounds__(kPwBlock, 2) void pw_gemm_kernel(const float* __res
 // NaN/Inf inputs propagate as NaN (Inf - Inf in the split) rather than Inf.
 // ------------------------------------------------------------------------------------------------
 
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-
-// two floats -> packed bf16 pairs (a in the low half = lower k) of the three terms.
-// Round-to-nearest-even cuts (v_cvt_pk_bf16_f32, one instruction per pair): h = bf16(x), m = bf16(x - h),
-// l = bf16(x - h - m).  The residuals are exact in float32 (x - h has at most 16 significant bits, x - h - m at most
-// 8, so l is exact too): h + m + l == x.  Compared with cuts by truncation the parts are up to 4x smaller
-// (|x - h| <= 2^-9 |x|, |x - h - m| <= 2^-17 |x|), which matters for the three-product mode where the terms
-// am*bm, al*bh, ah*bl are dropped: worst case 3 * 2^-18 |ab| per product.
-using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-__device__ __forceinline__ unsigned pack_bf16(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
-__device__ __forceinline__ f32x2 unpack_bf16(unsigned p) {
-  f32x2 r = {__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)};
-  return r;
-}
-__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-  const f32x2 x = {a, b};
-  h = pack_bf16(x);
-  const f32x2 r1 = x - unpack_bf16(h);
-  m = pack_bf16(r1);
-  l = pack_bf16(r1 - unpack_bf16(m));
-}
-__device__ __forceinline__ void split2_hm(float a, float b, unsigned& h, unsigned& m) {
-  const f32x2 x = {a, b};
-  h = pack_bf16(x);
-  m = pack_bf16(x - unpack_bf16(h));
-}
-
-__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
+// (vector types, split2 / split2_hm / mfma_bf16: sfa_mfma.h)
 
 // Weight (rows x k; or its transpose) -> LDS images of the MFMA B operand, one image per 16 input
 // channels, three bf16 terms:  packed16[(((rb*KC + kc)*COT + t)*3 + term)*64 + lane] (16-byte units) holds
@@ -1119,6 +1085,7 @@ struct PackJob {
   const float* w[2];     // conv1, conv2
   u32x4* dst[4];         // conv1, conv2, conv1^T, conv2^T
   int c, cob, nt, blocks_each;
+  int cu;                // images for pw_gemm_cu_kernel (sfa_gemm_cu.h: A fragments, one 32-channel tile after the other)
 };
 
 __global__ __launch_bounds__(kEwBlock) void plane_mean_pack_kernel(const float* __restrict__ x, float* __restrict__ part, int hw,
@@ -1128,29 +1095,11 @@ __global__ __launch_bounds__(kEwBlock) void plane_mean_pack_kernel(const float* 
   const int pb = ((int)blockIdx.y - n_planes) * kPlaneChunks + (int)blockIdx.x;
   const int which = pb / job.blocks_each;
   if (which >= 4) return;
-  pack_weight_res_block(job.w[which & 1], which >> 1, job.dst[which], job.c, job.cob, job.nt, pb % job.blocks_each);
+  if (job.cu) cu_pack_weight(job.w[which & 1], which >> 1, job.dst[which], job.c, (pb % job.blocks_each) * kEwBlock + (int)threadIdx.x);
+  else pack_weight_res_block(job.w[which & 1], which >> 1, job.dst[which], job.c, job.cob, job.nt, pb % job.blocks_each);
 }
 
 constexpr int kResTrPitch = 36;
-// word with lane L replaced by the wave-uniform value sval (v_writelane_b32: one VALU instruction).  gfx940+ needs two
-// wait states between a VALU write of an SGPR (the v_cmp that made sval) and a VALU read of it; the compiler inserts
-// them for its own instructions but cannot see into inline assembly (without them: stale pass bits, found by the
-// full-size parity test).
-template <int L>
-__device__ __forceinline__ int write_lane(int word, int sval) {
-  asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(sval), "n"(L));
-  return word;
-}
-
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {   // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), straight-line
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
 template <int NT, int COB, int KCN, bool TWO_IN, bool RELU, int EPI, int WAVES, int AUX, int DPF>
 __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
                                                                     size_t in_bstride, unsigned in_bytes, const float* __restrict__ coef,
@@ -2083,7 +2032,9 @@ SavedLayout saved_layout(int b, int c, int hw, int r) {
   // backward | kTickWords others; zeroed by the forward (fc_forward_kernel), left at zero by every kernel that uses them
   L.tick = take(2 * (size_t)c + kTickWords);
   L.wp1t = take(2 * (size_t)c * c); L.wp2t = take(2 * (size_t)c * c);   // transposed weight images, packed by the forward for the backward
-  L.mask = take((size_t)b * c * ((hw + 31) / 32));  // ReLU pass bits, one word per (32 pixels, channel): [sample][wave tile][channel]
+  // ReLU pass bits: one word per (32 pixels, channel), [sample][wave tile][channel] (resident / streamed kernels), or two per
+  // (32 pixels, channel) in the staging lanes' order (cu kernels, sfa_gemm_cu.h: cu_mask_words)
+  L.mask = take((size_t)2 * b * c * ((hw + 31) / 32));
   L.y1 = take((size_t)b * c * hw);
   L.y2 = take((size_t)b * c * hw);
   L.total = o;
@@ -2188,6 +2139,62 @@ int cu_count() {
   return n[dev];
 }
 
+// One-CU-per-pixel-tile kernels (sfa_gemm_cu.h): the default precision (bf16x3) at the channel counts whose weight fragments
+// fit the register file of a CU -- C = 256 (8 waves x 32 channels) and C = 128 (4 waves).  C = 512 (1 MB of fragments) and the
+// bf16x6 precision (three parts) stay on the LDS-resident / streamed kernels.
+inline bool cu_supported(int c) { return g_gemm_mode == 3 && (c == 128 || c == 256); }
+
+int launch_pw_gemm_cu(const float* in0, const float* in1, size_t in_bstride, int in_channels, const float* coef, bool relu, const float* wp,
+                      const float* bias, unsigned* relu_mask, float* stat_part, float* y, int epi, int b, int c, int hw, hipStream_t st,
+                      int* stat_rows) {
+  const int waves = c == 256 ? 8 : 4;
+  const int max_b = cu_max_batch(c, waves);
+  if (max_b < 1) return DHD_EUNSUPPORTED;
+  const bool two = in1 != nullptr;
+  const unsigned in_bytes = (unsigned)((size_t)in_channels * hw * sizeof(float));
+  const int nwt = (hw + 31) / 32;
+  int cus = cu_count();
+  if (cus <= 0) cus = 256;
+  int rows_done = 0;
+  for (int b0 = 0; b0 < b; b0 += max_b) {
+    const int nb = b - b0 < max_b ? b - b0 : max_b;
+    const long total = (long)nb * nwt;
+    const int grid = (int)(total < cus ? total : cus);
+    const size_t shmem = cu_lds_bytes(c, waves, nb);
+    const float* i0 = in0 + (size_t)b0 * in_bstride;
+    const float* i1 = two ? in1 + (size_t)b0 * in_bstride : nullptr;
+    const float* cf = coef + (size_t)b0 * 3 * c;
+    unsigned* rm = relu_mask ? relu_mask + cu_mask_words(b0, c, hw) : nullptr;
+    float* sp = stat_part ? stat_part + (size_t)rows_done * 2 * c : nullptr;
+    rows_done += grid;                                   // one statistics row per workgroup
+    float* yo = y + (size_t)b0 * c * hw;
+    // <KCN, WAVES, TWO_IN, RELU, EPI, RECORD, AUX = nt loads, R = 1, NACC = 1, ABL = 0, SAUX = 0, PP = ping-pong>, contiguous tile ranges
+#define DHD_CU(KCN, WAVES, TWO, RELU, EPI, REC)                                                                          \
+  do {                                                                                                                \
+    auto kern = pw_gemm_cu_kernel<KCN, WAVES, TWO, RELU, EPI, REC, 2, 1, 1, 0, 0, true>;                              \
+    DHD_LDS_ATTR_ONCE(kern, kLdsBytes);                                                                               \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), shmem, st, i0, i1, in_bstride, in_bytes, cf,               \
+                       reinterpret_cast<const u32x4*>(wp), bias, rm, sp, yo, hw, nb, 1);                              \
+  } while (0)
+#define DHD_CU_V(KCN, WAVES)                                                                       \
+  do {                                                                                             \
+    if (epi == 0 && two && !relu) DHD_CU(KCN, WAVES, true, false, 0, false);                       \
+    else if (epi == 0 && !two && relu && rm) DHD_CU(KCN, WAVES, false, true, 0, true);             \
+    else if (epi == 0 && !two && relu) DHD_CU(KCN, WAVES, false, true, 0, false);                  \
+    else if (epi == 1 && two && !relu) DHD_CU(KCN, WAVES, true, false, 1, false);                  \
+    else if (epi == 2 && two && !relu) DHD_CU(KCN, WAVES, true, false, 2, false);                  \
+    else return DHD_EUNSUPPORTED;                                                                  \
+  } while (0)
+    if (c == 256) DHD_CU_V(16, 8);
+    else DHD_CU_V(8, 4);
+#undef DHD_CU_V
+#undef DHD_CU
+    DHD_LAUNCH_CHECK();
+  }
+  if (stat_rows) *stat_rows = rows_done;
+  return DHD_OK;
+}
+
 int launch_pack(const float* w, int transpose, float* packed, int c, hipStream_t st, const float* w2 = nullptr,
                 float* packed2 = nullptr) {
   const int cot = pw_cot(c);
@@ -2279,6 +2286,8 @@ int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in
                    const float* bias, const float* aux, const float* aux_scsh, unsigned* relu_mask, float* stat_part, float* y, int epi, int b,
                    int c, int hw, hipStream_t st, int* stat_rows = nullptr) {
   if (stat_rows) *stat_rows = b * ((hw + 31) / 32);   // the streamed kernels: a row per (sample, wave tile)
+  if (cu_supported(c))
+    return launch_pw_gemm_cu(in0, in1, in_bstride, in_channels, coef, relu, wp, bias, relu_mask, stat_part, y, epi, b, c, hw, st, stat_rows);
   if (res_supported(c))
     return launch_pw_gemm_res(in0, in1, in_bstride, in_channels, coef, relu, wp, bias, relu_mask, stat_part, y, epi, b, c, hw, st,
                               stat_rows);
@@ -2467,7 +2476,7 @@ static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, float* o
       job.w[0] = w->conv1_w; job.w[1] = w->conv2_w;
       job.dst[0] = reinterpret_cast<u32x4*>(sc + T.wp1); job.dst[1] = reinterpret_cast<u32x4*>(sc + T.wp2);
       job.dst[2] = reinterpret_cast<u32x4*>(sv + S.wp1t); job.dst[3] = reinterpret_cast<u32x4*>(sv + S.wp2t);
-      job.c = c; job.nt = mode_terms(); job.cob = res_cob(c, job.nt);
+      job.c = c; job.nt = mode_terms(); job.cob = res_cob(c, job.nt); job.cu = cu_supported(c) ? 1 : 0;
       job.blocks_each = dhd_cdiv((c / 32) * (c / 16) * 64, kEwBlock);
       const dim3 grid(kPlaneChunks, b * 2 * c + dhd_cdiv(4 * job.blocks_each, kPlaneChunks));
       hipLaunchKernelGGL(plane_mean_pack_kernel, grid, dim3(kEwBlock), 0, st, x, sc + T.mean_part, hw, b * 2 * c, job);

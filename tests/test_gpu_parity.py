@@ -925,7 +925,11 @@ def test_static_lift_with_unaligned_grid0_counters_equals_a_full_lift(gpu):
     from dhd_amd import mghs_op
     cfg = syn.smoke_config()
     calib_np = syn.make_calibration(421, 1, 1, cfg['input_size'])
-    plan, axes = make_plan(cfg, 1, 1, channels=16)
+    from oracle import mghs_oracle as O
+    axes = O.frustum_axes(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    full = {a: cfg['grid_config'][a] for a in 'xyz'}            # the smoke configuration's own 50 x 50 x 1 full-height grid
+    grids = [mghs_op.grid_from_cfg(g) for g in (full, cfg['mask_1_grid'], cfg['mask_2_grid'], cfg['mask_3_grid'])]
+    plan = mghs_op.Plan(1, 1, len(axes[2]), 4, 11, 16, grids)
     assert (plan.grids[0].n[0] * plan.grids[0].n[1] * plan.grids[0].n[2] * 4) % 256 != 0
     calib, keep = device_calib(calib_np, axes, gpu)
     ws_static = plan.new_workspace(gpu, private_scratch=True)
