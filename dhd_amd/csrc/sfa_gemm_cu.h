@@ -79,7 +79,8 @@ __device__ __forceinline__ void cu_pack_weight(const float* __restrict__ w, int 
 // 8 no activation loads (stale registers are staged), 16 no staging, 32 no B-fragment LDS reads (MFMAs on registers),
 // 64 shader clocks of the workgroup (s_memtime) into stat_part, 128 s_sleep in place of the MFMAs (with 1), 256 shader clocks per
 // phase and wave into stat_part
-template <int KCN, int WAVES, bool TWO_IN, bool RELU, int EPI, bool RECORD, int AUX, int R, int NACC, int ABL = 0, int SAUX = 0, bool PP = false>
+template <int KCN, int WAVES, bool TWO_IN, bool RELU, int EPI, bool RECORD, int AUX, int R, int NACC, int ABL = 0, int SAUX = 0, bool PP = false,
+          int BPF = 0, int EORD = 0>
 __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_cu_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
                                                                    size_t in_bstride, unsigned in_bytes, const float* __restrict__ coef,
                                                                    const u32x4* __restrict__ wp, const float* __restrict__ bias,
@@ -261,18 +262,36 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_cu_kernel(const float* 
     const unsigned char* src = cu_lds + PAR * BUFB;
     // NACC = 2: acc holds W_h X_h, acc2 the two small terms W_m X_h + W_h X_m (two independent MFMA chains, 16 more registers)
     f32x16 acc[MT], acc2[NACC == 2 ? MT : 1];
-    static_for<KCN>([&](auto ksc) {
+    // B fragments are requested BPF K-steps ahead of their MFMAs (BPF = 2: 8 more registers; in the ping-pong form a wave has no
+    // partner's MFMAs to cover its LDS latency during the MFMA phase)
+    u32x4 bfh[BPF + 1], bfm[BPF + 1];
+    auto frag = [&](auto ksc) {
       constexpr int ks = decltype(ksc)::value;
+      if (BPF == 0 && ks > 0) return;
       // (the XOR as an opaque instruction: hipcc would otherwise keep all eight swizzled addresses in registers)
       int a;
       asm("v_xor_b32 %0, %1, %2" : "=v"(a) : "n"(((2 * ks) & 15) << 4), "v"(rbase));
       a += (ks >> 3) * 256;
-      u32x4 bh, bm;
       if (ABL & 32) {                                                // no fragment reads: the MFMAs run on a register
-        bh = wh[(ks + 1) % KCN][0]; bm = wm[(ks + 1) % KCN][0];
+        bfh[ks % (BPF + 1)] = wh[(ks + 1) % KCN][0]; bfm[ks % (BPF + 1)] = wm[(ks + 1) % KCN][0];
       } else {
+        bfh[ks % (BPF + 1)] = *reinterpret_cast<const u32x4*>(src + a);
+        bfm[ks % (BPF + 1)] = *reinterpret_cast<const u32x4*>(src + PARTB + a);
+      }
+    };
+    static_for<BPF>([&](auto ksc) { frag(ksc); });
+    static_for<KCN>([&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      u32x4 bh, bm;
+      if constexpr (BPF == 0) {                                      // requested where they are used: the compiler's own schedule
+        int a;
+        asm("v_xor_b32 %0, %1, %2" : "=v"(a) : "n"(((2 * ks) & 15) << 4), "v"(rbase));
+        a += (ks >> 3) * 256;
         bh = *reinterpret_cast<const u32x4*>(src + a);
         bm = *reinterpret_cast<const u32x4*>(src + PARTB + a);
+      } else {
+        if constexpr (ks + BPF < KCN) frag(std::integral_constant<int, ks + BPF>{});
+        bh = bfh[ks % (BPF + 1)]; bm = bfm[ks % (BPF + 1)];
       }
       if (ABL & 128) __builtin_amdgcn_s_sleep(4);                    // (with ABL & 1) the MFMA phase's duration without its MFMAs
       if (ABL & 1) {
@@ -297,12 +316,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_cu_kernel(const float* 
     });
     stamp(0);                                                        // MFMA phase (issue; the last MFMAs may still run)
     if (PP) cu_lds_barrier();
+    auto next_tile = [&]() {
     // ---- next tile: registers -> other buffer, then the set is free for the tile R further on ------------------------------
     // (ping-pong: the late group is a whole tile ahead with its staging -- tile t + 2 into the buffer it has just read)
     stage(std::integral_constant<int, SN>{}, (PAR ^ 1) ^ grp, t + (1 + grp) * t_step);
     stamp(1);                                                        // wait for the loads + staging
     issue(std::integral_constant<int, SN>{}, t + (1 + grp + R) * t_step);
     stamp(2);                                                        // load issue
+    };
+    auto epilogue = [&]() {
     // ---- epilogue: transposition through the wave's patch, row-wise 16-byte stores -------------------------------------
     const __amdgpu_buffer_rsrc_t ry =
         __builtin_amdgcn_make_buffer_rsrc(y + (size_t)b * C * hw, 0, (unsigned)((size_t)C * hw * sizeof(float)), 0x00020000);
@@ -338,6 +360,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_cu_kernel(const float* 
         if (!(ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, voff_st, soff, SAUX);
       }
     }
+    };
+    // EORD = 1: the epilogue (which needs nothing from memory) before the staging (which waits for the next tile's loads)
+    if (EORD == 0) { next_tile(); epilogue(); } else { epilogue(); next_tile(); }
     stamp(3);                                                        // epilogue incl. store issue
     cu_lds_barrier();
   };

@@ -2168,10 +2168,12 @@ int launch_pw_gemm_cu(const float* in0, const float* in1, size_t in_bstride, int
     float* sp = stat_part ? stat_part + (size_t)rows_done * 2 * c : nullptr;
     rows_done += grid;                                   // one statistics row per workgroup
     float* yo = y + (size_t)b0 * c * hw;
-    // <KCN, WAVES, TWO_IN, RELU, EPI, RECORD, AUX = nt loads, R = 1, NACC = 1, ABL = 0, SAUX = 0, PP = ping-pong>, contiguous tile ranges
+    // <KCN, WAVES, TWO_IN, RELU, EPI, RECORD, AUX = nt loads, R = 1, NACC = 1, ABL = 0, SAUX = 0, PP = ping-pong, BPF = 0, EORD>,
+    // contiguous tile ranges.  EORD: with two inputs the epilogue goes before the staging (which waits for twice the loads), with
+    // one input after it -- measured either way (experiments/gemm_cu_bench.hip): 100 vs 107 us (conv1), 96 vs 97 (dgrad), 82 vs 76 (conv2)
 #define DHD_CU(KCN, WAVES, TWO, RELU, EPI, REC)                                                                          \
   do {                                                                                                                \
-    auto kern = pw_gemm_cu_kernel<KCN, WAVES, TWO, RELU, EPI, REC, 2, 1, 1, 0, 0, true>;                              \
+    auto kern = pw_gemm_cu_kernel<KCN, WAVES, TWO, RELU, EPI, REC, 2, 1, 1, 0, 0, true, 0, (TWO) ? 1 : 0>;           \
     DHD_LDS_ATTR_ONCE(kern, kLdsBytes);                                                                               \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), shmem, st, i0, i1, in_bstride, in_bytes, cf,               \
                        reinterpret_cast<const u32x4*>(wp), bias, rm, sp, yo, hw, nb, 1);                              \

@@ -162,10 +162,6 @@ int main(int argc, char** argv) {
   RUNP(8, true, false, 0, false, 2, 1, 1, 0, 0, true, 1, "8w conv1 (bias+stats), PING-PONG");
   RUNP(8, false, true, 0, true, 2, 1, 1, 0, 0, true, 1, "8w conv2 (relu+record), PING-PONG");
   RUNP(8, true, false, 1, false, 2, 1, 1, 0, 0, true, 1, "8w dgrad2 (mask), PING-PONG");
-  RUNA(8, true, false, 2, false, 2, 1, 1, 64 + 256, 1, "8w two-in plain, R=1, phase clocks");
-  RUNA(8, true, false, 2, false, 2, 1, 1, 64 + 256 + 1, 1, "  R=1 no MFMA, phase clocks");
-  RUNA(8, true, false, 2, false, 2, 1, 1, 64 + 256 + 1 + 128, 1, "  R=1 no MFMA but sleeping, phase clocks");
-  RUNA(8, true, false, 2, false, 2, 1, 1, 64 + 256 + 8, 1, "  R=1 no loads, phase clocks");
   // ---- A/B against the resident-weights kernel of the product (teams of two CUs), alternating, same process ---------------
   {
     float* wpres; float* statres;
@@ -178,28 +174,31 @@ int main(int argc, char** argv) {
     auto old_dgrad = [&] { int rows; launch_pw_gemm_res(x, x + plane, 2 * plane, C, coef, false, wpres, nullptr, nullptr, nullptr, y, 2, B, C, HW, 0, &rows); };
     auto old_conv2 = [&] { int rows; launch_pw_gemm_res(x, nullptr, 2 * plane, C, coef, true, wpres, bias, mask, statres, y, 0, B, C, HW, 0, &rows); };
 #define NEWK(WAVES, TWO, RELU, EPI, REC, AUX, RR, NACC, contig) NEWP(WAVES, TWO, RELU, EPI, REC, AUX, RR, NACC, false, contig)
-#define NEWP(WAVES, TWO, RELU, EPI, REC, AUX, RR, NACC, PP, contig)                                                            \
+#define NEWP(WAVES, TWO, RELU, EPI, REC, AUX, RR, NACC, PP, contig) NEWQ(WAVES, TWO, RELU, EPI, REC, AUX, RR, NACC, PP, 0, 0, contig)
+#define NEWQ(WAVES, TWO, RELU, EPI, REC, AUX, RR, NACC, PP, BPF, EORD, contig)                                                            \
     [&] {                                                                                                                  \
-      auto kern = pw_gemm_cu_kernel<KCN, WAVES, TWO, RELU, EPI, REC, AUX, RR, NACC, 0, 0, PP>;                                 \
+      auto kern = pw_gemm_cu_kernel<KCN, WAVES, TWO, RELU, EPI, REC, AUX, RR, NACC, 0, 0, PP, BPF, EORD>;                                 \
       const size_t lds = cu_lds_bytes(C, WAVES, B);                                                                        \
       static bool once = false;                                                                                            \
       if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
       hipLaunchKernelGGL(kern, dim3(cus), dim3(WAVES * 64), lds, 0, x, TWO ? x + plane : nullptr, 2 * plane,               \
                          (unsigned)(plane * 4), coef, wp, bias, mask, stat, y, HW, B, contig);                             \
     }
-    auto n_conv1_r1 = NEWK(8, true, false, 0, false, 2, 1, 1, 1);
-    auto n_conv1_pp = NEWP(8, true, false, 0, false, 2, 1, 1, true, 1);
-    auto n_dgrad_r1 = NEWK(8, true, false, 2, false, 2, 1, 1, 1);
-    auto n_dgrad_pp = NEWP(8, true, false, 2, false, 2, 1, 1, true, 1);
-    auto n_dgrad_ppi = NEWP(8, true, false, 2, false, 2, 1, 1, true, 0);
-    auto n_dgrad2_pp = NEWP(8, true, false, 1, false, 2, 1, 1, true, 1);
-    auto n_conv2_r1 = NEWK(8, false, true, 0, true, 2, 1, 1, 1);
-    auto n_conv2_pp = NEWP(8, false, true, 0, true, 2, 1, 1, true, 1);
+    auto c1_0 = NEWQ(8, true, false, 0, false, 2, 1, 1, true, 0, 1, 1);
+    auto c1_1 = NEWQ(8, true, false, 0, false, 2, 1, 1, true, 1, 1, 1);
+    auto dg_0 = NEWQ(8, true, false, 2, false, 2, 1, 1, true, 0, 1, 1);
+    auto dg_1 = NEWQ(8, true, false, 2, false, 2, 1, 1, true, 1, 1, 1);
+    auto dg_00 = NEWQ(8, true, false, 2, false, 2, 1, 1, true, 0, 0, 1);
+    auto c2_0 = NEWQ(8, false, true, 0, true, 2, 1, 1, true, 0, 1, 1);
+    auto c2_1 = NEWQ(8, false, true, 0, true, 2, 1, 1, true, 1, 1, 1);
+    auto c2_00 = NEWQ(8, false, true, 0, true, 2, 1, 1, true, 0, 0, 1);
+    auto d2_0 = NEWQ(8, true, false, 1, false, 2, 1, 1, true, 0, 1, 1);
     auto blend = [&] { hipLaunchKernelGGL(blend_kernel, dim3(cus * 8), dim3(512), 0, 0, (f32x4*)x, (f32x4*)(x + (size_t)B * plane), (f32x4*)y, (size_t)B * plane / 4, 0.5f, 0.25f); };
-    for (int round = 0; round < 3; ++round) {
-      printf("round %d:  blend %.1f | conv1 old %.1f new %.1f pp %.1f | dgrad old %.1f new %.1f pp %.1f pp-interleaved %.1f dgrad2(mask) pp %.1f | conv2 old %.1f new %.1f pp %.1f  (us)\n", round,
-             time_kernel(blend, 7), time_kernel(old_conv1, 7), time_kernel(n_conv1_r1, 7), time_kernel(n_conv1_pp, 7), time_kernel(old_dgrad, 7),
-             time_kernel(n_dgrad_r1, 7), time_kernel(n_dgrad_pp, 7), time_kernel(n_dgrad_ppi, 7), time_kernel(n_dgrad2_pp, 7), time_kernel(old_conv2, 7), time_kernel(n_conv2_r1, 7), time_kernel(n_conv2_pp, 7));
+    for (int round = 0; round < 4; ++round) {
+      printf("round %d:  blend %.1f | conv1 old %.1f epi-first bpf0 %.1f bpf1 %.1f | dgrad old %.1f epi-first bpf0 %.1f bpf1 %.1f epi-last bpf0 %.1f dgrad2 %.1f | conv2 old %.1f epi-first bpf0 %.1f bpf1 %.1f epi-last bpf0 %.1f  (us)\n", round,
+             time_kernel(blend, 7), time_kernel(old_conv1, 7), time_kernel(c1_0, 7), time_kernel(c1_1, 7),
+             time_kernel(old_dgrad, 7), time_kernel(dg_0, 7), time_kernel(dg_1, 7), time_kernel(dg_00, 7), time_kernel(d2_0, 7),
+             time_kernel(old_conv2, 7), time_kernel(c2_0, 7), time_kernel(c2_1, 7), time_kernel(c2_00, 7));
       CK(hipGetLastError());
     }
   }
