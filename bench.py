@@ -165,6 +165,13 @@ def parse():
     p.add_argument('--no-ddp-static-graph', dest='ddp_static_graph', action='store_false',
                    help='e2e under DDP: DistributedDataParallel(static_graph=False) (default: static_graph=True -- the step has the same '
                         'autograd graph every iteration; exercised with two ranks over gloo incl. the no_sync() comparison)')
+    p.add_argument('--repeats', type=int, default=7,
+                   help='hotpath: the timed loop of EXACTLY --steps steps is run this many times in the process (barrier + synchronize on both '
+                        'sides each time); ms_per_step / value are the median loop, min / max / all are reported beside it')
+    p.add_argument('--fresh-procs', type=int, default=2,
+                   help='hotpath, N = 1: repeat the whole measurement in this many fresh processes (other allocator placement of the 0.7 GB '
+                        'outputs: one build differs by up to 11 % on the writer between two processes on one box)')
+    p.add_argument('--child', action='store_true', help='(internal) a --fresh-procs child: print the timing statistics only')
     p.add_argument('--ddp-graph', action='store_true',
                    help='e2e under DDP: capture the whole step, RCCL all-reduces included, into a HIP graph (N = 1 always does; with N > 1 '
                         'it is opt-in because it cannot be validated on the one-GPU development box: falls back to eager on a capture error)')
@@ -861,16 +868,36 @@ def main():
         ddist.barrier()
         torch.cuda.synchronize()
 
-    hp.make_events((a.steps + 3) // 4)
-    with no_gc():   # a cyclic collection inside the timed steps is a 30-40 ms host pause in a 0.1 s region
-        fence()
-        t0 = time.perf_counter()
-        for k in range(a.steps):
-            # HIP events around the dominant kernel / the backward / the SFA stage on every 4th timed step (and the first): each
-            # recorded step carries seven extra marker packets and host calls, 35 us on a 0.34 ms MGHS-only step
-            hp.step(k % 4 == 0)
-        fence()
-        elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+    # R repeats of the timed loop of exactly K steps; each repeat has its own fences and its own event samples
+    def timed_loop(record=True):
+        hp.ev, hp.ev_bwd, hp.ev_sfa = [], [], []
+        hp.make_events((a.steps + 3) // 4)
+        with no_gc():   # a cyclic collection inside the timed steps is a 30-40 ms host pause in a 0.1 s region
+            fence()
+            t0 = time.perf_counter()
+            for k in range(a.steps):
+                # HIP events around the dominant kernel / the backward / the SFA stage on every 4th timed step (and the first): each
+                # recorded step carries seven extra marker packets and host calls, 35 us on a 0.34 ms MGHS-only step
+                hp.step(record and k % 4 == 0)
+            fence()
+            el = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+        parts = dict(writer_ms=event_mean(hp.ev), mghs_bwd_ms=event_mean(hp.ev_bwd)) if record else {}
+        if record and hp.ev_sfa:
+            parts['sfa_fwd_ms'] = event_mean([(e[0], e[1]) for e in hp.ev_sfa])
+            parts['sfa_bwd_ms'] = event_mean([(e[1], e[2]) for e in hp.ev_sfa])
+        return el, parts
+
+    reps = [timed_loop() for _ in range(max(1, a.repeats))]
+    per_step = sorted(1e3 * el / a.steps for el, _ in reps)
+    elapsed = float(np.median([el for el, _ in reps]))
+    stats = lambda v: dict(median=float(np.median(v)), min=float(np.min(v)), max=float(np.max(v)))
+    part_stats = {k: stats([p[k] for _, p in reps]) for k in reps[0][1]}
+    n_event_samples = len(hp.ev) * len(reps)
+    if a.child:   # a fresh-process repeat: the statistics only
+        if rank == 0:
+            print(json.dumps(dict(ms_per_step=stats(per_step), parts=part_stats, repeats=len(reps), steps=a.steps)), flush=True)
+        ddist.shutdown()
+        return
 
     # the same step with float32-level GEMM products in the SFA stage (bf16x6), W warm-ups + K timed steps
     elapsed_x6 = None
@@ -878,20 +905,14 @@ def main():
         main_gemm, hp.stage.gemm = hp.stage.gemm, 'bf16x6'
         for _ in range(a.warmup):
             hp.step(False)
-        with no_gc():
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                hp.step(False)
-            fence()
-            elapsed_x6 = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+        elapsed_x6 = float(np.median([timed_loop(False)[0] for _ in range(min(3, max(1, a.repeats)))]))
         hp.stage.gemm = main_gemm
     cal_ms, cal_bytes = hbm_calibration(dev, hp.pool_fwd_bytes)   # every rank runs it, rank 0 reports
     lift_us = lift_timing(hp)
 
     line = None
     if rank == 0:
-        kern_ms = event_mean(hp.ev)
+        kern_ms = part_stats['writer_ms']['median']
         achieved = hp.pool_fwd_bytes / (kern_ms * 1e-3) / 1e9
         line = dict(
             metric=f'samples/sec (6-cam fwd+bwd) {a.geometry.upper()} view-transform hot path', value=a.batch * world * a.steps / elapsed,
@@ -913,34 +934,41 @@ def main():
                           memset_ms=cal_ms['memset'], fill_ms=cal_ms['fill'], read_ms=cal_ms['read'], calibration_bytes=cal_bytes,
                           frac_of_fill=cal_ms['fill'] / kern_ms, frac_of_memset=cal_ms['memset'] / kern_ms,
                           fill_GBps=cal_bytes / (cal_ms['fill'] * 1e-3) / 1e9, read_GBps=cal_bytes / (cal_ms['read'] * 1e-3) / 1e9,
-                          event_samples=len(hp.ev)))
+                          launch_ms_min=part_stats['writer_ms']['min'], launch_ms_max=part_stats['writer_ms']['max'],
+                          event_samples=n_event_samples))
+        # the protocol: R in-process repeats of the K-step loop; the headline is the MEDIAN loop
+        line.update(repeats=len(reps), ms_per_step_min=per_step[0], ms_per_step_max=per_step[-1], ms_per_step_first=1e3 * reps[0][0] / a.steps,
+                    ms_per_step_all=[round(v, 5) for v in (1e3 * el / a.steps for el, _ in reps)], parts=part_stats)
         line['prepare'] = dict(lift_us, note='dhd_mghs_lift = height argmax -> band + context re-layout + geometry + grouping (4 launches, '
                                'every frame in training); dhd_mghs_lift_static = the same for a static rig at inference (SURVEY 8f-1)')
         if elapsed_x6 is not None:
             line['ms_per_step_bf16x6'] = 1e3 * elapsed_x6 / a.steps
             line['value_bf16x6'] = a.batch * world * a.steps / elapsed_x6
-        bwd_ms = event_mean(hp.ev_bwd)
+        bwd_ms = part_stats['mghs_bwd_ms']['median']
         bwd_ach = hp.pool_bwd_bytes / (bwd_ms * 1e-3) / 1e9
         line['roofline_bwd'] = dict(bound='hbm', kernel='mghs_stream_bwd + mghs_pixel_bwd (dhd_mghs_backward)', achieved=bwd_ach,
                                     peak=HBM_PEAK_GBPS, unit='GB/s', frac=bwd_ach / HBM_PEAK_GBPS,
                                     traffic=(lambda p: None if None in p else int(sum(p)))([pmc_traffic(k, a.batch) for k in ('mghs_stream_bwd', 'mghs_pixel_bwd')]),
                                     launch_ms=bwd_ms, algorithmic_bytes=hp.pool_bwd_bytes)
-        if hp.ev_sfa:
+        if 'sfa_fwd_ms' in part_stats:
             # second roofline, for the SFA stage operator as a whole (a dozen kernels per call): SURVEY 8(d) gives its forward
             # algorithmic traffic as x read twice + u/out written + the two 1x1 convs reading and writing (B,C,H,W) once each
-            fwd_ms = event_mean([(e[0], e[1]) for e in hp.ev_sfa])
-            bwd_ms = event_mean([(e[1], e[2]) for e in hp.ev_sfa])
+            fwd_ms, bwd_ms = part_stats['sfa_fwd_ms']['median'], part_stats['sfa_bwd_ms']['median']
             c, hw = 256, 200 * 200
             fwd_bytes = a.batch * 4 * hw * (2 * 2 * c + 4 * c)   # 2 reads of (2C,H,W) + 4 passes over (C,H,W) = 328 MB/sample
             gemm_flop = 2.0 * c * c * hw * a.batch
             line['roofline_sfa_stage'] = dict(
-                bound='hbm', kernel='dhd_sfa_stage_forward (plane_mean, fc, 2 x pw_gemm_res, stat reductions, blend2_bn)',
+                bound='hbm', kernel='dhd_sfa_stage_forward (plane_mean, fc, 2 x pw_gemm_cu, stat reductions, blend2_bn)',
                 achieved=fwd_bytes / (fwd_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit='GB/s',
                 frac=fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, traffic=sfa_forward_traffic(a.batch, 3 if a.sfa_gemm == 'bf16x6' else 2), launch_ms=fwd_ms,
                 algorithmic_bytes=fwd_bytes,
                 backward_ms=bwd_ms, gemm_tflops_fp32_equivalent=6 * gemm_flop / ((fwd_ms + bwd_ms) * 1e-3) / 1e12,
                 note='six C x C GEMMs per forward+backward; GEMM precision as config.sfa_gemm (include/dhd_amd.h: dhd_sfa_weights.gemm); '
                      'f32-MFMA peak is 157 TFLOP/s')
+    if rank == 0 and world == 1 and a.fresh_procs > 0:
+        t_stage = time.perf_counter()
+        line['fresh_processes'] = fresh_process_repeats(a)
+        print(f'[bench] {a.fresh_procs} fresh-process repeats {time.perf_counter() - t_stage:.1f} s', file=sys.stderr, flush=True)
     t_stage = time.perf_counter()
     if a.geometry == 'dhd-s' and not a.no_operator:
         with no_gc():
@@ -962,8 +990,28 @@ def main():
             line['e2e'] = e2e
             print(f'[bench] e2e leg {time.perf_counter() - t_stage:.1f} s', file=sys.stderr, flush=True)
     if rank == 0:
+        line['event_samples_dropped'] = dict(EVENT_DROPS)   # event intervals event_mean() left out as host stalls (> 3 x median)
         print(json.dumps(line), flush=True)
     ddist.shutdown()
+
+
+def fresh_process_repeats(a):
+    """The same W + R x K measurement in `--fresh-procs` new processes (N = 1): another placement of the 0.7 GB outputs and
+    scratch by the allocator, another clock / thermal state.  Returns their statistics (what --child prints)."""
+    import subprocess
+    out = []
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(a.steps), '--warmup', str(a.warmup), '--repeats', str(a.repeats),
+           '--batch', str(a.batch), '--geometry', a.geometry, '--child', '--fresh-procs', '0', '--cpu-samples', '0', '--no-e2e', '--no-operator']
+    cmd += (['--no-sfa'] if a.no_sfa else []) + (['--deterministic'] if a.deterministic else []) + (['--sfa-gemm', a.sfa_gemm] if a.sfa_gemm else [])
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    for _ in range(a.fresh_procs):
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            rows = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            out.append(json.loads(rows[-1]) if r.returncode == 0 and rows else dict(error=(r.stderr or r.stdout)[-300:]))
+        except Exception as exc:  # noqa: BLE001 -- the main line must still be printed
+            out.append(dict(error=f'{type(exc).__name__}: {exc}'[:300]))
+    return out
 
 
 if __name__ == '__main__':

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
-                          '--no-e2e', '--cpu-samples', '1'], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                          '--no-e2e', '--cpu-samples', '1', '--repeats', '3', '--fresh-procs', '1'], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -24,6 +24,16 @@ def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
     assert d['unit'] == 'samples/s' and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32'
     assert 'workload' in d['config'] and 'model' not in d['config']
     assert abs(d['value'] - 4 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']
+    # the protocol of the timed region: R repeats of the K-step loop, the headline is the median loop; per-part statistics; the
+    # same again from a fresh process
+    assert d['repeats'] == 3 and len(d['ms_per_step_all']) == 3 and d['ms_per_step_min'] <= d['ms_per_step'] <= d['ms_per_step_max']
+    for part in ('writer_ms', 'mghs_bwd_ms', 'sfa_fwd_ms', 'sfa_bwd_ms'):
+        st = d['parts'][part]
+        assert 0 < st['min'] <= st['median'] <= st['max']
+    assert abs(d['roofline']['launch_ms'] - d['parts']['writer_ms']['median']) < 1e-12
+    fp = d['fresh_processes']
+    assert len(fp) == 1 and 'error' not in fp[0] and fp[0]['repeats'] == 3 and fp[0]['ms_per_step']['median'] > 0
+    assert set(d['event_samples_dropped']) == {'dropped', 'total'} and d['event_samples_dropped']['dropped'] <= 0.1 * d['event_samples_dropped']['total'] + 1
     for name in ('roofline', 'roofline_bwd', 'roofline_operator', 'roofline_sfa_stage'):
         r = d[name]
         assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
