@@ -649,13 +649,18 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
         ddist.barrier()
         torch.cuda.synchronize()
 
-    def timed(job, n):
+    per_rank = {}
+
+    def timed(job, n, tag=None):
         fence()
         t0 = time.perf_counter()
         for _ in range(n):
             job.step(True)
         fence()
-        return ddist.max_over_ranks(time.perf_counter() - t0, dev) / n
+        mine = time.perf_counter() - t0
+        if tag is not None and world > 1:   # every rank's own time next to the MAX that defines the step
+            per_rank[tag] = [round(1e3 * v / n, 3) for v in ddist.gather_values(mine)]
+        return ddist.max_over_ranks(mine, dev) / n
 
     n_params = None
     for amp in ('off', 'fp16'):
@@ -683,7 +688,7 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
         if world > 1 and job.want_graph:   # a capture that failed on one rank only: every rank goes back to eager
             if ddist.gather_errors(job.graph_error):
                 job.graphed = None
-        per_step = timed(job, steps)
+        per_step = timed(job, steps, tag)
         rec = dict(samples_per_s=a.batch * world / per_step, ms_per_step=1e3 * per_step, steps=steps, warmup=warmup,
                    hip_graph=job.graphed is not None)
         if eager is not None:
@@ -691,6 +696,8 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
         if job.graph_error:
             rec['hip_graph_error'] = job.graph_error
         if world > 1:
+            rec['ms_per_step_by_rank'] = per_rank.get(tag)
+            rec['ddp_graph_requested'] = bool(a.ddp_graph)
             graphed, job.graphed = job.graphed, None     # the no_sync() comparison runs eagerly
             with job.net.no_sync():
                 job.step(False)
@@ -880,14 +887,19 @@ def main():
                 # recorded step carries seven extra marker packets and host calls, 35 us on a 0.34 ms MGHS-only step
                 hp.step(record and k % 4 == 0)
             fence()
-            el = ddist.max_over_ranks(time.perf_counter() - t0, dev)
+            mine = time.perf_counter() - t0
+            el = ddist.max_over_ranks(mine, dev)
+        own_ms.append(1e3 * mine / a.steps)
         parts = dict(writer_ms=event_mean(hp.ev), mghs_bwd_ms=event_mean(hp.ev_bwd)) if record else {}
         if record and hp.ev_sfa:
             parts['sfa_fwd_ms'] = event_mean([(e[0], e[1]) for e in hp.ev_sfa])
             parts['sfa_bwd_ms'] = event_mean([(e[1], e[2]) for e in hp.ev_sfa])
         return el, parts
 
+    own_ms = []   # this rank's own loop times (the headline is the MAX over ranks per loop)
     reps = [timed_loop() for _ in range(max(1, a.repeats))]
+    # every rank describes itself (backend, world size as the process group reports it, device, own step time): identical on all ranks
+    dist_report = ddist.rank_report(ms_per_step_own=float(np.median(own_ms)))
     per_step = sorted(1e3 * el / a.steps for el, _ in reps)
     elapsed = float(np.median([el for el, _ in reps]))
     stats = lambda v: dict(median=float(np.median(v)), min=float(np.min(v)), max=float(np.max(v)))
@@ -937,6 +949,7 @@ def main():
                           launch_ms_min=part_stats['writer_ms']['min'], launch_ms_max=part_stats['writer_ms']['max'],
                           event_samples=n_event_samples))
         # the protocol: R in-process repeats of the K-step loop; the headline is the MEDIAN loop
+        line['distributed'] = dist_report
         line.update(repeats=len(reps), ms_per_step_min=per_step[0], ms_per_step_max=per_step[-1], ms_per_step_first=1e3 * reps[0][0] / a.steps,
                     ms_per_step_all=[round(v, 5) for v in (1e3 * el / a.steps for el, _ in reps)], parts=part_stats)
         line['prepare'] = dict(lift_us, note='dhd_mghs_lift = height argmax -> band + context re-layout + geometry + grouping (4 launches, '

@@ -96,6 +96,7 @@ _PROTOTYPES = {
     'dhd_mghs_voxel_index': ([C.POINTER(MghsDesc), C.POINTER(Calib), _I, _P, _P, _P], _I),
     'dhd_mghs_stats': ([C.POINTER(MghsDesc), C.POINTER(MghsWorkspace), C.POINTER(C.c_int32 * DHD_MAX_GRIDS),
                         C.POINTER(C.c_int32 * DHD_MAX_GRIDS), _P], _I),
+    'dhd_mghs_debug_keys': ([C.POINTER(MghsDesc), C.POINTER(MghsWorkspace), _P, _P], _I),
     'dhd_hbm_calibrate': ([_P, C.c_size_t, _I, _P], _I),
     'dhd_sfa_channel_mean': ([_P, _P, _I, _I, _I, _P], _I),
     'dhd_sfa_blend1': ([_P, _P, _P, _I, _I, _I, _P], _I),

@@ -543,6 +543,15 @@ int dhd_mghs_voxel_index(const dhd_mghs_desc* desc, const dhd_calib* calib, int 
   return DHD_OK;
 }
 
+int dhd_mghs_debug_keys(const dhd_mghs_desc* desc, const dhd_mghs_workspace* ws, int32_t* keys, void* stream) {
+  Layout L;
+  if (!ws || !keys) return DHD_EINVAL;
+  int rc = make_layout(desc, ws, &L);
+  if (rc) return rc;
+  DHD_HIP(hipMemcpyAsync(keys, L.key, (size_t)2 * L.P * sizeof(int32_t), hipMemcpyDeviceToDevice, dhd_stream(stream)));
+  return DHD_OK;
+}
+
 int dhd_mghs_stats(const dhd_mghs_desc* desc, const dhd_mghs_workspace* ws, int32_t n_kept[DHD_MAX_GRIDS],
                    int32_t n_intervals[DHD_MAX_GRIDS], void* stream) {
   Layout L;

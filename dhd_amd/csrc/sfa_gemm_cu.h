@@ -46,9 +46,9 @@ inline size_t cu_lds_bytes(int c, int waves, int nb) {
 // samples per launch: as many as have their coefficient tables next to the tiles and patches in 160 KB of LDS
 inline int cu_max_batch(int c, int waves) { return (int)((160 * 1024 - cu_lds_bytes(c, waves, 0)) / ((size_t)3 * c * sizeof(float))); }
 
-// ReLU pass bits of the cu kernels: one 32-bit word per (tile, 32-row group, staging lane); bit 4*j + e = row 4*g + j of
-// the group, pixel 4*q + e of the tile (lane = 8*g + q).  Words per tile: 2*C.
-inline size_t cu_mask_words(int nb, int c, int hw) { return (size_t)nb * ((hw + 31) / 32) * 2 * c; }
+// ReLU pass bits of the cu kernels: one 16-bit word per (tile, 32-row group, staging lane); bit 4*j + e = row 4*g + j of
+// the group, pixel 4*q + e of the tile (lane = 8*g + q): one bit per activation, C 32-bit words per tile.
+inline size_t cu_mask_words(int nb, int c, int hw) { return (size_t)nb * ((hw + 31) / 32) * c; }
 
 // Weight M (rows x k, or its transpose) -> MFMA A fragments in the two-part split, one 32-channel tile after the other:
 //   wp[((ct * KCN + ks) * 2 + part) * 64 + lane] = part(M[32 ct + (lane & 31)][16 ks + 8 (lane >> 5) + j]), j = 0..7
@@ -210,7 +210,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_cu_kernel(const float* 
         *reinterpret_cast<u32x2*>(dst + wa + e * ROWB) = hq;
         *reinterpret_cast<u32x2*>(dst + wa + e * ROWB + PARTB) = mq;
       }
-      if (RECORD && !(ABL & 16)) relu_mask[((size_t)t * (C / 32) + wv * MT + rg) * 64 + lane] = bits;
+      if (RECORD && !(ABL & 16))
+        reinterpret_cast<unsigned short*>(relu_mask)[((size_t)t * (C / 32) + wv * MT + rg) * 64 + lane] = (unsigned short)bits;
     }
   };
 
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_cu_kernel(const float* 
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          mask_r[mt][k] = relu_mask[((size_t)t * (C / 32) + wv * MT + mt) * 64 + 8 * ((g >> 2) + 2 * k) + q];
+          mask_r[mt][k] = reinterpret_cast<const unsigned short*>(relu_mask)[((size_t)t * (C / 32) + wv * MT + mt) * 64 + 8 * ((g >> 2) + 2 * k) + q];
     }
     // ---- MFMA phase: D[channel][pixel] over all K ---------------------------------------------------------------------
     const unsigned char* src = cu_lds + PAR * BUFB;

@@ -2032,9 +2032,9 @@ SavedLayout saved_layout(int b, int c, int hw, int r) {
   // backward | kTickWords others; zeroed by the forward (fc_forward_kernel), left at zero by every kernel that uses them
   L.tick = take(2 * (size_t)c + kTickWords);
   L.wp1t = take(2 * (size_t)c * c); L.wp2t = take(2 * (size_t)c * c);   // transposed weight images, packed by the forward for the backward
-  // ReLU pass bits: one word per (32 pixels, channel), [sample][wave tile][channel] (resident / streamed kernels), or two per
-  // (32 pixels, channel) in the staging lanes' order (cu kernels, sfa_gemm_cu.h: cu_mask_words)
-  L.mask = take((size_t)2 * b * c * ((hw + 31) / 32));
+  // ReLU pass bits, one per activation: a word per (32 pixels, channel), [sample][wave tile][channel] (resident / streamed
+  // kernels), or 16-bit words in the staging lanes' order (cu kernels, sfa_gemm_cu.h: cu_mask_words)
+  L.mask = take((size_t)b * c * ((hw + 31) / 32));
   L.y1 = take((size_t)b * c * hw);
   L.y2 = take((size_t)b * c * hw);
   L.total = o;

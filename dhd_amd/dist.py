@@ -65,6 +65,15 @@ def sum_over_ranks(value, device='cpu'):
     return float(t.item())
 
 
+def gather_values(value):
+    """The python value of every rank, as a list ordered by rank (this rank's alone without a process group)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [value]
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, value)
+    return got
+
+
 def gather_errors(err):
     """`err`: this rank's error text or None.  Returns the list of 'rank r: text' over ALL ranks (empty = every rank is fine),
     identical on every rank: a leg that failed on any rank can be abandoned by all of them together, and rank 0 can report a
@@ -74,6 +83,38 @@ def gather_errors(err):
     got = [None] * dist.get_world_size()
     dist.all_gather_object(got, err)
     return [f'rank {r}: {e}' for r, e in enumerate(got) if e is not None]
+
+
+def rank_report(**mine):
+    """What a first multi-GPU run must say about itself so that a wrong topology is visible in the output: the backend as
+    torch.distributed reports it (backend "nccl" is RCCL on ROCm), the world size the process group has, and one record per rank
+    -- rank, local rank, device index / name / PCI bus id, RCCL's version, plus whatever the caller measured on that rank
+    (`mine`: e.g. its own step time next to the MAX over ranks that defines the headline).  Identical on every rank."""
+    rank, local, world_env = env_world()
+    rec = dict(rank=rank, local_rank=local, pid=os.getpid())
+    if torch.cuda.is_available():
+        i = torch.cuda.current_device()
+        prop = torch.cuda.get_device_properties(i)
+        rec.update(device=i, device_name=prop.name, visible_devices=torch.cuda.device_count(),
+                   pci_bus_id=getattr(prop, 'pci_bus_id', None), hbm_bytes=prop.total_memory)
+    rec.update(mine)
+    live = dist.is_initialized()
+    out = dict(backend=dist.get_backend() if live else None, world_size=dist.get_world_size() if live else 1, world_size_env=world_env,
+               launcher=dict(MASTER_ADDR=os.environ.get('MASTER_ADDR'), MASTER_PORT=os.environ.get('MASTER_PORT')))
+    try:
+        out['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version()) if torch.cuda.is_available() else None
+    except Exception as exc:  # noqa: BLE001
+        out['rccl_version'] = f'unavailable ({type(exc).__name__})'
+    if live and dist.get_world_size() > 1:
+        got = [None] * dist.get_world_size()
+        dist.all_gather_object(got, rec)
+        out['ranks'] = got
+        devs = [(r.get('pci_bus_id') or r.get('device')) for r in got]
+        out['distinct_devices'] = len(set(devs))
+    else:
+        out['ranks'] = [rec]
+        out['distinct_devices'] = 1
+    return out
 
 
 def shutdown():

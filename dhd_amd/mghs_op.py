@@ -424,6 +424,19 @@ def voxel_index(plan, calib, grid_index, want_ego=False):
     return rank, ego
 
 
+def debug_keys(plan, workspace):
+    """dhd_mghs_debug_keys: the voxel keys of the last prepare on `workspace` as computed by the product's counting kernel,
+    (2, P) int32: row 0 = global voxel id in grid 0, row 1 = in the pixel's band grid, -1 = dropped."""
+    lib = _lib.load()
+    d = plan.desc
+    npts = d.batch * d.n_cams * d.n_depth * d.fh * d.fw
+    keys = torch.empty((2, npts), dtype=torch.int32, device=workspace.device)
+    with torch.cuda.device(workspace.device):
+        rc = lib.dhd_mghs_debug_keys(C.byref(d), C.byref(workspace.c), _lib.ptr(keys), _lib.stream_ptr(workspace.device))
+    _lib.check(rc, 'dhd_mghs_debug_keys')
+    return keys
+
+
 def stats(plan, workspace):
     lib = _lib.load()
     kept = (C.c_int32 * _lib.DHD_MAX_GRIDS)()

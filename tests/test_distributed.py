@@ -36,6 +36,10 @@ def _worker(rank, world, port, q):
     # a failure on one rank is known to every rank (bench.py abandons an end-to-end leg on all ranks together and rank 0
     # reports errors it did not see itself)
     assert D.gather_errors('boom' if r == 1 else None) == ['rank 1: boom'] and D.gather_errors(None) == []
+    assert D.gather_values(10 * r) == [0, 10]
+    rep = D.rank_report(ms_per_step_own=1.0 + r)
+    assert rep['backend'] == 'gloo' and rep['world_size'] == rep['world_size_env'] == 2 and [x['rank'] for x in rep['ranks']] == [0, 1]
+    assert [x['ms_per_step_own'] for x in rep['ranks']] == [1.0, 2.0] and rep['ranks'][r]['pid'] == os.getpid()
     # DDP over the dense producer: each rank sees different samples, gradients come out averaged
     torch.manual_seed(0)
     net = HeightNet(16, 16, 9, use_dcn=False, use_aspp=False)

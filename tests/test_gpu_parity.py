@@ -344,7 +344,32 @@ def test_dhd_m_and_l_geometry_vs_oracle(gpu, name, input_size):
     np.testing.assert_allclose(grads[1], fg, atol=5e-4, rtol=1e-5)
 
 
-@pytest.mark.parametrize('batch', [1, 2])
+def assert_product_keys_equal_maps(gpu, cfg, plan, ws, maps, hidx):
+    """The keys the PRODUCT's counting kernel wrote in the last prepare on `ws` (dhd_mghs_debug_keys) against per-grid point ->
+    voxel maps that have been verified against the reference: grid 0 for every point, the band grid of the point's pixel for
+    the second key (-1 where the pixel has no band or the point falls outside)."""
+    from dhd_amd import mghs_op
+    from oracle import mghs_oracle as O
+    d = plan.desc
+    keys = mghs_op.debug_keys(plan, ws)
+    P = keys.shape[1]
+    base = np.cumsum([0] + [d.batch * g_.n[0] * g_.n[1] * g_.n[2] for g_ in plan.grids])
+    m0 = maps[0].to(torch.int64)
+    want0 = torch.where(m0 >= 0, m0 + int(base[0]), m0)
+    assert torch.equal(keys[0].to(torch.int64), want0)
+    band = torch.from_numpy(O.band_index(hidx, cfg['height_range'], cfg['mask_range']).astype(np.int64)).to(gpu)   # (B*N, fH, fW): 0/1/2, 255 = none
+    band_pt = band[:, None].expand(-1, d.n_depth, -1, -1).reshape(-1)
+    assert band_pt.numel() == P
+    want1 = torch.full((P,), -1, dtype=torch.int64, device=gpu)
+    for b in range(3):
+        mb = maps[b + 1].to(torch.int64)
+        sel = (band_pt == b) & (mb >= 0)
+        want1[sel] = mb[sel] + int(base[b + 1])
+    assert torch.equal(keys[1].to(torch.int64), want1)
+    assert int((keys[1] >= 0).sum()) > 0
+
+
+@pytest.mark.parametrize('batch', [1, 2, 4])
 def test_full_dhds_size_vs_reference(gpu, batch):
     """DHD-S, 6 cameras, 200x200x{1,4,4,8}: index hashes, sampled voxels, sums and gradients of the
     reference run (fixtures hold hashes/samples; inputs are regenerated from integer hashes)."""
@@ -361,7 +386,9 @@ def test_full_dhds_size_vs_reference(gpu, batch):
         if k == 0:
             assert sha(ego.cpu().numpy()) == str(g['coor_sha'])
         assert sha(rank.cpu().numpy()) == str(g[f'rank_map_sha{k}']), k
+    maps = [mghs_op.voxel_index(plan, calib, k)[0] for k in range(4)]      # verified against the reference's hashes above
     outs, grads, (plan, ws) = run_fused(gpu, cfg, calib_np, depth, feat, hidx, g['ref_inv_post_rot'], g['ref_combine'], s_w)
+    assert_product_keys_equal_maps(gpu, cfg, plan, ws, maps, hidx)
     kept, ivs = mghs_op.stats(plan, ws)
     assert kept[0] == int(g['n_kept0']) and ivs[0] == int(g['n_intervals0'])
     for k, o in enumerate(outs):

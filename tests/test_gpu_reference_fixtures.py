@@ -203,13 +203,21 @@ def test_mghs_depth_view_transform_dhdl_size_b2_vs_reference(gpu):
     depth, feat, hidx = syn.lift_inputs(s_in, B, N, 88, fh, fw, 64, 65)
     plan, axes = make_plan(cfg, B, N)
     calib_s, keep = device_calib(golden_calib(g), axes, gpu, g['ref_inv_post_rot'], g['ref_combine'])
+    maps = []
     for k in range(4):
         rank, ego = mghs_op.voxel_index(plan, calib_s, k, want_ego=(k == 0))
         if k == 0:
             assert sha(ego.cpu().numpy()) == str(g['coor_sha'])
+        maps.append(rank)
         rank = rank.cpu().numpy()
         assert sha(rank) == str(g[f'rank_map_sha{k}']), k
         assert int((rank >= 0).sum()) == int(g[f'n_kept{k}'])
+    # the keys the product's own counting kernel computes in a lift (2 x 2.97 M words) equal those maps
+    from test_gpu_parity import assert_product_keys_equal_maps
+    ws = plan.new_workspace(gpu)
+    mghs_op.lift(plan, calib_s, T(syn.height_probs_from_index(hidx, 65), gpu), cfg['height_range'], cfg['mask_range'], T(feat, gpu), ws)
+    assert_product_keys_equal_maps(gpu, cfg, plan, ws, maps, hidx)
+    del ws, maps
     hn = dict(use_dcn=False, use_aspp=False)
     m = MGHS_Depth(**dict(cfg, heightnet_cfg=hn, depthnet_cfg=hn)).to(gpu)
     inject_reference_matrices(m, g, gpu)
