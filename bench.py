@@ -127,8 +127,12 @@ def sfa_forward_traffic(batch, terms=2):
     passes run both precisions, so the small finalize kernel's figure is an average over them: +-5 MB of ~1.8 GB.)"""
     k = pmc_summary(batch)
     import re
-    conv1 = [v for n, v in k.items() if re.match(rf'pw_gemm_res_kernel<{terms},\d+,\d+,true,false,0,', n)]
-    conv2 = [v for n, v in k.items() if re.match(rf'pw_gemm_res_kernel<{terms},\d+,\d+,false,true,0,', n)]
+    if terms == 2:   # default precision: the one-CU-per-tile kernels <K steps, waves, TWO_IN, RELU, EPI, RECORD, ...>
+        conv1 = [v for n, v in k.items() if re.match(r'pw_gemm_cu_kernel<\d+,\d+,true,false,0,', n)]
+        conv2 = [v for n, v in k.items() if re.match(r'pw_gemm_cu_kernel<\d+,\d+,false,true,0,', n)]
+    else:
+        conv1 = [v for n, v in k.items() if re.match(rf'pw_gemm_res_kernel<{terms},\d+,\d+,true,false,0,', n)]
+        conv2 = [v for n, v in k.items() if re.match(rf'pw_gemm_res_kernel<{terms},\d+,\d+,false,true,0,', n)]
     calls = {'plane_mean_pack_kernel': 1, 'fc_forward_kernel': 1, 'bn_stats_finalize_kernel': 2, 'blend2_bn_kernel': 1}
     if len(conv1) != 1 or len(conv2) != 1 or any(n not in k for n in calls):
         return None
@@ -442,6 +446,59 @@ def lift_timing(hp, reps=20, warmup=3):
                 ev.append((e0, e1))
         torch.cuda.synchronize()
         out[name] = 1e3 * event_mean(ev)
+    return out
+
+
+def mghs_amp_record(hp, steps, warmup, dtype=torch.float16):
+    """The MGHS node as an autocast region sees it (configs[1]: DHD-S fp16, DHD-S.py:281; the reference's operator returns float32,
+    bev_pool.py:20-21, and the convolutions on either side cast): per step lift + pooling forward + backward,
+      `f32_nodes_plus_casts`: float32 tensors out, cast to half for the consumer, half gradients cast back to float32 (what autocast
+                              does around a float32 node: 704 MB -> 352 MB and back at B = 4),
+      `half_io`:              dhd_tensor_view.dtype = DHD_F16: the writer emits the half tensors (bit-identical to the cast), the
+                              backward reads the half gradients.
+    HIP events around the whole step and around the streaming writer; `steps` steps after `warmup`."""
+    import ctypes as C
+    from dhd_amd.mghs_op import _alloc_outputs, _views
+    lib = _lib.load()
+    cfg, plan, dev = hp.cfg, hp.plan, hp.dev
+    gh = [g.to(dtype) for g in hp.out_grads]
+    out = {}
+    for mode in ('f32_nodes_plus_casts', 'half_io'):
+        odt = dtype if mode == 'half_io' else torch.float32
+        ev_step, ev_wr = [], []
+        for it in range(warmup + steps):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            st = _lib.stream_ptr(dev)
+            e[0].record()
+            _, feat_nhwc = mghs_op.lift(plan, hp.calib, hp.height, cfg['height_range'], cfg['mask_range'], hp.feat, hp.ws)
+            outs = _alloc_outputs(plan, 'collapsed', dev, odt)
+            arr = _views(plan, 'collapsed', outs)
+            _lib.check(lib.dhd_mghs_forward_gather(C.byref(plan.desc), _lib.ptr(hp.depth), _lib.ptr(feat_nhwc), C.byref(hp.ws.c), st),
+                       'dhd_mghs_forward_gather')
+            e[1].record()
+            _lib.check(lib.dhd_mghs_forward_stream_views(C.byref(plan.desc), _lib.ptr(hp.depth), _lib.ptr(feat_nhwc), C.byref(arr),
+                                                         C.byref(hp.ws.c), st), 'dhd_mghs_forward_stream_views')
+            e[2].record()
+            if mode == 'f32_nodes_plus_casts':
+                consumed = [o.to(dtype) for o in outs]                  # the consumer's cast of the float32 tensors
+                grads = [g.float() for g in gh]                        # the half gradients cast back for the float32 node
+            else:
+                consumed, grads = outs, gh
+            garr = _views(plan, 'collapsed', grads)
+            dg, fg = torch.empty_like(hp.depth), torch.empty_like(hp.feat)
+            _lib.check(lib.dhd_mghs_backward_views(C.byref(plan.desc), _lib.ptr(hp.depth), _lib.ptr(feat_nhwc), C.byref(garr), _lib.ptr(dg),
+                                                   _lib.ptr(fg), C.byref(hp.ws.c), st), 'dhd_mghs_backward_views')
+            e[3].record()
+            if it >= warmup:
+                ev_step.append((e[0], e[3]))
+                ev_wr.append((e[1], e[2]))
+            del outs, consumed, grads
+        torch.cuda.synchronize()
+        out[mode] = dict(mghs_step_ms=event_mean(ev_step), writer_ms=event_mean(ev_wr))
+    out['dtype'] = str(dtype).replace('torch.', '')
+    out['writer_half_GBps'] = hp.pool_fwd_bytes / 2 / (out['half_io']['writer_ms'] * 1e-3) / 1e9   # half the output bytes (+ the 1 % of inputs)
+    out['note'] = ('MGHS part of the hot path only (lift + pooling forward + backward), B = %d; writer_ms = the streaming writer alone '
+                   '(half: 352 MB instead of 704 MB at B = 4); the SFA stage operator keeps float32 I/O' % hp.B)
     return out
 
 
@@ -983,6 +1040,11 @@ def main():
         line['fresh_processes'] = fresh_process_repeats(a)
         print(f'[bench] {a.fresh_procs} fresh-process repeats {time.perf_counter() - t_stage:.1f} s', file=sys.stderr, flush=True)
     t_stage = time.perf_counter()
+    if hp.plan.half_outputs_supported:
+        with no_gc():
+            amp_rec = mghs_amp_record(hp, max(5, min(a.steps, 20)), 3)   # every rank runs it, rank 0 reports
+        if rank == 0:
+            line['hotpath_amp'] = amp_rec
     if a.geometry == 'dhd-s' and not a.no_operator:
         with no_gc():
             op_roof = operator_roofline(hp, max(5, min(a.steps, 20)), 3)   # every rank runs it, rank 0 reports

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DHD_AMD_LIB', os.path.join(_HERE, 'csrc', 'libdhd_amd.so'))
 
 DHD_MAX_GRIDS = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _ERRORS = {-1: 'DHD_EINVAL (bad argument)', -2: 'DHD_ENOSPACE (workspace too small)',
            -3: 'DHD_EUNSUPPORTED (size outside supported range)'}
@@ -43,7 +43,20 @@ class MghsWorkspace(C.Structure):
 
 
 class TensorView(C.Structure):
-    _fields_ = [('ptr', C.c_void_p), ('batch_stride', C.c_int64), ('z_stride', C.c_int64), ('channel_stride', C.c_int64)]
+    _fields_ = [('ptr', C.c_void_p), ('batch_stride', C.c_int64), ('z_stride', C.c_int64), ('channel_stride', C.c_int64),
+                ('dtype', C.c_int32)]
+
+
+DTYPE_CODE = {}   # torch dtype -> dhd_tensor_view.dtype (filled on first use: torch is imported lazily by some callers)
+
+
+def dtype_code(dt):
+    import torch
+    if not DTYPE_CODE:
+        DTYPE_CODE.update({torch.float32: 0, torch.float16: 1, torch.bfloat16: 2})
+    if dt not in DTYPE_CODE:
+        raise DhdError(f'pooled tensors are float32, float16 or bfloat16, not {dt}')
+    return DTYPE_CODE[dt]
 
 
 class Calib(C.Structure):
@@ -91,6 +104,7 @@ _PROTOTYPES = {
     'dhd_mghs_forward_gather': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(MghsWorkspace), _P], _I),
     'dhd_mghs_forward_stream': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), C.POINTER(MghsWorkspace), _P], _I),
     'dhd_mghs_forward_views': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(TensorView * DHD_MAX_GRIDS), C.POINTER(MghsWorkspace), _P], _I),
+    'dhd_mghs_forward_stream_views': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(TensorView * DHD_MAX_GRIDS), C.POINTER(MghsWorkspace), _P], _I),
     'dhd_mghs_backward_views': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(TensorView * DHD_MAX_GRIDS), _P, _P, C.POINTER(MghsWorkspace), _P], _I),
     'dhd_mghs_backward': ([C.POINTER(MghsDesc), _P, _P, C.POINTER(_P * DHD_MAX_GRIDS), _P, _P, C.POINTER(MghsWorkspace), _P], _I),
     'dhd_mghs_voxel_index': ([C.POINTER(MghsDesc), C.POINTER(Calib), _I, _P, _P, _P], _I),

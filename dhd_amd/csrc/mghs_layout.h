@@ -182,11 +182,19 @@ typedef float vfloat4 __attribute__((ext_vector_type(4)));  // native vector: ac
 // sz = C*plane, sc = plane.  The un-collapsed (B, C, nz_total, ny, nx) tensor of MGHS_Depth is the
 // same data with sb = C*nz_total*plane, sc = nz_total*plane, sz = plane and p offset by the grid's
 // first z slice.
-struct OutPtrs { float* p[DHD_MAX_GRIDS]; long sb[DHD_MAX_GRIDS], sz[DHD_MAX_GRIDS], sc[DHD_MAX_GRIDS]; };
-struct InPtrs { const float* p[DHD_MAX_GRIDS]; long sb[DHD_MAX_GRIDS], sz[DHD_MAX_GRIDS], sc[DHD_MAX_GRIDS]; };
+// (p is a float* for DHD_F32 and points to 2-byte elements for DHD_F16 / DHD_BF16: the half kernels cast it; strides in elements)
+struct OutPtrs { float* p[DHD_MAX_GRIDS]; long sb[DHD_MAX_GRIDS], sz[DHD_MAX_GRIDS], sc[DHD_MAX_GRIDS]; int dtype; };
+struct InPtrs { const float* p[DHD_MAX_GRIDS]; long sb[DHD_MAX_GRIDS], sz[DHD_MAX_GRIDS], sc[DHD_MAX_GRIDS]; int dtype; };
 
 template <class Ptrs, class T>
 inline int make_views(const Layout& L, T* const bases[DHD_MAX_GRIDS], const dhd_tensor_view* views, Ptrs* o) {
+  o->dtype = DHD_F32;
+  if (views) {
+    o->dtype = views[0].dtype;
+    if (o->dtype != DHD_F32 && o->dtype != DHD_F16 && o->dtype != DHD_BF16) return DHD_EINVAL;
+    if (o->dtype != DHD_F32 && !L.compact) return DHD_EUNSUPPORTED;   // half tensors: the segment writer / reader only
+  }
+  const long vec = o->dtype == DHD_F32 ? 4 : 8;                       // elements per 16-byte access
   for (int g = 0; g < DHD_MAX_GRIDS; ++g) {
     o->p[g] = nullptr; o->sb[g] = o->sz[g] = o->sc[g] = 0;
     if (g >= L.G) continue;
@@ -196,7 +204,9 @@ inline int make_views(const Layout& L, T* const bases[DHD_MAX_GRIDS], const dhd_
       o->p[g] = static_cast<T*>(const_cast<void*>(static_cast<const void*>(views[g].ptr)));
       o->sb[g] = views[g].batch_stride; o->sz[g] = views[g].z_stride; o->sc[g] = views[g].channel_stride;
       // the 16-byte vector path needs aligned rows
-      if ((o->sb[g] | o->sz[g] | o->sc[g]) & 3) return DHD_EINVAL;
+      if (views[g].dtype != o->dtype) return DHD_EINVAL;
+      if (((o->sb[g] | o->sz[g] | o->sc[g]) & (vec - 1)) || (reinterpret_cast<uintptr_t>(views[g].ptr) & 15)) return DHD_EINVAL;
+      if (o->dtype != DHD_F32 && (L.grid[g].n[0] & 1)) return DHD_EUNSUPPORTED;   // 4 rows of nx voxels in 8-voxel vectors
     } else {
       if (!bases || !bases[g]) return DHD_EINVAL;
       o->p[g] = bases[g];

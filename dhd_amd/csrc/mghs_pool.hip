@@ -212,7 +212,40 @@ constexpr size_t kStreamLds = (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2 
 // channels per workgroup are best; where they are dense (D = 88: twice the points, or the 32 x 88 feature maps of
 // DHD-L) the table holds 32 channels per pass anyway and halves are best.  The host picks by points per segment
 // (stream_split).  mghs_stream_bwd gains nothing from 2 parts (134 us) and loses with 4 (147 us): it stays whole.
+// Element types of the dense tensors (dhd_tensor_view.dtype): a lane always moves 16 bytes = kVox<T> voxels of one channel run.
+// Half types: float32 sums from the table, rounded to nearest even on the way out (what `.half()` / `.bfloat16()` of the
+// float32 tensor would give); gradients are widened exactly.
+template <class T> struct VoxVec { static constexpr int n = 16 / sizeof(T); };
+template <class T> __device__ __forceinline__ vfloat4 pack_vox(const float* f);
+template <> __device__ __forceinline__ vfloat4 pack_vox<float>(const float* f) { return vfloat4{f[0], f[1], f[2], f[3]}; }
+template <> __device__ __forceinline__ vfloat4 pack_vox<_Float16>(const float* f) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const h8 v = {(_Float16)f[0], (_Float16)f[1], (_Float16)f[2], (_Float16)f[3], (_Float16)f[4], (_Float16)f[5], (_Float16)f[6], (_Float16)f[7]};
+  return __builtin_bit_cast(vfloat4, v);
+}
+template <> __device__ __forceinline__ vfloat4 pack_vox<__bf16>(const float* f) {
+  typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+  const b8 v = {(__bf16)f[0], (__bf16)f[1], (__bf16)f[2], (__bf16)f[3], (__bf16)f[4], (__bf16)f[5], (__bf16)f[6], (__bf16)f[7]};
+  return __builtin_bit_cast(vfloat4, v);
+}
+template <class T> __device__ __forceinline__ void unpack_vox(vfloat4 v, float* f);
+template <> __device__ __forceinline__ void unpack_vox<float>(vfloat4 v, float* f) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+template <> __device__ __forceinline__ void unpack_vox<_Float16>(vfloat4 v, float* f) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const h8 h = __builtin_bit_cast(h8, v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) f[k] = (float)h[k];
+}
+template <> __device__ __forceinline__ void unpack_vox<__bf16>(vfloat4 v, float* f) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 w = __builtin_bit_cast(u4, v);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(w[k] << 16); f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+}
+
+template <class T>
 __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtrs out, int split) {
+  constexpr int VPL = VoxVec<T>::n;                // voxels per lane and store: 4 (float32) or 8 (half types)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* table = reinterpret_cast<float*>(smem);
   unsigned short* slot_of = reinterpret_cast<unsigned short*>(smem + (size_t)kTableFloats * 4);
@@ -230,8 +263,8 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
   const int k0 = rfl(ctl[0]), nnz = rfl(ctl[1]) - k0;
   for (int j = t; j < nnz; j += kStreamBlock) slot_of[L.nzvox[k0 + j] - sg.v0] = (unsigned short)(j + 1);
   const int cp = min(channels_per_pass(nnz), c_end - c_begin);
-  const int nvec = sg.nvox / 4;
-  float* og = out.p[sg.g];
+  const int nvec = sg.nvox / VPL;
+  T* og = reinterpret_cast<T*>(out.p[sg.g]);
   const long sb = out.sb[sg.g], sz = out.sz[sg.g], sc = out.sc[sg.g];
   for (int c_lo = c_begin; c_lo < c_end; c_lo += cp) {
     __syncthreads();  // slot_of complete / previous pass done with the table
@@ -245,25 +278,38 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
     // `wv` stores vectors [(it * waves + wv) * 64, + 64).  With a wave per channel run, 200 vectors were 3 full
     // stores + one 8-lane store (32 store instructions per wave and pass for 25 stores' worth of bytes); flat, every
     // store but the last of the pass is a full 1 KB and the workgroup writes 8 KB contiguous per iteration.
-    float* base = og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)c_lo * sc + (size_t)sg.y0 * sg.nx;
+    T* base = og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)c_lo * sc + (size_t)sg.y0 * sg.nx;
     const int total = cp * nvec;
     constexpr int kStride = kStreamWaves * DHD_WAVE;
     const int q_step = kStride / nvec, r_step = kStride % nvec;
     int idx = wv * DHD_WAVE + lane;
     int cc = idx / nvec, i = idx % nvec;
     for (; idx < total; idx += kStride) {
-      vfloat4 v = {0.f, 0.f, 0.f, 0.f};
-      const uint2 sl = *reinterpret_cast<const uint2*>(slot_of + 4 * i);
-      if (sl.x | sl.y) {
-        const unsigned s0 = sl.x & 0xffffu, s1 = sl.x >> 16, s2 = sl.y & 0xffffu, s3 = sl.y >> 16;
-        if (s0) v.x = table[(s0 - 1) * cp + cc];
-        if (s1) v.y = table[(s1 - 1) * cp + cc];
-        if (s2) v.z = table[(s2 - 1) * cp + cc];
-        if (s3) v.w = table[(s3 - 1) * cp + cc];
+      float f[VPL];
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) f[k] = 0.f;
+      unsigned sl[VPL / 2];                        // two 16-bit slot words per 32-bit word
+      if (VPL == 4) {
+        const uint2 w = *reinterpret_cast<const uint2*>(slot_of + 4 * i);
+        sl[0] = w.x; sl[1] = w.y;
+      } else {
+        const uint4 w = *reinterpret_cast<const uint4*>(slot_of + 8 * i);
+        sl[0] = w.x; sl[1] = w.y; sl[VPL / 2 - 2] = w.z; sl[VPL / 2 - 1] = w.w;
+      }
+      unsigned any = 0;
+#pragma unroll
+      for (int k = 0; k < VPL / 2; ++k) any |= sl[k];
+      if (any) {
+#pragma unroll
+        for (int k = 0; k < VPL / 2; ++k) {
+          const unsigned s0 = sl[k] & 0xffffu, s1 = sl[k] >> 16;
+          if (s0) f[2 * k] = table[(s0 - 1) * cp + cc];
+          if (s1) f[2 * k + 1] = table[(s1 - 1) * cp + cc];
+        }
       }
       vfloat4* dst = reinterpret_cast<vfloat4*>(base + (size_t)cc * sc) + i;
       // streamed once, not re-read here: non-temporal, so the output stream does not evict vsum from L2
-      __builtin_nontemporal_store(v, dst);
+      __builtin_nontemporal_store(pack_vox<T>(f), dst);
       cc += q_step;
       i += r_step;
       if (i >= nvec) { i -= nvec; ++cc; }
@@ -275,7 +321,9 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
 // backward 1: stream out_grad, extract the rows of the non-empty voxels into vsum[slot][64].
 // Segments without any point are skipped: their out_grad is never needed.
 // ---------------------------------------------------------------------------------------
+template <class T>
 __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs og_in) {
+  constexpr int VPL = VoxVec<T>::n;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* table = reinterpret_cast<float*>(smem);
   unsigned short* slot_of = reinterpret_cast<unsigned short*>(smem + (size_t)kTableFloats * 4);
@@ -292,8 +340,8 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
   if (nnz == 0) return;
   for (int j = t; j < nnz; j += kStreamBlock) slot_of[L.nzvox[k0 + j] - sg.v0] = (unsigned short)(j + 1);
   const int cp = channels_per_pass(nnz);
-  const int nvec = sg.nvox / 4;
-  const float* og = og_in.p[sg.g];
+  const int nvec = sg.nvox / VPL;
+  const T* og = reinterpret_cast<const T*>(og_in.p[sg.g]);
   const long sb = og_in.sb[sg.g], sz = og_in.sz[sg.g], sc = og_in.sc[sg.g];
   // Only ~7 % of the voxels (~56 % of the 128-byte lines of out_grad) hold a point, and the gradient of every other
   // voxel is never needed: a lane reads its 16 bytes only if one of its four voxels does.  The loads stay
@@ -304,7 +352,7 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
   // consecutive positions of a wave are requested together.
   constexpr int kStride = kStreamWaves * DHD_WAVE, kBatch = 5;
   const int q_step = kStride / nvec, r_step = kStride % nvec;
-  const float* gbase = og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)sg.y0 * sg.nx;
+  const T* gbase = og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)sg.y0 * sg.nx;
   __syncthreads();  // slot_of complete
   for (int c_lo = 0; c_lo < kTileC; c_lo += cp) {
     __syncthreads();
@@ -312,16 +360,25 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
     int idx = wv * DHD_WAVE + lane;
     int cc = idx / nvec, i = idx % nvec;
     for (; idx - lane < total; ) {                 // wave-uniform condition
-      uint2 sl[kBatch];
+      unsigned sl[kBatch][VPL / 2], any[kBatch];
       vfloat4 v[kBatch];
       int ccs[kBatch];
 #pragma unroll
       for (int k = 0; k < kBatch; ++k) {
         const bool in = idx < total;
-        sl[k] = in ? *reinterpret_cast<const uint2*>(slot_of + 4 * i) : make_uint2(0u, 0u);
+        if (VPL == 4) {
+          const uint2 w = in ? *reinterpret_cast<const uint2*>(slot_of + 4 * i) : make_uint2(0u, 0u);
+          sl[k][0] = w.x; sl[k][1] = w.y;
+        } else {
+          const uint4 w = in ? *reinterpret_cast<const uint4*>(slot_of + 8 * i) : make_uint4(0u, 0u, 0u, 0u);
+          sl[k][0] = w.x; sl[k][1] = w.y; sl[k][VPL / 2 - 2] = w.z; sl[k][VPL / 2 - 1] = w.w;
+        }
+        any[k] = 0;
+#pragma unroll
+        for (int u = 0; u < VPL / 2; ++u) any[k] |= sl[k][u];
         ccs[k] = cc;
-        const vfloat4* p = (sl[k].x | sl[k].y) ? reinterpret_cast<const vfloat4*>(gbase + (size_t)(c_lo + cc) * sc) + i
-                                               : reinterpret_cast<const vfloat4*>(L.vsum);
+        const vfloat4* p = any[k] ? reinterpret_cast<const vfloat4*>(gbase + (size_t)(c_lo + cc) * sc) + i
+                                  : reinterpret_cast<const vfloat4*>(L.vsum);
         v[k] = __builtin_nontemporal_load(p);
         idx += kStride;
         cc += q_step;
@@ -330,12 +387,15 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
       }
 #pragma unroll
       for (int k = 0; k < kBatch; ++k) {
-        if (sl[k].x | sl[k].y) {
-          const unsigned s0 = sl[k].x & 0xffffu, s1 = sl[k].x >> 16, s2 = sl[k].y & 0xffffu, s3 = sl[k].y >> 16;
-          if (s0) table[(s0 - 1) * cp + ccs[k]] = v[k].x;
-          if (s1) table[(s1 - 1) * cp + ccs[k]] = v[k].y;
-          if (s2) table[(s2 - 1) * cp + ccs[k]] = v[k].z;
-          if (s3) table[(s3 - 1) * cp + ccs[k]] = v[k].w;
+        if (any[k]) {
+          float f[VPL];
+          unpack_vox<T>(v[k], f);
+#pragma unroll
+          for (int u = 0; u < VPL / 2; ++u) {
+            const unsigned s0 = sl[k][u] & 0xffffu, s1 = sl[k][u] >> 16;
+            if (s0) table[(s0 - 1) * cp + ccs[k]] = f[2 * u];
+            if (s1) table[(s1 - 1) * cp + ccs[k]] = f[2 * u + 1];
+          }
         }
       }
     }
@@ -712,7 +772,9 @@ static int forward_stream_impl(const dhd_mghs_desc* desc, const float* depth, co
   hipStream_t st = dhd_stream(stream);
   if (L.compact) {
     const int split = stream_split(L);
-    hipLaunchKernelGGL(mghs_stream_fwd, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
+    if (o.dtype == DHD_F16) hipLaunchKernelGGL(mghs_stream_fwd<_Float16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
+    else if (o.dtype == DHD_BF16) hipLaunchKernelGGL(mghs_stream_fwd<__bf16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
+    else hipLaunchKernelGGL(mghs_stream_fwd<float>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
     DHD_LAUNCH_CHECK();
   } else {
     int stride; size_t smem; dim3 grid;
@@ -726,6 +788,12 @@ static int forward_stream_impl(const dhd_mghs_desc* desc, const float* depth, co
 int dhd_mghs_forward_stream(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                             float* const out[DHD_MAX_GRIDS], const dhd_mghs_workspace* workspace, void* stream) {
   return forward_stream_impl(desc, depth, feat_nhwc, out, nullptr, workspace, stream);
+}
+
+int dhd_mghs_forward_stream_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                                  const dhd_tensor_view out[DHD_MAX_GRIDS], const dhd_mghs_workspace* workspace, void* stream) {
+  if (!out) return DHD_EINVAL;
+  return forward_stream_impl(desc, depth, feat_nhwc, nullptr, out, workspace, stream);
 }
 
 int dhd_mghs_forward(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
@@ -754,7 +822,9 @@ static int backward_impl(const dhd_mghs_desc* desc, const float* depth, const fl
   if ((rc = make_views<InPtrs, const float>(L, out_grad, views, &in))) return rc;
   hipStream_t st = dhd_stream(stream);
   if (L.compact) {
-    hipLaunchKernelGGL(mghs_stream_bwd, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, in);
+    if (in.dtype == DHD_F16) hipLaunchKernelGGL(mghs_stream_bwd<_Float16>, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, in);
+    else if (in.dtype == DHD_BF16) hipLaunchKernelGGL(mghs_stream_bwd<__bf16>, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, in);
+    else hipLaunchKernelGGL(mghs_stream_bwd<float>, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, in);
     DHD_LAUNCH_CHECK();
     hipLaunchKernelGGL(mghs_pixel_bwd, dim3(dhd_cdiv((long)L.B * L.N * L.hw, 8 * (kBlock / DHD_WAVE)) * 8), dim3(kBlock), 0, st, L,
                        depth, feat_nhwc, depth_grad, feat_grad_nhwc);

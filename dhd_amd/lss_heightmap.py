@@ -62,6 +62,7 @@ class MGHS(nn.Module):
         self._axes_dev = {}
         self._static = {}           # plan -> (workspace, stamp, tensors kept alive) of an accelerate=True static rig
         self.deterministic = None   # None: mghs_op's default (DHD_MGHS_DETERMINISTIC); True / False: this module's plans
+        self.amp_outputs = True     # under autocast: pooled tensors in the autocast dtype (= the float32 result cast, see _pool)
 
     # ------------------------------------------------------------------ grid / frustum ---
     def create_grid_infos(self, x, y, z, **kwargs):
@@ -184,6 +185,13 @@ class MGHS(nn.Module):
         plan = self._plan(B, N, fh, fw, key, grids)
         calib, keep = self._calib(sensor2ego, cam2imgs, post_rots, post_trans, bda)
         layout = layout or ('collapsed' if self.collapse_z else 'split')
+        # Under autocast the reference's operator returns float32 (bev_pool.py:20-21) and the first convolution behind it casts
+        # the 174 MB per sample to half at once.  `amp_outputs` (default on) lets the writer emit that half tensor directly --
+        # bit-identical to the cast of the float32 result -- and the backward read half gradients.
+        odt = (torch.get_autocast_gpu_dtype() if self.amp_outputs and torch.is_autocast_enabled() and plan.half_outputs_supported
+               else torch.float32)
+        if odt not in (torch.float16, torch.bfloat16):
+            odt = torch.float32
         needs_grad = torch.is_grad_enabled() and (depth.requires_grad or tran_feat.requires_grad)
         if self.accelerate and not needs_grad:
             # Static rig at inference (the reference's dormant accelerate / pre_compute idea, :234-258,374-378): while the
@@ -197,16 +205,16 @@ class MGHS(nn.Module):
             hit = self._static.get(plan)
             if hit is None or hit[1] != stamp:
                 ws = plan.new_workspace(depth.device, private_scratch=True)
-                outs = mghs_op.mghs_lift_pool(plan, calib, height, self.height_range, self.mask_range, depth, tran_feat, ws, layout)
+                outs = mghs_op.mghs_lift_pool(plan, calib, height, self.height_range, self.mask_range, depth, tran_feat, ws, layout, out_dtype=odt)
                 self._static = {p_: e for p_, e in self._static.items() if e[1] == stamp}   # one rig at a time
                 self._static[plan] = (ws, stamp, srcs, keep)
                 return list(outs)
             if len(grids) == 1:
                 tf = tran_feat.float().contiguous()
-                return list(mghs_op._MGHSPool.apply(depth.float(), tf, plan, hit[0], mghs_op._nchw_to_nhwc(tf), layout))
+                return list(mghs_op._MGHSPool.apply(depth.float(), tf, plan, hit[0], mghs_op._nchw_to_nhwc(tf), layout, odt))
             return list(mghs_op.mghs_lift_pool(plan, calib, height, self.height_range, self.mask_range, depth, tran_feat,
-                                               hit[0], layout, static=True))
-        return list(mghs_op.mghs_lift_pool(plan, calib, height, self.height_range, self.mask_range, depth, tran_feat, layout=layout))
+                                               hit[0], layout, static=True, out_dtype=odt))
+        return list(mghs_op.mghs_lift_pool(plan, calib, height, self.height_range, self.mask_range, depth, tran_feat, layout=layout, out_dtype=odt))
 
     def view_transform_core(self, input, depth, tran_feat):
         """Single-grid lift-splat on the CURRENT grid_config (reference :380-405)."""

@@ -109,6 +109,11 @@ class Plan:
         _lib.check(_lib.load().dhd_mghs_workspace_bytes(C.byref(d), C.byref(st), C.byref(sc)), 'dhd_mghs_workspace_bytes')
         self.state_bytes, self.scratch_bytes = int(st.value), int(sc.value)
 
+    @property
+    def half_outputs_supported(self):
+        """dhd_tensor_view.dtype DHD_F16 / DHD_BF16 need the segment writer (include/dhd_amd.h): C = 64, ny % 4 == 0, nx % 4 == 0."""
+        return self.desc.channels == 64 and all(g.n[1] % 4 == 0 and g.n[0] % 4 == 0 and 4 * g.n[0] <= 1024 for g in self.grids)
+
     def out_shapes(self):
         d = self.desc
         return [(d.batch, g.n[2] * d.channels, g.n[1], g.n[0]) for g in self.grids]
@@ -289,20 +294,20 @@ def pool_backward(plan, depth, feat_nhwc, out_grads, workspace):
 LAYOUTS = ('collapsed', 'split', 'stacked')
 
 
-def _alloc_outputs(plan, layout, device):
+def _alloc_outputs(plan, layout, device, dtype=torch.float32):
     d = plan.desc
     if layout == 'collapsed':
-        return [torch.empty(s, dtype=torch.float32, device=device) for s in plan.out_shapes()]
+        return [torch.empty(s, dtype=dtype, device=device) for s in plan.out_shapes()]
     if layout == 'split':
-        return [torch.empty((d.batch, d.channels, g.n[2], g.n[1], g.n[0]), dtype=torch.float32, device=device)
+        return [torch.empty((d.batch, d.channels, g.n[2], g.n[1], g.n[0]), dtype=dtype, device=device)
                 for g in plan.grids]
     bands = plan.grids[1:]
     if not bands or any((g.n[0], g.n[1]) != (bands[0].n[0], bands[0].n[1]) for g in bands):
         raise ValueError("layout 'stacked' needs band grids of equal (nx, ny)")
     g0 = plan.grids[0]
-    return [torch.empty((d.batch, d.channels, g0.n[2], g0.n[1], g0.n[0]), dtype=torch.float32, device=device),
+    return [torch.empty((d.batch, d.channels, g0.n[2], g0.n[1], g0.n[0]), dtype=dtype, device=device),
             torch.empty((d.batch, d.channels, sum(g.n[2] for g in bands), bands[0].n[1], bands[0].n[0]),
-                        dtype=torch.float32, device=device)]
+                        dtype=dtype, device=device)]
 
 
 def _views(plan, layout, tensors):
@@ -321,10 +326,11 @@ def _views(plan, layout, tensors):
             zt = t.shape[2]
             v = (d.channels * zt * plane, plane, zt * plane, zoff * plane)
             zoff += g.n[2]
-        if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
-            raise _lib.DhdError('pooled tensors must be contiguous float32 GPU tensors')
-        arr[i].ptr = t.data_ptr() + 4 * v[3]
+        if not t.is_contiguous() or not t.is_cuda or t.dtype != tensors[0].dtype:
+            raise _lib.DhdError('pooled tensors must be contiguous GPU tensors of one dtype')
+        arr[i].ptr = t.data_ptr() + t.element_size() * v[3]
         arr[i].batch_stride, arr[i].z_stride, arr[i].channel_stride = v[0], v[1], v[2]
+        arr[i].dtype = _lib.dtype_code(t.dtype)
     return arr
 
 
@@ -333,19 +339,20 @@ class _MGHSPool(torch.autograd.Function):
     re-laid-out context the lift produced for `workspace` (mghs_op.lift); tran_feat itself only carries the gradient."""
 
     @staticmethod
-    def forward(ctx, depth, tran_feat, plan, workspace, feat_nhwc, layout='collapsed'):
-        # float32 only: callers cast outside the node (see mghs_pool) so that autograd casts the
-        # gradients back to whatever dtype an autocast region produced
+    def forward(ctx, depth, tran_feat, plan, workspace, feat_nhwc, layout='collapsed', out_dtype=torch.float32):
+        # float32 inputs: callers cast outside the node (see mghs_pool) so that autograd casts the gradients back to whatever
+        # dtype an autocast region produced.  out_dtype float16 / bfloat16: the writer rounds its float32 sums on the way out
+        # (= the float32 result followed by .half(), at half the bytes) and the backward reads half gradients as they come.
         depth = _lib.require_gpu_tensor(depth.contiguous(), torch.float32, 'depth')
         lib = _lib.load()
         dev = depth.device
-        outs = _alloc_outputs(plan, layout, dev)
+        outs = _alloc_outputs(plan, layout, dev, out_dtype)
         arr = _views(plan, layout, outs)
         with torch.cuda.device(dev):
             rc = lib.dhd_mghs_forward_views(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
                                             C.byref(workspace.c), _lib.stream_ptr(dev))
         _lib.check(rc, 'dhd_mghs_forward_views')
-        ctx.plan, ctx.layout = plan, layout
+        ctx.plan, ctx.layout, ctx.out_dtype = plan, layout, out_dtype
         ctx.save_for_backward(depth, feat_nhwc, workspace.state)
         return tuple(outs)
 
@@ -356,8 +363,8 @@ class _MGHSPool(torch.autograd.Function):
         lib = _lib.load()
         dev = depth.device
         shapes = [tuple(t.shape) for t in _alloc_shapes(plan, layout)]
-        gs = [torch.zeros(s, dtype=torch.float32, device=dev) if g is None else g.float().contiguous()
-              for g, s in zip(grads, shapes)]
+        gdt = ctx.out_dtype if all(g is None or g.dtype == ctx.out_dtype for g in grads) else torch.float32
+        gs = [torch.zeros(s, dtype=gdt, device=dev) if g is None else g.to(gdt).contiguous() for g, s in zip(grads, shapes)]
         arr = _views(plan, layout, gs)
         bn, fh, fw, c = feat_nhwc.shape
         with torch.cuda.device(dev):
@@ -368,7 +375,7 @@ class _MGHSPool(torch.autograd.Function):
             rc = lib.dhd_mghs_backward_views(C.byref(plan.desc), _lib.ptr(depth), _lib.ptr(feat_nhwc), C.byref(arr),
                                              _lib.ptr(depth_grad), _lib.ptr(feat_grad), C.byref(ws.c), _lib.stream_ptr(dev))
         _lib.check(rc, 'dhd_mghs_backward_views')
-        return depth_grad, (feat_grad if plan.feat_grad_nchw else _nhwc_to_nchw(feat_grad)), None, None, None, None
+        return depth_grad, (feat_grad if plan.feat_grad_nchw else _nhwc_to_nchw(feat_grad)), None, None, None, None, None
 
 
 class _Shape:
@@ -387,25 +394,25 @@ def _alloc_shapes(plan, layout):
             _Shape((d.batch, d.channels, sum(g.n[2] for g in bands), bands[0].n[1], bands[0].n[0]))]
 
 
-def mghs_pool(plan, calib, band, depth, tran_feat, workspace=None, layout='collapsed'):
+def mghs_pool(plan, calib, band, depth, tran_feat, workspace=None, layout='collapsed', out_dtype=torch.float32):
     """Prepare (geometry + grouping) from a given band map and pool.  `workspace` may be passed to reuse memory in
     inference; under autograd a fresh state is held by the graph until backward has run."""
     if workspace is None:
         workspace = plan.new_workspace(depth.device)
     prepare(plan, calib, band, workspace)
     tf = _lib.require_gpu_tensor(tran_feat.float().contiguous(), torch.float32, 'tran_feat')
-    return _MGHSPool.apply(depth.float(), tf, plan, workspace, _nchw_to_nhwc(tf.detach()), layout)
+    return _MGHSPool.apply(depth.float(), tf, plan, workspace, _nchw_to_nhwc(tf.detach()), layout, out_dtype)
 
 
 def mghs_lift_pool(plan, calib, height, height_range, mask_range, depth, tran_feat, workspace=None, layout='collapsed',
-                   static=False):
+                   static=False, out_dtype=torch.float32):
     """MGHS.view_transform's whole device side: dhd_mghs_lift (band ids, context re-layout, geometry + grouping: four
     launches) and the pooling node.  height: (B*N, H, fH, fW) distribution or logits (only its argmax matters)."""
     if workspace is None:
         workspace = plan.new_workspace(depth.device)
     tf = tran_feat.float().contiguous()
     _, feat_nhwc = lift(plan, calib, height, height_range, mask_range, tf.detach(), workspace, static=static)
-    return _MGHSPool.apply(depth.float(), tf, plan, workspace, feat_nhwc, layout)
+    return _MGHSPool.apply(depth.float(), tf, plan, workspace, feat_nhwc, layout, out_dtype)
 
 
 def voxel_index(plan, calib, grid_index, want_ego=False):

@@ -31,7 +31,7 @@ extern "C" {
 #define DHD_ENOSPACE (-2)   /* workspace too small */
 #define DHD_EUNSUPPORTED (-3)
 
-#define DHD_ABI_VERSION 2
+#define DHD_ABI_VERSION 3
 int dhd_abi_version(void);
 
 /* ------------------------------------------------------------------------------------ *
@@ -214,18 +214,33 @@ int dhd_mghs_forward_stream(const dhd_mghs_desc* desc, const float* depth, const
                             float* const out[DHD_MAX_GRIDS], const dhd_mghs_workspace* ws, void* stream);
 
 /* Strided placement of one grid's dense tensor: element (b, z, c, y, x) lives at
- *   ptr + b*batch_stride + z*z_stride + c*channel_stride + y*nx + x      (strides in floats, multiples of 4).
+ *   ptr + b*batch_stride + z*z_stride + c*channel_stride + y*nx + x      (strides in elements, multiples of 4).
  * The default layout of out[g] above is {nz*C*ny*nx, C*ny*nx, ny*nx}.  MGHS_Depth's un-collapsed
  * (B, C, 16, ny, nx) tensor (lss_heightmap.py:845, bev_feat_w_z) is written in place by giving every band
  * grid the view {C*16*ny*nx, ny*nx, 16*ny*nx} with ptr advanced to the band's first z slice: no
  * permute / cat copies. */
+/* Element type of a dense pooled tensor / its gradient.  The reference's operator computes and returns float32
+ * (bev_pool.py:20-21); under autocast (DHD-S.py:281, the fp16 / bf16 configurations) the first convolution behind it casts
+ * that tensor to half at once.  With DHD_F16 / DHD_BF16 the writer emits what that cast would produce -- float32 sums in
+ * the per-voxel table, rounded to nearest even when patched in: bit-identical to `float32 result -> .half()` -- at half
+ * the bytes, and the backward reads half gradients (float32 arithmetic inside).  All views of a call share one dtype; half
+ * types need the compact path (C = 64, ny % 4 == 0, nx % 4 == 0), strides that are multiples of 8 elements and 16-byte
+ * aligned pointers (DHD_EUNSUPPORTED / DHD_EINVAL otherwise). */
+#define DHD_F32 0
+#define DHD_F16 1
+#define DHD_BF16 2
+
 typedef struct dhd_tensor_view {
-  const float* ptr; /* [dev]; written through by dhd_mghs_forward_views */
-  int64_t batch_stride, z_stride, channel_stride;
+  const void* ptr; /* [dev]; written through by dhd_mghs_forward_views */
+  int64_t batch_stride, z_stride, channel_stride; /* in elements */
+  int32_t dtype;   /* DHD_F32 / DHD_F16 / DHD_BF16 */
 } dhd_tensor_view;
 
 int dhd_mghs_forward_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                            const dhd_tensor_view out[DHD_MAX_GRIDS], const dhd_mghs_workspace* ws, void* stream);
+/* the stream phase alone (after dhd_mghs_forward_gather), as dhd_mghs_forward_stream but through views */
+int dhd_mghs_forward_stream_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
+                                  const dhd_tensor_view out[DHD_MAX_GRIDS], const dhd_mghs_workspace* ws, void* stream);
 int dhd_mghs_backward_views(const dhd_mghs_desc* desc, const float* depth, const float* feat_nhwc,
                             const dhd_tensor_view out_grad[DHD_MAX_GRIDS], float* depth_grad,
                             float* feat_grad, const dhd_mghs_workspace* ws, void* stream);

@@ -39,6 +39,7 @@ grep -h ema_update_kernel $(find $OUT/ef -name 'ef_counter_collection.csv') $(fi
 rm -rf $OUT/es $OUT/ef $OUT/ew
 fi
 PREV=${PREV_PROFILES:-$R/profiles/r3}
+ROUND=${ROUND:-r4}
 [ -f $OUT/pmc_fetch_size.csv ] || cp $PREV/pmc_fetch_size.csv $PREV/pmc_write_size.csv $OUT/
 [ -f $OUT/pmc_ema.csv ] || cp $PREV/pmc_ema.csv $OUT/ 2>/dev/null || head -1 $OUT/pmc_fetch_size.csv > $OUT/pmc_ema.csv
 cd $R
@@ -72,7 +73,7 @@ print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in ks.items()}, indent=0
 PY
 # the plain bench line last, with the fresh PMC summary in place (bench.py reports `traffic` only for a matching source hash)
 if [[ " $WHAT " == *" hotpath "* ]]; then
-mkdir -p $R/profiles/r3 && cp $OUT/pmc_summary.json $R/profiles/r3/pmc_summary.json
+mkdir -p $R/profiles/$ROUND && cp $OUT/pmc_summary.json $R/profiles/$ROUND/pmc_summary.json
 cd $R && python bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err
 fi
 ls -la $OUT

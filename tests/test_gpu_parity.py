@@ -403,6 +403,59 @@ def test_full_dhds_size_vs_reference(gpu, batch):
         assert abs(a.astype(np.float64).sum() - g[key][0]) < 1e-5 * g[key][1] + 1e-2
 
 
+@pytest.mark.parametrize('geometry,batch', [('dhd-s', 4), ('dhd-l', 2)])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_half_outputs_equal_the_cast_of_the_float32_path_bit_for_bit(gpu, geometry, batch, dtype):
+    """dhd_tensor_view.dtype = DHD_F16 / DHD_BF16 (the autocast configurations, DHD-S.py:281; the reference's operator returns
+    float32, bev_pool.py:20-21, which the next convolution casts at once): at the full G3 (B = 4) and G15 (DHD-L, B = 2) sizes
+    the writer's half tensors are bit-identical to `float32 outputs -> .to(dtype)`, in the collapsed and the stacked layout, and
+    the backward fed with half gradients returns bit-identical depth / context gradients to the float32 backward fed with the
+    same gradients widened (deterministic grouping: both runs sum in the same order)."""
+    from dhd_amd import mghs_op
+    cfg = syn.dhd_s_config()
+    if geometry == 'dhd-l':
+        cfg['grid_config'] = dict(cfg['grid_config'], depth=[1.0, 45.0, 0.5])
+        cfg['input_size'] = (512, 1408)
+    N = 6
+    fh, fw = cfg['input_size'][0] // 16, cfg['input_size'][1] // 16
+    calib_np = syn.make_calibration(611, batch, N, cfg['input_size'])
+    from oracle import mghs_oracle as O
+    axes = O.frustum_axes(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    D = len(axes[2])
+    depth, feat, hidx = syn.lift_inputs(612, batch, N, D, fh, fw, 64, 65)
+    grids = [mghs_op.grid_from_cfg(g_) for g_ in grid_cfgs(cfg)]
+    plan = mghs_op.Plan(batch, N, D, fh, fw, 64, grids, deterministic=True)
+    assert plan.half_outputs_supported
+    calib, keep = device_calib(calib_np, axes, gpu)
+    height = T(syn.height_probs_from_index(hidx, 65), gpu)
+    for layout in ('collapsed', 'stacked'):
+        res = {}
+        for odt in (torch.float32, dtype):
+            dt, ft = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+            outs = mghs_op.mghs_lift_pool(plan, calib, height, cfg['height_range'], cfg['mask_range'], dt, ft, layout=layout, out_dtype=odt)
+            assert all(o.dtype == odt for o in outs)
+            gs = [T(syn.hash_signed(620 + k, tuple(o.shape)), gpu).to(dtype) for k, o in enumerate(outs)]   # half-representable gradients
+            torch.autograd.backward(outs, [g_.to(odt) for g_ in gs])
+            res[odt] = ([o.detach() for o in outs], dt.grad, ft.grad)
+        for a, b in zip(res[torch.float32][0], res[dtype][0]):
+            assert torch.equal(a.to(dtype), b) and int((b != 0).sum()) > 1000
+        assert torch.equal(res[torch.float32][1], res[dtype][1]) and torch.equal(res[torch.float32][2], res[dtype][2])
+        assert res[dtype][1].abs().sum() > 0
+        del res
+
+
+def test_half_outputs_are_refused_off_the_compact_path(gpu):
+    from dhd_amd import _lib, mghs_op
+    cfg = small_dhds_cfg()
+    plan, axes = make_plan(cfg, 1, 3, channels=24)          # C != 64: the generic row kernels, float32 only
+    assert not plan.half_outputs_supported
+    calib, keep = device_calib(syn.make_calibration(5, 1, 3, cfg['input_size']), axes, gpu)
+    depth, feat, hidx = syn.lift_inputs(6, 1, 3, 44, 4, 11, 24, 65)
+    with pytest.raises(_lib.DhdError, match='UNSUPPORTED'):
+        mghs_op.mghs_lift_pool(plan, calib, T(syn.height_probs_from_index(hidx, 65), gpu), cfg['height_range'], cfg['mask_range'],
+                               T(depth, gpu), T(feat, gpu), out_dtype=torch.float16)
+
+
 def test_full_size_properties_batch4(gpu):
     """BASELINE workload size (B=4): size-independent checks.  (1) checksum: the sum over every
     voxel and channel equals sum over kept points of depth * sum_c feat, computed from the per-point
