@@ -175,6 +175,7 @@ def parse():
     p.add_argument('--fresh-procs', type=int, default=2,
                    help='hotpath, N = 1: repeat the whole measurement in this many fresh processes (other allocator placement of the 0.7 GB '
                         'outputs: one build differs by up to 11 % on the writer between two processes on one box)')
+    p.add_argument('--no-dhdl', action='store_true', help='hotpath: leave out the MGHS-only record at the DHD-L geometry (configs[3]/[4], B = 2)')
     p.add_argument('--child', action='store_true', help='(internal) a --fresh-procs child: print the timing statistics only')
     p.add_argument('--ddp-graph', action='store_true',
                    help='e2e under DDP: capture the whole step, RCCL all-reduces included, into a HIP graph (N = 1 always does; with N > 1 '
@@ -964,7 +965,8 @@ def main():
     n_event_samples = len(hp.ev) * len(reps)
     if a.child:   # a fresh-process repeat: the statistics only
         if rank == 0:
-            print(json.dumps(dict(ms_per_step=stats(per_step), parts=part_stats, repeats=len(reps), steps=a.steps)), flush=True)
+            print(json.dumps(dict(ms_per_step=stats(per_step), parts=part_stats, repeats=len(reps), steps=a.steps,
+                                  pool_fwd_bytes=hp.pool_fwd_bytes, pool_bwd_bytes=hp.pool_bwd_bytes)), flush=True)
         ddist.shutdown()
         return
 
@@ -1035,6 +1037,22 @@ def main():
                 backward_ms=bwd_ms, gemm_tflops_fp32_equivalent=6 * gemm_flop / ((fwd_ms + bwd_ms) * 1e-3) / 1e12,
                 note='six C x C GEMMs per forward+backward; GEMM precision as config.sfa_gemm (include/dhd_amd.h: dhd_sfa_weights.gemm); '
                      'f32-MFMA peak is 157 TFLOP/s')
+    if rank == 0 and world == 1 and a.geometry == 'dhd-s' and not a.no_dhdl and not a.child:
+        # configs[3] / [4]: the view transform of DHD-L.py (6 x 512x1408 -> 32 x 88 maps, D = 88, B = 2 samples per GPU), MGHS part only,
+        # in a child process: 2.97 M points instead of 0.74 M -- the point-proportional kernels weigh more than the writers there
+        t_stage = time.perf_counter()
+        c = fresh_process_repeats(a, n=1, geometry='dhd-l', batch=2, no_sfa=True)[0]
+        if 'error' not in c:
+            wr, bw = c['parts']['writer_ms']['median'], c['parts']['mghs_bwd_ms']['median']
+            c = dict(workload='DHD-L geometry (configs[3]/[4]): 6 cams 512x1408 -> 32x88, D = 88, C = 64, grids 200x200x{1,4,4,8}, B = 2; MGHS '
+                              'lift + pooling forward + backward only', samples_per_gpu=2, ms_per_step=c['ms_per_step'], parts=c['parts'],
+                     bound='hbm', kernel='mghs_stream_fwd', algorithmic_bytes=c['pool_fwd_bytes'], launch_ms=wr,
+                     achieved=c['pool_fwd_bytes'] / (wr * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit='GB/s',
+                     frac=c['pool_fwd_bytes'] / (wr * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     step_frac_of_hbm_floor=(c['pool_fwd_bytes'] + c['pool_bwd_bytes']) / (HBM_PEAK_GBPS * 1e9) / (c['ms_per_step']['median'] * 1e-3),
+                     backward_ms=bw)
+        line['roofline_dhdl'] = c
+        print(f'[bench] DHD-L geometry record {time.perf_counter() - t_stage:.1f} s', file=sys.stderr, flush=True)
     if rank == 0 and world == 1 and a.fresh_procs > 0:
         t_stage = time.perf_counter()
         line['fresh_processes'] = fresh_process_repeats(a)
@@ -1070,16 +1088,19 @@ def main():
     ddist.shutdown()
 
 
-def fresh_process_repeats(a):
+def fresh_process_repeats(a, n=None, geometry=None, batch=None, no_sfa=None):
     """The same W + R x K measurement in `--fresh-procs` new processes (N = 1): another placement of the 0.7 GB outputs and
-    scratch by the allocator, another clock / thermal state.  Returns their statistics (what --child prints)."""
+    scratch by the allocator, another clock / thermal state.  Returns their statistics (what --child prints).  With `geometry` /
+    `batch` / `no_sfa`: another workload of the hot path in a child (the DHD-L geometry record of the default line)."""
     import subprocess
     out = []
+    no_sfa = a.no_sfa if no_sfa is None else no_sfa
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(a.steps), '--warmup', str(a.warmup), '--repeats', str(a.repeats),
-           '--batch', str(a.batch), '--geometry', a.geometry, '--child', '--fresh-procs', '0', '--cpu-samples', '0', '--no-e2e', '--no-operator']
-    cmd += (['--no-sfa'] if a.no_sfa else []) + (['--deterministic'] if a.deterministic else []) + (['--sfa-gemm', a.sfa_gemm] if a.sfa_gemm else [])
+           '--batch', str(batch or a.batch), '--geometry', geometry or a.geometry, '--child', '--fresh-procs', '0', '--cpu-samples', '0', '--no-e2e',
+           '--no-operator']
+    cmd += (['--no-sfa'] if no_sfa else []) + (['--deterministic'] if a.deterministic else []) + (['--sfa-gemm', a.sfa_gemm] if a.sfa_gemm else [])
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    for _ in range(a.fresh_procs):
+    for _ in range(a.fresh_procs if n is None else n):
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
             rows = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]

@@ -40,6 +40,7 @@ struct Layout {
   int nxc;                        // x chunks per row
   int sched_heavy, sched_ratio;   // grid-0 row groups front-loaded 1:ratio among the others
   int flags;       // dhd_mghs_desc.flags
+  int columns;     // the full-height grid's forward sums by pixel column (mghs_col_sums): its sorted entry list is not built
   // scratch carve (device pointers): valid from prepare to the forward after it (offset / s_ent: state carve when
   // !compact, see make_layout)
   int* count;      // [V]     entries per voxel                      } one contiguous, zero-filled range per prepare:
@@ -104,6 +105,10 @@ inline int make_layout(const dhd_mghs_desc* d, const dhd_mghs_workspace* ws, Lay
   for (int g = d->n_grids; g < DHD_MAX_GRIDS; ++g) { L->vox_base[g] = (int)v; L->row_base[g] = (int)r; }
   L->V = (int)v; L->R = (int)r;
   L->compact = compact ? 1 : 0;
+  // Column form (mghs_pool.hip, mghs_col_sums): pays where the runs of equal keys along a pixel column are long and every context
+  // row is re-read many times -- the 32-row feature maps of the DHD-L geometry (measured: gather 134 -> 99 us at B = 2; at the
+  // 16-row maps of DHD-S it loses, 39 -> 47 us); needs the compact path and the default (unordered) summation
+  L->columns = (compact && d->n_grids > 1 && !(d->flags & DHD_MGHS_DETERMINISTIC) && d->fh == 32) ? 1 : 0;
   L->n_segs = compact ? (int)(r / kSegRows) : 0;
   for (int g = d->n_grids; g <= DHD_MAX_GRIDS; ++g) L->seg_base[g] = (int)(r / kSegRows);
   L->n_chunks = dhd_cdiv(v, kChunk);

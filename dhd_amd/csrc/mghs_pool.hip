@@ -116,18 +116,21 @@ struct GatherStep<DHD_WAVE> {
                                              int&, float&) {}
 };
 
+// BANDS_ONLY: the entries of the full-height grid 0 (the first offset[vox_base[1]] of the list) are left to mghs_col_sums.
+template <bool BANDS_ONLY>
 __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float* __restrict__ depth,
                                                             const float* __restrict__ feat) {
   const int lane = threadIdx.x & 63;
+  const int T0 = BANDS_ONLY ? L.offset[L.vox_base[1]] : 0;
   const int T = L.offset[L.V];  // total entries (device-side value, scalar load)
   // everything that steers control flow is forced into SGPRs: the compiler cannot see that
   // threadIdx.x >> 6 is wave-uniform and would otherwise predicate every branch through EXEC
   // XCD x (workgroups x, x+8, ...) takes the x-th eighth of the entries actually present: entries are
   // sorted by voxel, so one XCD's waves gather a compact part of the feature map through their L2
-  const int per_xcd = ((T + kBlock - 1) / kBlock + 7) >> 3;
+  const int per_xcd = ((T - T0 + kBlock - 1) / kBlock + 7) >> 3;
   if ((int)(blockIdx.x >> 3) >= per_xcd) return;
   const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  const int a = rfl((wg * (kBlock / DHD_WAVE) + (threadIdx.x >> 6)) * DHD_WAVE);
+  const int a = rfl(T0 + (wg * (kBlock / DHD_WAVE) + (threadIdx.x >> 6)) * DHD_WAVE);
   if (a >= T) return;
   const int b = min(T, a + DHD_WAVE);
   const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float
     slot_n = en.z;
     pix_n = en.y;
     pid_n = en.x;
-    if (idx > 0) prev_n = L.s_ent[idx - 1].z;
+    if (idx > T0) prev_n = L.s_ent[idx - 1].z;   // (column form: grid 0's entries before T0 are not written)
   }
   if (idx < T) dv_n = depth[pid_n];
   for (int a0 = a; a0 < T; a0 += DHD_WAVE) {
@@ -193,6 +196,87 @@ __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float
     if (idx < T) dv_n = depth[pid_n];
   }
   vrow[(size_t)cur * kTileC] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// 1b. forward sums of the FULL-HEIGHT grid 0 by pixel column ("column form").
+// Grid 0 pools every pixel and has one z cell, so the fH rows of a pixel column at one depth bin mostly fall into the same
+// voxel: measured on the benchmark's rigs, runs of equal keys along a column are 6.3 rows long at the DHD-S geometry and 11.9
+// at DHD-L, and grid 0 holds 80 % of all entries.  mghs_gather_sums reads one 256-byte context row per ENTRY (D = 44 / 88 times
+// per row: 1.5 GB of L2 gathers per step at the DHD-L geometry, B = 2).  Here a wave owns a pixel column (camera, w) and
+// kDepthChunk depth bins: the column's fH context rows are loaded ONCE into registers (lane = channel), the keys / depth
+// values / slots of a depth bin are fetched by lanes 0..fH-1, and the rows are walked with compile-time register numbers --
+// one v_readlane + v_fmac per row, a flush of the running sum at every key change: one atomic add per RUN and channel into
+// vsum[slot].  The band grids (z cells of 0.4 m: runs of 1.1-1.2 rows) stay with mghs_gather_sums<true>.
+// Summation order inside a voxel is the arrival order of the atomics (the float32 sum differs in its last bits from run to
+// run, as with the default grouping); DHD_MGHS_DETERMINISTIC keeps the sorted gather for all grids.
+// ---------------------------------------------------------------------------------------
+constexpr int kDepthChunk = 8;
+
+__global__ __launch_bounds__(kBlock) void mghs_zero_grid0_rows(Layout L) {
+  const int n0 = L.nzoff[L.vox_base[1]];                       // non-empty voxels of grid 0 = its slots [0, n0)
+  vfloat4* v = reinterpret_cast<vfloat4*>(L.vsum);
+  const size_t n4 = (size_t)n0 * (kTileC / 4);
+  const vfloat4 z = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) v[i] = z;
+}
+
+template <int FH, int H>
+struct ColStep {
+  static __device__ __forceinline__ void run(const float (&f)[FH], unsigned long long firsts, int slot, float dv, float* vrow,
+                                             int& cur, float& acc) {
+    if ((firsts >> H) & 1ull) {                                  // wave-uniform: a new run starts at row H
+      if (cur >= 0) atomicAdd(vrow + (size_t)cur * kTileC, acc);
+      cur = rfl(lane_i(slot, H));
+      acc = 0.f;
+    }
+    acc = fmaf(lane_f(dv, H), f[H], acc);                        // dv = 0 for dropped points
+    ColStep<FH, H + 1>::run(f, firsts, slot, dv, vrow, cur, acc);
+  }
+};
+template <int FH>
+struct ColStep<FH, FH> {
+  static __device__ __forceinline__ void run(const float (&)[FH], unsigned long long, int, float, float*, int&, float&) {}
+};
+
+template <int FH>
+__global__ __launch_bounds__(kBlock) void mghs_col_sums(Layout L, const float* __restrict__ depth, const float* __restrict__ feat) {
+  const int lane = threadIdx.x & 63;
+  const int n_chunks = (L.D + kDepthChunk - 1) / kDepthChunk;
+  const int wave = rfl((int)(blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6)));
+  const int n_cols = L.B * L.N * L.fw;
+  if (wave >= n_cols * n_chunks) return;
+  // consecutive waves = consecutive columns of one camera and depth chunk (neighbouring columns hit neighbouring voxels)
+  const int chunk = wave / n_cols, col = wave - chunk * n_cols;
+  const int bn = col / L.fw, w = col - bn * L.fw;
+  float f[FH];
+#pragma unroll
+  for (int h = 0; h < FH; ++h) f[h] = feat[((size_t)(bn * FH + h) * L.fw + w) * kTileC + lane];
+  float* vrow = L.vsum + lane;
+  const int d0 = chunk * kDepthChunk;
+  const int hl = lane < FH ? lane : FH - 1;                      // lanes >= FH repeat the last row (never a run start)
+  int key[kDepthChunk], slot[kDepthChunk];
+  float dv[kDepthChunk];
+#pragma unroll
+  for (int k = 0; k < kDepthChunk; ++k) {
+    const int d = min(d0 + k, L.D - 1);
+    const int p = ((bn * L.D + d) * FH + hl) * L.fw + w;
+    key[k] = d0 + k < L.D ? L.key[p] : -1;
+    dv[k] = depth[p];
+  }
+#pragma unroll
+  for (int k = 0; k < kDepthChunk; ++k) slot[k] = key[k] >= 0 ? L.nzoff[key[k]] : -1;
+#pragma unroll
+  for (int k = 0; k < kDepthChunk; ++k) {
+    const int prev = __shfl_up(slot[k], 1, DHD_WAVE);
+    // run starts: row 0 and every change of slot (dropped rows form runs of slot -1, whose sums are discarded)
+    const unsigned long long firsts = __ballot(lane < FH && (lane == 0 || slot[k] != prev));
+    const float dvk = key[k] >= 0 ? dv[k] : 0.f;
+    int cur = -1;
+    float acc = 0.f;
+    ColStep<FH, 0>::run(f, firsts, slot[k], dvk, vrow, cur, acc);
+    if (cur >= 0) atomicAdd(vrow + (size_t)cur * kTileC, acc);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -753,9 +837,19 @@ int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const
   if (rc) return rc;
   if (!workspace || !depth || !feat_nhwc) return DHD_EINVAL;
   if (!L.compact) return DHD_OK;  // the generic path gathers inside its row kernel
-  // 2P is an upper bound of the entry count; waves past the real count exit at once
-  hipLaunchKernelGGL(mghs_gather_sums, dim3(dhd_cdiv(2L * L.P, 8 * kBlock) * 8), dim3(kBlock), 0, dhd_stream(stream), L, depth,
-                     feat_nhwc);
+  hipStream_t st = dhd_stream(stream);
+  // column form for the full-height grid (Layout::columns), sorted gather for the rest
+  if (L.columns) {
+    hipLaunchKernelGGL(mghs_zero_grid0_rows, dim3(1024), dim3(kBlock), 0, st, L);
+    const int waves = L.B * L.N * L.fw * dhd_cdiv(L.D, kDepthChunk);
+    const dim3 grid(dhd_cdiv(waves, kBlock / DHD_WAVE));
+    hipLaunchKernelGGL(mghs_col_sums<32>, grid, dim3(kBlock), 0, st, L, depth, feat_nhwc);
+    // the band grids' entries: at most one per point
+    hipLaunchKernelGGL(mghs_gather_sums<true>, dim3(dhd_cdiv((long)L.P, 8 * kBlock) * 8), dim3(kBlock), 0, st, L, depth, feat_nhwc);
+  } else {
+    // 2P is an upper bound of the entry count; waves past the real count exit at once
+    hipLaunchKernelGGL(mghs_gather_sums<false>, dim3(dhd_cdiv(2L * L.P, 8 * kBlock) * 8), dim3(kBlock), 0, st, L, depth, feat_nhwc);
+  }
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }

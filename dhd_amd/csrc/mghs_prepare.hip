@@ -396,9 +396,9 @@ __global__ __launch_bounds__(kBlock) void mghs_scatter(Layout L, int blocks_per_
     int k = L.key[j * L.P + pid];
     int slot = -1;
     if (k >= 0) {
-      int pos = L.offset[k] + L.rnk[j * L.P + pid];
       slot = L.nzoff[k];
-      L.s_ent[pos] = make_int4(pid, pix, slot, 0);
+      if (j == 1 || !L.columns)   // column form: nobody reads grid 0's sorted entries (forward by column, backward by p_slot)
+        L.s_ent[L.offset[k] + L.rnk[j * L.P + pid]] = make_int4(pid, pix, slot, 0);
     }
     L.p_slot[j * L.P + pid] = slot;
   }

@@ -188,7 +188,7 @@ class MGHS(nn.Module):
         # Under autocast the reference's operator returns float32 (bev_pool.py:20-21) and the first convolution behind it casts
         # the 174 MB per sample to half at once.  `amp_outputs` (default on) lets the writer emit that half tensor directly --
         # bit-identical to the cast of the float32 result -- and the backward read half gradients.
-        odt = (torch.get_autocast_gpu_dtype() if self.amp_outputs and torch.is_autocast_enabled() and plan.half_outputs_supported
+        odt = (torch.get_autocast_dtype('cuda') if self.amp_outputs and torch.is_autocast_enabled() and plan.half_outputs_supported
                else torch.float32)
         if odt not in (torch.float16, torch.bfloat16):
             odt = torch.float32
