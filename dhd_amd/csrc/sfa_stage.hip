@@ -10,11 +10,18 @@
 // backward).  They run on the matrix cores with everything element-wise FUSED into the operand path, so no
 // intermediate but y1 and y2 is ever stored.  GEMM precision per call (dhd_sfa_weights.gemm, include/dhd_amd.h):
 //   bf16x3 (default) bf16 MFMA on a two-way split of every float32 operand, three products per a*b (error <= 3 * 2^-18 |ab|
-//               per product): pw_gemm_res<2> (weights resident in LDS) / pw_wgrad3;
+//               per product): pw_gemm_cu (sfa_gemm_cu.h: one CU per pixel tile, weights in registers) at C = 128 / 256,
+//               pw_gemm_res<2> (weights resident in LDS, teams of CUs) at C = 512; pw_wgrad3;
 //   bf16x6      exact three-way split, six products per a*b: float32-level accuracy at 6/16 of the f32-MFMA cost
 //               (pw_gemm_res<3>, or pw_gemm6 with the weights streamed through LDS where the resident form does not cover the
 //               channel count; pw_wgrad6);
 //   f32         f32 MFMA (v_mfma_f32_32x32x2_f32), a plain float32 fma chain (pw_gemm / pw_wgrad).
+// Which shapes reach which family (all three stay reachable, so all three stay in this file):
+//   pw_gemm_cu           bf16x3, C = 128, 256                       (DHD-S / DHD-L: SFA(512, 256))
+//   pw_gemm_res<2>       bf16x3, C = 512                            (DHD-M: SFA(1024, 512))
+//   pw_gemm_res<3>       bf16x6, C = 128, 256
+//   pw_gemm6 (streamed)  bf16x6, C = 512 and multiples of 256 beyond (three parts of 512 channels do not fit LDS)
+//   pw_gemm / pw_wgrad   DHD_SFA_GEMM_F32 at every supported C (the float32 reference point of the precision table)
 // Common structure:
 //   * forward / dgrad GEMM: a wave owns 32 pixels x 256 output channels (128 accumulator registers).  The
 //     activation operand is loaded straight from NCHW global memory into the MFMA operand layout (lane =

@@ -647,8 +647,12 @@ _TIE = 2e-6
 
 # GEMM precisions of the stage operator (include/dhd_amd.h: dhd_sfa_weights.gemm, per call) and the tolerance factor the
 # tests grant them relative to the float32-level one: bf16x3 (the default) drops product terms of relative size
-# <= 3 * 2^-18, the path's bar on outputs is 1e-3 (BASELINE.json north_star)
-GEMM_MODES = {'bf16x3': 20.0, 'bf16x6': 1.0}
+# <= 3 * 2^-18, the path's bar on outputs is 1e-3 (BASELINE.json north_star).  The factor is what the gradients measure, not slack:
+# round 4 reran the bf16x3 cases with DHD_TEST_BF16X3_FACTOR = 3 / 5 / 8 (the full-size comparison with PyTorch and the float64
+# oracle's training case fail: parameter gradients of sums over 10^5 products) and 12 (two C = 128 cases fail); 20 is the first
+# round value that holds everywhere.
+import os as _os
+GEMM_MODES = {'bf16x3': float(_os.environ.get('DHD_TEST_BF16X3_FACTOR', 20.0)), 'bf16x6': 1.0}
 
 
 class gemm_mode:
