@@ -36,6 +36,7 @@ class MghsDesc(C.Structure):
 
 MGHS_DETERMINISTIC = 1     # dhd_mghs_desc.flags
 MGHS_FEAT_GRAD_NCHW = 2
+MGHS_DEBUG_SCAN_SELF_SERVE = 4
 
 
 class MghsWorkspace(C.Structure):

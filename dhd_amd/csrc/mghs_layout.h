@@ -74,7 +74,7 @@ inline int make_layout(const dhd_mghs_desc* d, const dhd_mghs_workspace* ws, Lay
   if (d->batch <= 0 || d->n_cams <= 0 || d->n_depth <= 0 || d->fh <= 0 || d->fw <= 0 || d->channels <= 0)
     return DHD_EINVAL;
   if (d->n_grids < 1 || d->n_grids > DHD_MAX_GRIDS) return DHD_EINVAL;
-  if (d->flags & ~(DHD_MGHS_DETERMINISTIC | DHD_MGHS_FEAT_GRAD_NCHW)) return DHD_EINVAL;
+  if (d->flags & ~(DHD_MGHS_DETERMINISTIC | DHD_MGHS_FEAT_GRAD_NCHW | DHD_MGHS_DEBUG_SCAN_SELF_SERVE)) return DHD_EINVAL;
   L->flags = d->flags;
   L->B = d->batch; L->N = d->n_cams; L->D = d->n_depth; L->fh = d->fh; L->fw = d->fw;
   L->C = d->channels; L->G = d->n_grids;

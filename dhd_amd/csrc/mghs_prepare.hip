@@ -297,6 +297,8 @@ __global__ __launch_bounds__(kBlock) void mghs_voxel_index_kernel(Layout L, dhd_
 // 30 us with chunks handed out by an atomic ticket (1 328 returning atomics on one address), with or without a look-back
 // chain; 14 us as below.  Value and flag share one word, written and read with relaxed device-scope atomics: no fences.
 // ---------------------------------------------------------------------------------------
+constexpr int kScanSpinLimit = 1 << 16;   // polls of one predecessor word (~1 us each under load) before self-service
+
 __device__ __forceinline__ unsigned long long scan_word(int entries, int slots) {
   return (1ull << 63) | ((unsigned long long)(unsigned)entries << 32) | (unsigned long long)(unsigned)slots;
 }
@@ -341,11 +343,29 @@ __global__ __launch_bounds__(kBlock) void mghs_scan(Layout L) {
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // the aggregates of all predecessor chunks
   int part = 0, partz = 0;
+  // Waiting only for lower-numbered workgroups is safe while a 1-D grid is dispatched in index order -- what the hardware does,
+  // not something HIP promises.  So the wait is BOUNDED: a predecessor that has not published after kScanSpinLimit polls (it may
+  // not have been started yet while this workgroup occupies its slot) is not waited for any longer -- its counters are final
+  // (the counting kernel finished before this launch), so the thread sums that chunk itself.  Slow, never taken in practice,
+  // and exact; DHD_MGHS_DEBUG_SCAN_SELF_SERVE (tests) sets the limit to zero so that every aggregate goes this way.
+  const int spin_limit = (L.flags & DHD_MGHS_DEBUG_SCAN_SELF_SERVE) ? 0 : kScanSpinLimit;
   for (int j = t; j < chunk; j += kBlock) {
-    unsigned long long w;
-    do { w = __hip_atomic_load(L.scan_state + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 63) == 0);
-    part += (int)((w >> 32) & 0x7fffffffu);
-    partz += (int)(w & 0xffffffffu);
+    unsigned long long w = 0;
+    for (int spins = 0; spins < spin_limit; ++spins) {
+      w = __hip_atomic_load(L.scan_state + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w >> 63) break;
+    }
+    if (w >> 63) {
+      part += (int)((w >> 32) & 0x7fffffffu);
+      partz += (int)(w & 0xffffffffu);
+    } else {
+      const int lo = j * kChunk, hi = min(V, lo + kChunk);
+      for (int i = lo; i < hi; ++i) {
+        const int cnt = L.count[i];
+        part += cnt;
+        partz += cnt > 0;
+      }
+    }
   }
   part = wave_sum_i(part);
   partz = wave_sum_i(partz);

@@ -115,6 +115,7 @@ typedef struct dhd_mghs_desc {
  *       reference's tran_feat -- instead of (B*N, fH, fW, C), so that the caller needs no transposition pass. */
 #define DHD_MGHS_DETERMINISTIC 1
 #define DHD_MGHS_FEAT_GRAD_NCHW 2
+#define DHD_MGHS_DEBUG_SCAN_SELF_SERVE 4 /* tests only: the single-pass scan never waits for another workgroup (its bounded-spin fallback for every chunk) */
 
 /* Camera calibration, all [dev] float32, laid out as the reference's input list
  * (lss_heightmap.py:384-390).  inv_post_rot / combine are OPTIONAL (may be NULL): when given they

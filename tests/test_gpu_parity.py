@@ -924,6 +924,34 @@ def test_accelerate_caches_only_what_is_static(gpu):
         mghs_op.set_deterministic(False)
 
 
+def test_scan_without_waiting_for_other_workgroups_gives_the_same_grouping(gpu):
+    """mghs_scan waits for lower-numbered workgroups' chunk aggregates with a bounded spin; past the bound a thread sums the
+    predecessor's chunk itself (exact: the counters are final).  DHD_MGHS_DEBUG_SCAN_SELF_SERVE sets the bound to zero, so EVERY
+    aggregate takes the fallback: at the full DHD-S size with B = 4 (1 328 chunks) the slots, the per-point keys and (deterministic
+    mode) the pooled tensors are identical to the normal run."""
+    from dhd_amd import _lib, mghs_op
+    cfg = syn.dhd_s_config()
+    B = 4
+    calib_np = syn.make_calibration(901, B, 6, cfg['input_size'])
+    depth, feat, hidx = syn.lift_inputs(902, B, 6, 44, 16, 44, 64, 65)
+    plan, axes = make_plan(cfg, B, 6)
+    calib, keep = device_calib(calib_np, axes, gpu)
+    height = T(syn.height_probs_from_index(hidx, 65), gpu)
+    res = []
+    for self_serve in (False, True):
+        p = mghs_op.Plan(B, 6, 44, 16, 44, 64, plan.grids, deterministic=True)
+        if self_serve:
+            p.desc.flags |= _lib.MGHS_DEBUG_SCAN_SELF_SERVE
+        ws = p.new_workspace(gpu, private_scratch=True)
+        with torch.no_grad():
+            outs = mghs_op.mghs_lift_pool(p, calib, height, cfg['height_range'], cfg['mask_range'], T(depth, gpu), T(feat, gpu), ws)
+        res.append((outs, mghs_op.debug_keys(p, ws), mghs_op.stats(p, ws)))
+    (o0, k0, s0), (o1, k1, s1) = res
+    assert s0 == s1 and s0[0][0] > 400000 and torch.equal(k0, k1)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+
+
 def test_batch_of_eight_equals_two_batches_of_four(gpu):
     """B = 8 at the full DHD-S size: 5.44 M voxel counters = 2 656 scan chunks, more workgroups than the chip holds at once
     (the single-pass scan waits only for lower-numbered chunks, which are dispatched first).  Samples are independent, so
