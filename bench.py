@@ -496,10 +496,33 @@ def mghs_amp_record(hp, steps, warmup, dtype=torch.float16):
             del outs, consumed, grads
         torch.cuda.synchronize()
         out[mode] = dict(mghs_step_ms=event_mean(ev_step), writer_ms=event_mean(ev_wr))
+    if hp.with_sfa:
+        # the SFA stage operator in the same two regimes: x arrives in half (the concatenated encoder outputs of an autocast region)
+        xh = hp.x.detach().to(dtype).requires_grad_()
+        gyh = hp.gy.to(dtype)
+        for mode in ('f32_nodes_plus_casts', 'half_io'):
+            ev = []
+            for it in range(warmup + steps):
+                xh.grad = None
+                for prm in hp.stage_params:
+                    prm.grad = None
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                e[0].record()
+                # float32 node: the caller widens x and narrows the result, autograd does the same to the gradients on the way back
+                y = hp.stage(xh.float()).to(dtype) if mode == 'f32_nodes_plus_casts' else hp.stage(xh)
+                y.backward(gyh)
+                e[1].record()
+                if it >= warmup:
+                    ev.append(tuple(e))
+            torch.cuda.synchronize()
+            out[mode]['sfa_stage_ms'] = event_mean(ev)
+            out[mode]['hot_path_ms'] = out[mode]['mghs_step_ms'] + out[mode]['sfa_stage_ms']
+        del xh, gyh
     out['dtype'] = str(dtype).replace('torch.', '')
     out['writer_half_GBps'] = hp.pool_fwd_bytes / 2 / (out['half_io']['writer_ms'] * 1e-3) / 1e9   # half the output bytes (+ the 1 % of inputs)
     out['note'] = ('MGHS part of the hot path only (lift + pooling forward + backward), B = %d; writer_ms = the streaming writer alone '
-                   '(half: 352 MB instead of 704 MB at B = 4); the SFA stage operator keeps float32 I/O' % hp.B)
+                   '(half: 352 MB instead of 704 MB at B = 4); sfa_stage_ms = the stage operator forward + backward with a half x: widened and '
+                   'narrowed around a float32 node, or dhd_sfa_weights.io_dtype (out / gout / gx in half, x widened once inside)' % hp.B)
     return out
 
 

@@ -72,7 +72,7 @@ class SfaWeights(C.Structure):
                   'conv2_w', 'conv2_b', 'bn2_w', 'bn2_b', 'bn2_mean', 'bn2_var')] +
                 [('hidden', C.c_int32), ('training', C.c_int32), ('eps1', C.c_float), ('eps2', C.c_float),
                  ('momentum1', C.c_float), ('momentum2', C.c_float), ('gemm', C.c_int32),
-                 ('bn1_batches', C.c_void_p), ('bn2_batches', C.c_void_p)])
+                 ('bn1_batches', C.c_void_p), ('bn2_batches', C.c_void_p), ('io_dtype', C.c_int32)])
 
 
 SFA_GEMM = {'default': 0, 'bf16x6': 1, 'f32': 2, 'bf16x3': 3}   # dhd_sfa_weights.gemm

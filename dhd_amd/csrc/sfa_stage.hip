@@ -535,16 +535,47 @@ __global__ __launch_bounds__(kEwBlock) void pair_sums_kernel(const float* __rest
 // fused blends
 // ------------------------------------------------------------------------------------------------
 
+// Four consecutive elements of the stage's edge tensors (out, gout, gx: dhd_sfa_weights.io_dtype) as float32: 16 bytes of
+// float32, 8 bytes of a half type (widened exactly / rounded to nearest even).
+template <class T> __device__ __forceinline__ f32x4 ld4(const T* base, size_t i4);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* base, size_t i4) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base) + i4);
+}
+template <> __device__ __forceinline__ f32x4 ld4<_Float16>(const _Float16* base, size_t i4) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const h4 v = __builtin_nontemporal_load(reinterpret_cast<const h4*>(base) + i4);
+  return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w};
+}
+template <> __device__ __forceinline__ f32x4 ld4<__bf16>(const __bf16* base, size_t i4) {
+  const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(base) + i4);
+  return f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
+}
+template <class T> __device__ __forceinline__ void st4(T* base, size_t i4, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* base, size_t i4, f32x4 v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base) + i4);
+}
+template <> __device__ __forceinline__ void st4<_Float16>(_Float16* base, size_t i4, f32x4 v) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  __builtin_nontemporal_store(h, reinterpret_cast<h4*>(base) + i4);
+}
+template <> __device__ __forceinline__ void st4<__bf16>(__bf16* base, size_t i4, f32x4 v) {
+  typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+  const b4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  __builtin_nontemporal_store(h, reinterpret_cast<b4*>(base) + i4);
+}
+
 // out = g*(a*xb) + (1-g)*((1-a)*xv),  g = sigmoid(sc*y2 + sh)
+template <class TO>
 __global__ __launch_bounds__(kEwBlock) void blend2_bn_kernel(const float* __restrict__ x, const float* __restrict__ a1,
                                                              const float* __restrict__ y2, const float* __restrict__ scsh,
-                                                             float* __restrict__ out, int c, int hw) {
+                                                             TO* __restrict__ out, int c, int hw) {
   const int plane = blockIdx.y, b = plane / c, ch = plane % c;
   const float a = a1[plane], na = 1.0f - a, sc = scsh[ch], sh = scsh[c + ch];
   const f32x4* b4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + ch) * hw);
   const f32x4* v4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + c + ch) * hw);
   const f32x4* y4 = reinterpret_cast<const f32x4*>(y2 + (size_t)plane * hw);
-  f32x4* o4 = reinterpret_cast<f32x4*>(out + (size_t)plane * hw);
+  TO* o4 = out + (size_t)plane * hw;
   int lo, hi;
   chunk_range4(hw, &lo, &hi);
   for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
@@ -554,15 +585,16 @@ __global__ __launch_bounds__(kEwBlock) void blend2_bn_kernel(const float* __rest
       const float g = sigmoidf_(fmaf(sc, s[j], sh));
       r[j] = g * (a * p[j]) + (1.0f - g) * (na * q[j]);
     }
-    __builtin_nontemporal_store(r, o4 + i);
+    st4<TO>(o4, i, r);
   }
 }
 
 // g2 = dL/d s2 = go*(a*xb - (1-a)*xv)*g*(1-g); sums for BatchNorm-2 backward; the go-part of dL/da:
 // sum go*(g*xb - (1-g)*xv).   part: [(b*chunks+chunk)][2][c];  da_p1: [(b*chunks+chunk)][c]
+template <class TO>
 __global__ __launch_bounds__(kEwBlock) void blend2_bn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ a1,
                                                                  const float* __restrict__ y2, const float* __restrict__ scsh,
-                                                                 const float* __restrict__ mean, const float* __restrict__ go,
+                                                                 const float* __restrict__ mean, const TO* __restrict__ go,
                                                                  float* __restrict__ g2, float* __restrict__ part,
                                                                  float* __restrict__ da_p1, int c, int hw, BnTail tail) {
   __shared__ float sm[kEwBlock / DHD_WAVE];
@@ -571,13 +603,13 @@ __global__ __launch_bounds__(kEwBlock) void blend2_bn_bwd_kernel(const float* __
   const f32x4* b4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + ch) * hw);
   const f32x4* v4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + c + ch) * hw);
   const f32x4* y4 = reinterpret_cast<const f32x4*>(y2 + (size_t)plane * hw);
-  const f32x4* o4 = reinterpret_cast<const f32x4*>(go + (size_t)plane * hw);
+  const TO* o4 = go + (size_t)plane * hw;
   f32x4* r4 = reinterpret_cast<f32x4*>(g2 + (size_t)plane * hw);
   int lo, hi;
   chunk_range4(hw, &lo, &hi);
   float s1 = 0.f, s2 = 0.f, sa = 0.f;
   for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
-    f32x4 p = __builtin_nontemporal_load(b4 + i), q = __builtin_nontemporal_load(v4 + i), s = y4[i], o = __builtin_nontemporal_load(o4 + i), r;
+    f32x4 p = __builtin_nontemporal_load(b4 + i), q = __builtin_nontemporal_load(v4 + i), s = y4[i], o = ld4<TO>(o4, i), r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float g = sigmoidf_(fmaf(sc, s[j], sh));
@@ -619,10 +651,11 @@ __global__ __launch_bounds__(kEwBlock) void blend1_da_kernel(const float* __rest
 }
 
 // gx_bev = a*(go*g + du) + ds_bev/hw;  gx_vox = (1-a)*(go*(1-g) + du) + ds_vox/hw
+template <class TO>
 __global__ __launch_bounds__(kEwBlock) void stage_gx_kernel(const float* __restrict__ a1, const float* __restrict__ y2,
-                                                            const float* __restrict__ scsh, const float* __restrict__ go,
+                                                            const float* __restrict__ scsh, const TO* __restrict__ go,
                                                             const float* __restrict__ du, const float* __restrict__ ds,
-                                                            float* __restrict__ gx, int c, int hw, int fc_rows, FcGradJob fc) {
+                                                            TO* __restrict__ gx, int c, int hw, int fc_rows, FcGradJob fc) {
   if ((int)blockIdx.y < fc_rows) {   // the first block rows: the Linear layers' parameter gradients (dispatched first, no tail)
     fc_param_grad_block(fc, (int)blockIdx.y * kPlaneChunks + (int)blockIdx.x, c);
     return;
@@ -631,22 +664,22 @@ __global__ __launch_bounds__(kEwBlock) void stage_gx_kernel(const float* __restr
   const float a = a1[plane], na = 1.0f - a, sc = scsh[ch], sh = scsh[c + ch];
   const float kb = ds[(size_t)b * 2 * c + ch] / (float)hw, kv = ds[(size_t)b * 2 * c + c + ch] / (float)hw;
   const f32x4* y4 = reinterpret_cast<const f32x4*>(y2 + (size_t)plane * hw);
-  const f32x4* o4 = reinterpret_cast<const f32x4*>(go + (size_t)plane * hw);
+  const TO* o4 = go + (size_t)plane * hw;
   const f32x4* d4 = reinterpret_cast<const f32x4*>(du + (size_t)plane * hw);
-  f32x4* gb4 = reinterpret_cast<f32x4*>(gx + ((size_t)b * 2 * c + ch) * hw);
-  f32x4* gv4 = reinterpret_cast<f32x4*>(gx + ((size_t)b * 2 * c + c + ch) * hw);
+  TO* gb4 = gx + ((size_t)b * 2 * c + ch) * hw;
+  TO* gv4 = gx + ((size_t)b * 2 * c + c + ch) * hw;
   int lo, hi;
   chunk_range4(hw, &lo, &hi);
   for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
-    f32x4 s = __builtin_nontemporal_load(y4 + i), o = __builtin_nontemporal_load(o4 + i), d = __builtin_nontemporal_load(d4 + i), rb, rv;
+    f32x4 s = __builtin_nontemporal_load(y4 + i), o = ld4<TO>(o4, i), d = __builtin_nontemporal_load(d4 + i), rb, rv;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float g = sigmoidf_(fmaf(sc, s[j], sh));
       rb[j] = fmaf(a, fmaf(o[j], g, d[j]), kb);
       rv[j] = fmaf(na, fmaf(o[j], 1.0f - g, d[j]), kv);
     }
-    __builtin_nontemporal_store(rb, gb4 + i);
-    __builtin_nontemporal_store(rv, gv4 + i);
+    st4<TO>(gb4, i, rb);
+    st4<TO>(gv4, i, rv);
   }
 }
 
@@ -2457,7 +2490,7 @@ size_t dhd_sfa_stage_scratch_bytes(int b, int c, int hw, int hidden) {
 // this call's own statistics.  sync != nullptr (nn.SyncBatchNorm): phases [lo, hi]; a phase that ends at a statistics point
 // leaves this rank's sums in `sync` ((2C + 1) doubles: [sum (y - bias)][C] | [sum (y - bias)^2][C] | count), the next phase
 // starts from the caller's all-reduced vector in the same place.
-static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, float* out, void* saved, void* scratch, int b, int c, int hw,
+static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch, int b, int c, int hw,
                               int lo, int hi, double* sync, void* stream) {
   if (!x || !w || !saved || !scratch || b <= 0 || (hi == 2 && !out)) return DHD_EINVAL;
   if (!stage_supported(c, hw) || w->hidden <= 0) return DHD_EUNSUPPORTED;
@@ -2466,6 +2499,7 @@ static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, float* o
     return DHD_EINVAL;
   if (!w->training && (!w->bn1_mean || !w->bn1_var || !w->bn2_mean || !w->bn2_var)) return DHD_EINVAL;
   if (set_call_mode(w->gemm) != DHD_OK) return DHD_EINVAL;
+  if (w->io_dtype != DHD_F32 && w->io_dtype != DHD_F16 && w->io_dtype != DHD_BF16) return DHD_EINVAL;
   hipStream_t st = dhd_stream(stream);
   const int r = w->hidden;
   const SavedLayout S = saved_layout(b, c, hw, r);
@@ -2558,14 +2592,19 @@ static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, float* o
     hipLaunchKernelGGL(bn_eval_coef_kernel, per_ch, dim3(kEwBlock), 0, st, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, w->eps2,
                        sv + S.mean2, sv + S.rstd2, sv + S.scsh2, tab_unused, b, c);
   }
-  hipLaunchKernelGGL(blend2_bn_kernel, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, out, c, hw);
+  if (w->io_dtype == DHD_F16)
+    hipLaunchKernelGGL(blend2_bn_kernel<_Float16>, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, static_cast<_Float16*>(out), c, hw);
+  else if (w->io_dtype == DHD_BF16)
+    hipLaunchKernelGGL(blend2_bn_kernel<__bf16>, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, static_cast<__bf16*>(out), c, hw);
+  else
+    hipLaunchKernelGGL(blend2_bn_kernel<float>, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, static_cast<float*>(out), c, hw);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
 
 // Backward in up to three phases, cut where the two BatchNorm backward passes need their sums (sum g, sum g (y - mu)); `sync`
 // as in stage_forward_impl ((2C + 1) doubles: [sum g][C] | [sum g (y - mu)][C] | count).
-static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const void* saved, const float* gout, float* gx,
+static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const void* saved, const void* gout, void* gx,
                                const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw, int lo, int hi, double* sync,
                                void* stream) {
   if (!x || !w || !saved || !gout || !grads || !scratch || b <= 0 || (hi == 2 && !gx)) return DHD_EINVAL;
@@ -2574,6 +2613,7 @@ static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const v
       !grads->bn1_b || !grads->conv2_w || !grads->conv2_b || !grads->bn2_w || !grads->bn2_b)
     return DHD_EINVAL;
   if (set_call_mode(w->gemm) != DHD_OK) return DHD_EINVAL;
+  if (w->io_dtype != DHD_F32 && w->io_dtype != DHD_F16 && w->io_dtype != DHD_BF16) return DHD_EINVAL;
   if (sync && !(w->training && g_gemm_mode >= 1)) return DHD_EUNSUPPORTED;
   hipStream_t st = dhd_stream(stream);
   const int r = w->hidden;
@@ -2592,8 +2632,13 @@ static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const v
     int* tick = reinterpret_cast<int*>(const_cast<float*>(sv + S.tick));
     const BnTail tail2 = {sync ? nullptr : tick, w->bn2_w, sv + S.mean2, sv + S.rstd2, sc + T.tab_g2, grads->bn2_w, grads->bn2_b,
                           grads->conv2_b, w->training, b, hw};
-    hipLaunchKernelGGL(blend2_bn_bwd_kernel, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, sv + S.mean2, gout,
-                       sc + T.g2, sc + T.part, sc + T.da1, c, hw, tail2);
+#define DHD_B2BWD(TO)                                                                                                        \
+  hipLaunchKernelGGL(blend2_bn_bwd_kernel<TO>, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, sv + S.mean2, \
+                     static_cast<const TO*>(gout), sc + T.g2, sc + T.part, sc + T.da1, c, hw, tail2)
+    if (w->io_dtype == DHD_F16) DHD_B2BWD(_Float16);
+    else if (w->io_dtype == DHD_BF16) DHD_B2BWD(__bf16);
+    else DHD_B2BWD(float);
+#undef DHD_B2BWD
     if (sync)
       hipLaunchKernelGGL(bn_backward_coef_kernel, per_ch, dim3(kEwBlock), 0, st, sc + T.part, w->bn2_w, sv + S.mean2, sv + S.rstd2,
                          w->training, sc + T.tab_g2, grads->bn2_w, grads->bn2_b, grads->conv2_b, b, c, hw, sync, nullptr, nullptr, nullptr);
@@ -2645,29 +2690,34 @@ static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const v
   const FcGradJob fcj = {sc + T.dpre2, sc + T.dh, sv + S.h, sv + S.s, grads->fc1_w, grads->fc1_b, grads->fc2_w, grads->fc2_b, b, r};
   const int fc_rows = dhd_cdiv(dhd_cdiv(n_fc, kEwBlock), kPlaneChunks);
   const dim3 planes_fc(kPlaneChunks, b * c + fc_rows);
-  hipLaunchKernelGGL(stage_gx_kernel, planes_fc, dim3(kEwBlock), 0, st, sv + S.a1, sv + S.y2, sv + S.scsh2, gout, sc + T.du, sc + T.ds, gx,
-                     c, hw, fc_rows, fcj);
+#define DHD_GX(TO)                                                                                                           \
+  hipLaunchKernelGGL(stage_gx_kernel<TO>, planes_fc, dim3(kEwBlock), 0, st, sv + S.a1, sv + S.y2, sv + S.scsh2,                 \
+                     static_cast<const TO*>(gout), sc + T.du, sc + T.ds, static_cast<TO*>(gx), c, hw, fc_rows, fcj)
+  if (w->io_dtype == DHD_F16) DHD_GX(_Float16);
+  else if (w->io_dtype == DHD_BF16) DHD_GX(__bf16);
+  else DHD_GX(float);
+#undef DHD_GX
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
 
-int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, void* saved, void* scratch, int b, int c, int hw,
+int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch, int b, int c, int hw,
                           void* stream) {
   return stage_forward_impl(x, w, out, saved, scratch, b, c, hw, 0, 2, nullptr, stream);
 }
 
-int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void* saved, const float* gout, float* gx,
+int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void* saved, const void* gout, void* gx,
                            const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw, void* stream) {
   return stage_backward_impl(x, w, saved, gout, gx, grads, scratch, b, c, hw, 0, 2, nullptr, stream);
 }
 
-int dhd_sfa_stage_forward_phase(const float* x, const dhd_sfa_weights* w, float* out, void* saved, void* scratch, int b, int c, int hw,
+int dhd_sfa_stage_forward_phase(const float* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch, int b, int c, int hw,
                                 int phase, double* sync_sums, void* stream) {
   if (phase < 0 || phase > 2 || !sync_sums || (reinterpret_cast<uintptr_t>(sync_sums) & 7)) return DHD_EINVAL;
   return stage_forward_impl(x, w, out, saved, scratch, b, c, hw, phase, phase, sync_sums, stream);
 }
 
-int dhd_sfa_stage_backward_phase(const float* x, const dhd_sfa_weights* w, const void* saved, const float* gout, float* gx,
+int dhd_sfa_stage_backward_phase(const float* x, const dhd_sfa_weights* w, const void* saved, const void* gout, void* gx,
                                  const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw, int phase, double* sync_sums,
                                  void* stream) {
   if (phase < 0 || phase > 2 || !sync_sums || (reinterpret_cast<uintptr_t>(sync_sums) & 7)) return DHD_EINVAL;

@@ -141,7 +141,12 @@ class _FusedStage(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, stage, *params):
-        x = _lib.require_gpu_tensor(x.contiguous(), torch.float32, 'SFA input')
+        # A half x (a caller inside an autocast region: the concatenated encoder outputs) is widened once for the operator, whose
+        # arithmetic, saved tensors and parameters are float32; the stage's result then leaves in x's dtype (dhd_sfa_weights.
+        # io_dtype: rounded to nearest even, what the next convolution's cast would make of a float32 result), the gradient comes
+        # back in that dtype and the input gradient is returned in it -- no float32 round trips of (B,C,H,W) / (B,2C,H,W) tensors
+        io_dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
+        x = _lib.require_gpu_tensor(x.float().contiguous(), torch.float32, 'SFA input')
         if x.data_ptr() % 16:
             x = x.clone()
         b, c2, h, w = x.shape
@@ -164,6 +169,7 @@ class _FusedStage(torch.autograd.Function):
             setattr(wts, tag + '_var', bn.running_var.data_ptr() if track else None)
         wts.hidden, wts.training = hidden, training
         wts.gemm = _lib.SFA_GEMM[stage.gemm or default_gemm()]   # per call; backward reuses this struct
+        wts.io_dtype = _lib.dtype_code(io_dtype)
         wts.eps1, wts.eps2 = bn1.eps, bn2.eps
         (wts.momentum1, wts.bn1_batches), (wts.momentum2, wts.bn2_batches) = _bn_momentum(bn1, training), _bn_momentum(bn2, training)
         if training and not bn1.training:
@@ -172,7 +178,7 @@ class _FusedStage(torch.autograd.Function):
         with torch.cuda.device(dev):
             saved = torch.empty(lib.dhd_sfa_stage_saved_bytes(b, c, hw, hidden), dtype=torch.uint8, device=dev)
             scratch = _stage_scratch(dev, lib.dhd_sfa_stage_scratch_bytes(b, c, hw, hidden))
-            out = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
+            out = torch.empty((b, c, h, w), dtype=io_dtype, device=dev)
             if group is None:
                 _lib.check(lib.dhd_sfa_stage_forward(_lib.ptr(x), C.byref(wts), _lib.ptr(out), _lib.ptr(saved), _lib.ptr(scratch),
                                                      b, c, hw, _lib.stream_ptr(dev)), 'dhd_sfa_stage_forward')
@@ -190,6 +196,7 @@ class _FusedStage(torch.autograd.Function):
             ctx.wts = wts
             ctx.dims = (b, c, hw)
             ctx.group = group
+            ctx.io_dtype = io_dtype
         return out
 
     @staticmethod
@@ -199,9 +206,9 @@ class _FusedStage(torch.autograd.Function):
         b, c, hw = ctx.dims
         dev = x.device
         lib = _lib.load()
-        go = go.float().contiguous()
+        go = go.to(ctx.io_dtype).contiguous()
         with torch.cuda.device(dev):
-            gx = torch.empty_like(x)
+            gx = torch.empty(x.shape, dtype=ctx.io_dtype, device=dev)
             gps = [torch.empty_like(p) for p in ps]
             grads = _lib.SfaGrads()
             for n, g in zip(_STAGE_PARAMS, gps):
@@ -290,7 +297,7 @@ class channel_spatial_stage(nn.Module):
 
     def forward(self, x):
         if self.fused and fused_stage_supported(self, x):
-            return _FusedStage.apply(x.float(), self, *_stage_params(self))
+            return _FusedStage.apply(x, self, *_stage_params(self))
         params = list(self.fc.parameters()) + list(self.spacial_leanring.parameters())
         return _AttentionStage.apply(x.float(), self, *params)
 

@@ -343,6 +343,10 @@ typedef struct dhd_sfa_weights { /* [dev] float32 */
   int32_t gemm;         /* DHD_SFA_GEMM_* below */
   int64_t* bn1_batches; /* [dev] nn.BatchNorm2d.num_batches_tracked of the two layers, or NULL: incremented by one in a */
   int64_t* bn2_batches; /*       training-mode forward (instead of two one-element launches by the caller)              */
+  int32_t io_dtype;     /* DHD_F32 / DHD_F16 / DHD_BF16: element type of `out`, `gout` and `gx` (ABI 3).  x, the parameters and every
+                           tensor the operator keeps are float32.  Half types are for a caller inside an autocast region: it hands a
+                           half x (which it widens once for the operator), gets the stage's result rounded to nearest even -- what the
+                           next convolution's cast of a float32 result would produce -- and passes the half gradient straight back */
 } dhd_sfa_weights;
 
 typedef struct dhd_sfa_grads { /* [dev] float32 outputs, shapes as in dhd_sfa_weights, overwritten */
@@ -373,11 +377,11 @@ size_t dhd_sfa_stage_saved_bytes(int b, int c, int hw, int hidden);
 size_t dhd_sfa_stage_scratch_bytes(int b, int c, int hw, int hidden);
 
 /* x (B,2C,H,W) -> out (B,C,H,W) = x_fuse of mix.py:58. */
-int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, float* out, void* saved,
+int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, void* out /* w->io_dtype */, void* saved,
                           void* scratch, int b, int c, int hw, void* stream);
 /* gout (B,C,H,W) -> gx (B,2C,H,W) and every parameter gradient. */
 int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void* saved,
-                           const float* gout, float* gx, const dhd_sfa_grads* grads, void* scratch,
+                           const void* gout, void* gx /* both w->io_dtype */, const dhd_sfa_grads* grads, void* scratch,
                            int b, int c, int hw, void* stream);
 
 /* The same operator under nn.SyncBatchNorm (core/hook/syncbncontrol.py:18-32 converts the stage's two BatchNorms when
@@ -395,10 +399,10 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
  * gradients are this rank's contributions (the caller's DDP averages parameter gradients), exactly as torch's
  * SyncBatchNorm.  Training mode and the bf16 GEMM precisions only (DHD_EUNSUPPORTED otherwise).  With one rank and no
  * all-reduce the three phases reproduce dhd_sfa_stage_forward / backward. */
-int dhd_sfa_stage_forward_phase(const float* x, const dhd_sfa_weights* w, float* out, void* saved, void* scratch,
+int dhd_sfa_stage_forward_phase(const float* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch,
                                 int b, int c, int hw, int phase, double* sync_sums /*[dev] 2C+1*/, void* stream);
-int dhd_sfa_stage_backward_phase(const float* x, const dhd_sfa_weights* w, const void* saved, const float* gout,
-                                 float* gx, const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw,
+int dhd_sfa_stage_backward_phase(const float* x, const dhd_sfa_weights* w, const void* saved, const void* gout,
+                                 void* gx, const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw,
                                  int phase, double* sync_sums /*[dev] 2C+1*/, void* stream);
 
 /* ------------------------------------------------------------------------------------ *

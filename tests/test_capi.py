@@ -91,7 +91,7 @@ def test_argument_validation_happens_on_the_host():
     d.n_grids = 5
     assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n), C.byref(m)) == -1
     d.n_grids = 4
-    d.flags = 4                                                                     # unknown flag bit
+    d.flags = 8                                                                     # unknown flag bit (1, 2, 4 are defined)
     assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n), C.byref(m)) == -1
     d.flags = _lib.MGHS_DETERMINISTIC | _lib.MGHS_FEAT_GRAD_NCHW
     assert lib.dhd_mghs_workspace_bytes(C.byref(d), C.byref(n), C.byref(m)) == 0

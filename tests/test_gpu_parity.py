@@ -745,6 +745,36 @@ def test_sfa_stage_vs_torch(gpu, c, b, h, w, train, gemm):
         _check_stage_against_torch(st, x, tol_x=1e-4 * f, tol_p=5e-4 * f, tol_out=1e-4 * min(f, 3.0), tie=_TIE * f)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('c,b,h,w', [(256, 2, 52, 60), (128, 3, 36, 40), (512, 1, 24, 40)])
+def test_sfa_stage_half_io_equals_the_float32_operator_on_the_widened_input(gpu, c, b, h, w, dtype):
+    """dhd_sfa_weights.io_dtype (a caller inside an autocast region hands a half x): the operator widens x once, computes in
+    float32, and returns `out` / `gx` in x's dtype.  Bit for bit: out == float32 operator(x.float()).to(dtype), and with the same
+    half output gradient gx == float32 gx .to(dtype) and the 12 parameter gradients are identical."""
+    from dhd_amd.mix import channel_spatial_stage
+    torch.manual_seed(c + h)
+    st = channel_spatial_stage(2 * c).to(gpu).train()
+    xh = (torch.randn(b, 2 * c, h, w, device=gpu) * 0.7 + 0.1).to(dtype)
+    gh = torch.randn(b, c, h, w, device=gpu).to(dtype)
+    sd0 = {k: v.clone() for k, v in st.state_dict().items()}
+    res = []
+    for x_in, g_in in ((xh.float(), gh.float()), (xh, gh)):
+        st.load_state_dict(sd0)
+        st.zero_grad()
+        x_in = x_in.clone().requires_grad_()
+        out = st(x_in)
+        assert out.dtype == x_in.dtype
+        out.backward(g_in)
+        assert x_in.grad.dtype == x_in.dtype
+        res.append((out.detach(), x_in.grad, [p.grad.clone() for p in st.parameters()], [v.clone() for v in st.state_dict().values()]))
+    (o32, gx32, gp32, sd32), (oh, gxh, gph, sdh) = res
+    assert torch.equal(o32.to(dtype), oh) and torch.equal(gx32.to(dtype), gxh)
+    for a, b_ in zip(gp32, gph):
+        assert torch.equal(a, b_)
+    for a, b_ in zip(sd32, sdh):
+        assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize('c,b,h,w', [(128, 2, 20, 28), (256, 2, 36, 40), (512, 1, 24, 40)])
 def test_sfa_stage_f32_mfma_mode_vs_torch(gpu, c, b, h, w):
     """gemm = 'f32' (DHD_SFA_GEMM_F32: plain float32 MFMA kernels) through the same comparison."""
