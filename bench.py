@@ -604,6 +604,22 @@ def operator_roofline(hp, steps, warmup):
         bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln).backward(ogp)
     torch.cuda.synchronize()
     py_uncached_ms = (time.perf_counter() - t0) / steps * 1e3
+    # fused=True: the (B, C, Dz, Dy, Dx) tensor written once, its gradient read once in that layout
+    fev = []
+    for it in range(3 + steps):
+        if it == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        dt.grad = ft.grad = None
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        e[0].record()
+        bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln, fused=True).backward(ogp)
+        e[1].record()
+        if it >= 3:
+            fev.append(tuple(e))
+    torch.cuda.synchronize()
+    py_fused_ms = (time.perf_counter() - t0) / steps * 1e3
+    py_fused_gpu_ms = event_mean(fev)
     fwd_ms = event_mean([(e[0], e[1]) for e in ev])
     bwd_ms = event_mean([(e[1], e[2]) for e in ev])
     n_kept = int(rb.numel())
@@ -619,11 +635,15 @@ def operator_roofline(hp, steps, warmup):
                 launch_ms=fwd_ms + bwd_ms, forward_ms=fwd_ms, backward_ms=bwd_ms,
                 algorithmic_bytes=fwd_bytes + bwd_bytes, forward_bytes=fwd_bytes, backward_bytes=bwd_bytes, kept_points=n_kept,
                 intervals=int(ln.numel()), python_op_fwd_bwd_ms=py_ms, python_op_fwd_bwd_regroup_every_call_ms=py_uncached_ms,
+                python_op_fused_fwd_bwd_ms=py_fused_ms, python_op_fused_fwd_bwd_event_ms=py_fused_gpu_ms,
+                python_op_fused_frac=(fwd_bytes + bwd_bytes) / (py_fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 note='full-height grid only (Dz=1); traffic = PMC bytes of the two kernels (the zero-fills of the caller-owned outputs are '
                      'torch fills, not counted); python_op_fwd_bwd_ms = dhd_amd.bev_pool_v2(...).backward() incl. zero-fill and permute, with '
                      'the backward re-grouping (bev_pool.py:47-57: argsort + gathers + run-length scan in the reference; here '
                      'dhd_bev_pool_v2_regroup, a device counting sort) reused while the same index tensors come back; '
-                     '..._regroup_every_call_ms redoes it in every backward')
+                     '..._regroup_every_call_ms redoes it in every backward; python_op_fused_* = bev_pool_v2(..., fused=True): the '
+                     '(B, C, Dz, Dy, Dx) tensor written once by the segment writer, its gradient read once in that layout '
+                     '(dhd_bev_pool_v2_fused_forward / _backward), wall clock per call and HIP events around the same calls')
 
 
 def cpu_baseline(hp, max_batch, warmups=3, reps=5, budget_s=75.0):

@@ -112,8 +112,102 @@ def _regrouped(lib, ranks_depth, ranks_feat, ranks_bev, n_pixels):
     return res
 
 
+_fused_scratch = {}   # (device index, stream) -> uint8 scratch of the fused operator (reusable between calls on a stream)
+
+
+def fused_supported(bev_feat_shape):
+    """Shapes dhd_bev_pool_v2_fused_* takes (include/dhd_amd.h): C == 64, Dy % 4 == 0, Dx % 4 == 0, Dx <= 256."""
+    _, _, dy, dx, c = (int(v) for v in bev_feat_shape)
+    return c == 64 and dy % 4 == 0 and dx % 4 == 0 and dx <= 256
+
+
+class _FusedPool(torch.autograd.Function):
+    """bev_pool_v2 + `permute(0, 4, 1, 2, 3).contiguous()` (bev_pool.py:86-106) as one node: the (B, C, Dz, Dy, Dx) tensor is
+    written once, zeros included, and its gradient is read once in that layout (dhd_bev_pool_v2_fused_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts, interval_lengths):
+        lib = _lib.load()
+        if not depth.is_cuda:
+            raise _lib.DhdError('bev_pool_v2 runs only on the GPU (no CPU path, as in the reference)')
+        i32, f32 = torch.int32, torch.float32
+        ranks_bev = _as(ranks_bev, i32)
+        depth = _as(depth, f32)
+        feat = _as(feat, f32)
+        ranks_depth = _as(ranks_depth, i32)
+        ranks_feat = _as(ranks_feat, i32)
+        interval_lengths = _as(interval_lengths, i32)
+        interval_starts = _as(interval_starts, i32)
+        b, dz, dy, dx, c = (int(v) for v in bev_feat_shape)
+        n_iv = interval_lengths.numel()
+        dev = depth.device
+        sizes = _fused_sizes(lib, c, b, dz, dy, dx, n_iv)
+        with _on(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            out = torch.empty((b, c, dz, dy, dx), dtype=f32, device=dev)
+            state = torch.empty(sizes[0], dtype=torch.uint8, device=dev)
+            scratch = _scratch_for(dev, stream, sizes[1])
+            rc = lib.dhd_bev_pool_v2_fused_forward(
+                depth.data_ptr(), feat.data_ptr(), out.data_ptr(), ranks_depth.data_ptr(), ranks_feat.data_ptr(),
+                ranks_bev.data_ptr(), interval_lengths.data_ptr(), interval_starts.data_ptr(), c, n_iv, b, dz, dy, dx,
+                state.data_ptr(), sizes[0], scratch.data_ptr(), scratch.numel(), stream)
+        if rc:
+            _lib.check(rc, 'dhd_bev_pool_v2_fused_forward')
+        ctx.save_for_backward(ranks_bev, depth, feat, ranks_feat, ranks_depth, state)
+        ctx.dims = (b, dz, dy, dx, c, n_iv, sizes)
+        return out
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        lib = _lib.load()
+        ranks_bev, depth, feat, ranks_feat, ranks_depth, state = ctx.saved_tensors
+        b, dz, dy, dx, c, n_iv, sizes = ctx.dims
+        rd, rf, rb, starts, lengths = _regrouped(lib, ranks_depth, ranks_feat, ranks_bev, feat.numel() // c)
+        dev = depth.device
+        out_grad = _as(out_grad, torch.float32)
+        with _on(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            # one zero-fill for both gradients (bev_pool.py:67-68); feat's part starts on a 16-byte boundary
+            nd = (depth.numel() + 3) // 4 * 4
+            both = torch.zeros(nd + feat.numel(), dtype=torch.float32, device=dev)
+            depth_grad, feat_grad = both[:depth.numel()].view(depth.shape), both[nd:].view(feat.shape)
+            scratch = _scratch_for(dev, stream, sizes[1])
+            rc = lib.dhd_bev_pool_v2_fused_backward(
+                out_grad.data_ptr(), depth_grad.data_ptr(), feat_grad.data_ptr(), depth.data_ptr(), feat.data_ptr(),
+                rd.data_ptr(), rf.data_ptr(), rb.data_ptr(), lengths.data_ptr(), starts.data_ptr(), c, lengths.numel(), n_iv,
+                b, dz, dy, dx, state.data_ptr(), sizes[0], scratch.data_ptr(), scratch.numel(), stream)
+        if rc:
+            _lib.check(rc, 'dhd_bev_pool_v2_fused_backward')
+        return depth_grad, feat_grad, None, None, None, None, None, None
+
+
+_fused_size_cache = {}
+
+
+def _fused_sizes(lib, c, b, dz, dy, dx, n_iv):
+    key = (c, b, dz, dy, dx, n_iv)
+    hit = _fused_size_cache.get(key)
+    if hit is None:
+        import ctypes as C
+        sb, cb = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.dhd_bev_pool_v2_fused_workspace_bytes(c, b, dz, dy, dx, n_iv, C.byref(sb), C.byref(cb)),
+                   'dhd_bev_pool_v2_fused_workspace_bytes')
+        if len(_fused_size_cache) > 64:
+            _fused_size_cache.clear()
+        hit = _fused_size_cache[key] = (int(sb.value), int(cb.value))
+    return hit
+
+
+def _scratch_for(dev, stream, nbytes):
+    key = (dev.index, stream)
+    buf = _fused_scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _fused_scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return buf
+
+
 def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
-                interval_lengths):
+                interval_lengths, fused=False):
     """
     Args (identical to the reference, bev_pool.py:86-106):
         depth: (B, N, D, fH, fW)
@@ -121,9 +215,15 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
         ranks_depth, ranks_feat, ranks_bev: (N_points,)
         bev_feat_shape: (B, D_Z, D_Y, D_X, C)
         interval_starts, interval_lengths: (N_pillar,)
+        fused (not in the reference): write the returned (B, C, Dz, Dy, Dx) tensor directly, once, zeros included, instead
+            of zero-fill + kernel + permute copy; same values bit for bit.  Shapes outside `fused_supported` take the
+            reference's three steps.
     Returns:
         bev feature (B, C, Dz, Dy, Dx)
     """
+    if fused and fused_supported(bev_feat_shape):
+        return _FusedPool.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
+                                interval_lengths)
     x = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
                               interval_starts, interval_lengths)
     return x.permute(0, 4, 1, 2, 3).contiguous()

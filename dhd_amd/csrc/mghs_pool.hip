@@ -406,15 +406,19 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
 // Segments without any point are skipped: their out_grad is never needed.
 // ---------------------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs og_in) {
+__global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs og_in, int split) {
   constexpr int VPL = VoxVec<T>::n;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* table = reinterpret_cast<float*>(smem);
   unsigned short* slot_of = reinterpret_cast<unsigned short*>(smem + (size_t)kTableFloats * 4);
   int* ctl = reinterpret_cast<int*>(smem + (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2);
 
+  // `split` channel parts per segment (1 on the MGHS path, see above; the single-grid operator, whose whole tensor is 200
+  // segments, takes 4 so that every CU has work)
+  const int seg = blockIdx.x / split, pw = kTileC / split;
+  const int c_begin = (blockIdx.x % split) * pw, c_end = c_begin + pw;
   Segment sg;
-  if (!decode_segment(L, blockIdx.x, &sg)) return;
+  if (!decode_segment(L, seg, &sg)) return;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   if (t == 0) ctl[0] = L.nzoff[sg.v0];
   if (t == 1) ctl[1] = L.nzoff[sg.v0 + sg.nvox];
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
   const int k0 = rfl(ctl[0]), nnz = rfl(ctl[1]) - k0;
   if (nnz == 0) return;
   for (int j = t; j < nnz; j += kStreamBlock) slot_of[L.nzvox[k0 + j] - sg.v0] = (unsigned short)(j + 1);
-  const int cp = channels_per_pass(nnz);
+  const int cp = min(channels_per_pass(nnz), c_end - c_begin);
   const int nvec = sg.nvox / VPL;
   const T* og = reinterpret_cast<const T*>(og_in.p[sg.g]);
   const long sb = og_in.sb[sg.g], sz = og_in.sz[sg.g], sc = og_in.sc[sg.g];
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
   const int q_step = kStride / nvec, r_step = kStride % nvec;
   const T* gbase = og + (size_t)sg.b * sb + (size_t)sg.z * sz + (size_t)sg.y0 * sg.nx;
   __syncthreads();  // slot_of complete
-  for (int c_lo = 0; c_lo < kTileC; c_lo += cp) {
+  for (int c_lo = c_begin; c_lo < c_end; c_lo += cp) {
     __syncthreads();
     const int total = cp * nvec;
     int idx = wv * DHD_WAVE + lane;
@@ -818,6 +822,25 @@ void rows_launch_shape(const Layout& L, int* stride, size_t* smem, dim3* grid) {
 }
 
 }  // namespace
+
+int launch_stream_fwd(const Layout& L, const OutPtrs& o, int split, hipStream_t st) {
+  if (!L.compact || L.n_segs <= 0) return DHD_EINVAL;
+  if (o.dtype == DHD_F16) hipLaunchKernelGGL(mghs_stream_fwd<_Float16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
+  else if (o.dtype == DHD_BF16) hipLaunchKernelGGL(mghs_stream_fwd<__bf16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
+  else hipLaunchKernelGGL(mghs_stream_fwd<float>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+int launch_stream_bwd(const Layout& L, const InPtrs& in, int split, hipStream_t st) {
+  if (!L.compact || L.n_segs <= 0) return DHD_EINVAL;
+  if (in.dtype == DHD_F16) hipLaunchKernelGGL(mghs_stream_bwd<_Float16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, in, split);
+  else if (in.dtype == DHD_BF16) hipLaunchKernelGGL(mghs_stream_bwd<__bf16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, in, split);
+  else hipLaunchKernelGGL(mghs_stream_bwd<float>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, in, split);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
 }  // namespace dhd
 
 using namespace dhd;
@@ -867,11 +890,7 @@ static int forward_stream_impl(const dhd_mghs_desc* desc, const float* depth, co
   if (L.compact) {
     // half types: a channel run is half as many bytes, so a workgroup takes twice the channels (measured, writer alone: DHD-S B = 4
     // 88.3 / 70.3 / 75.3 us with 4 / 2 / 1 parts, DHD-L geometry B = 2 71.8 / 63.7 / 66.6)
-    const int split = o.dtype == DHD_F32 ? stream_split(L) : 2;
-    if (o.dtype == DHD_F16) hipLaunchKernelGGL(mghs_stream_fwd<_Float16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
-    else if (o.dtype == DHD_BF16) hipLaunchKernelGGL(mghs_stream_fwd<__bf16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
-    else hipLaunchKernelGGL(mghs_stream_fwd<float>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
-    DHD_LAUNCH_CHECK();
+    if ((rc = launch_stream_fwd(L, o, o.dtype == DHD_F32 ? stream_split(L) : 2, st))) return rc;
   } else {
     int stride; size_t smem; dim3 grid;
     rows_launch_shape(L, &stride, &smem, &grid);
@@ -918,10 +937,7 @@ static int backward_impl(const dhd_mghs_desc* desc, const float* depth, const fl
   if ((rc = make_views<InPtrs, const float>(L, out_grad, views, &in))) return rc;
   hipStream_t st = dhd_stream(stream);
   if (L.compact) {
-    if (in.dtype == DHD_F16) hipLaunchKernelGGL(mghs_stream_bwd<_Float16>, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, in);
-    else if (in.dtype == DHD_BF16) hipLaunchKernelGGL(mghs_stream_bwd<__bf16>, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, in);
-    else hipLaunchKernelGGL(mghs_stream_bwd<float>, dim3(L.n_segs), dim3(kStreamBlock), kStreamLds, st, L, in);
-    DHD_LAUNCH_CHECK();
+    if ((rc = launch_stream_bwd(L, in, 1, st))) return rc;
     hipLaunchKernelGGL(mghs_pixel_bwd, dim3(dhd_cdiv((long)L.B * L.N * L.hw, 8 * (kBlock / DHD_WAVE)) * 8), dim3(kBlock), 0, st, L,
                        depth, feat_nhwc, depth_grad, feat_grad_nhwc);
     DHD_LAUNCH_CHECK();

@@ -442,6 +442,13 @@ __global__ __launch_bounds__(kBlock) void mghs_rank_by_pid(Layout L, int t0) {
 }
 
 }  // namespace
+
+int launch_scan(const Layout& L, hipStream_t st) {
+  hipLaunchKernelGGL(mghs_scan, dim3(L.n_chunks), dim3(kBlock), 0, st, L);
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
 }  // namespace dhd
 
 using namespace dhd;
@@ -503,8 +510,7 @@ int lift_impl(const dhd_mghs_desc* desc, const dhd_calib* calib, const float* he
   if (static_rig) hipLaunchKernelGGL(mghs_geom_count<true>, gc, dim3(kBlock), 0, st, L, *calib, band);
   else hipLaunchKernelGGL(mghs_geom_count<false>, gc, dim3(kBlock), 0, st, L, *calib, band);
   DHD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(mghs_scan, dim3(L.n_chunks), dim3(kBlock), 0, st, L);
-  DHD_LAUNCH_CHECK();
+  if ((rc = launch_scan(L, st))) return rc;
   const dim3 gs(dhd_cdiv((long)gp.x * gp.y, 8) * 8);
   if (static_rig) hipLaunchKernelGGL(mghs_scatter<1>, gs, dim3(kBlock), 0, st, L, (int)gp.x);
   else hipLaunchKernelGGL(mghs_scatter<0>, gs, dim3(kBlock), 0, st, L, (int)gp.x);

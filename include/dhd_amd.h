@@ -75,6 +75,29 @@ int dhd_bev_pool_v2_regroup(const int32_t* ranks_depth, const int32_t* ranks_fea
                             int32_t* ranks_bev_bp, int32_t* interval_starts_bp, int32_t* interval_lengths_bp,
                             void* scratch /*[dev]*/, size_t scratch_bytes, void* stream);
 
+/* Fused form of the operator AS THE REFERENCE'S WRAPPER USES IT (bev_pool.py:27,86-106: zero-filled (B,Dz,Dy,Dx,C) tensor ->
+ * kernel -> `permute(0, 4, 1, 2, 3).contiguous()`): `out` is the FINAL (B,C,Dz,Dy,Dx) tensor, written exactly once, zeros
+ * included (no pre-zeroing, no permute copy); the backward takes out_grad in that same layout.  Same index lists as above
+ * (intervals = runs of equal ranks_bev, as voxel_pooling_prepare_v2 builds them, lss_heightmap.py:303-371; any interval
+ * order; voxels outside [0, B*Dz*Dy*Dx) are dropped).  Shapes: c == 64, Dy % 4 == 0, Dx % 4 == 0, Dx <= 256, else
+ * DHD_EUNSUPPORTED (use the entry points above).  `state` (voxel -> row map, kept from the forward to its backward) and
+ * `scratch` (reusable between calls on a stream) are 256-byte aligned device buffers of the sizes
+ * dhd_bev_pool_v2_fused_workspace_bytes returns; depth_grad / feat_grad are pre-zeroed by the caller as above; the *_bp lists
+ * are those of dhd_bev_pool_v2_regroup.  Values are bit-identical to the unfused entry points (same kernels, same order). */
+int dhd_bev_pool_v2_fused_workspace_bytes(int c, int batch, int dz, int dy, int dx, int n_intervals, size_t* state_bytes,
+                                          size_t* scratch_bytes);
+int dhd_bev_pool_v2_fused_forward(const float* depth, const float* feat, float* out /* [dev] (B,C,Dz,Dy,Dx) */,
+                                  const int32_t* ranks_depth, const int32_t* ranks_feat, const int32_t* ranks_bev,
+                                  const int32_t* interval_lengths, const int32_t* interval_starts, int c, int n_intervals,
+                                  int batch, int dz, int dy, int dx, void* state, size_t state_bytes, void* scratch,
+                                  size_t scratch_bytes, void* stream);
+int dhd_bev_pool_v2_fused_backward(const float* out_grad /* [dev] (B,C,Dz,Dy,Dx) */, float* depth_grad, float* feat_grad,
+                                   const float* depth, const float* feat, const int32_t* ranks_depth_bp,
+                                   const int32_t* ranks_feat_bp, const int32_t* ranks_bev_bp,
+                                   const int32_t* interval_lengths_bp, const int32_t* interval_starts_bp, int c,
+                                   int n_intervals_bp, int n_intervals, int batch, int dz, int dy, int dx, void* state,
+                                   size_t state_bytes, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------ *
  * 2. Fused MGHS view transform (replaces the 4x get_ego_coor + 4x voxel_pooling_prepare_v2
  *    + 4x bev_pool_v2 + permute + cat chain of models/necks/lss_heightmap.py:380-459).

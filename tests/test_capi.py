@@ -100,6 +100,16 @@ def test_argument_validation_happens_on_the_host():
     assert lib.dhd_hbm_calibrate(None, 1024, 0, None) == -1 and lib.dhd_hbm_calibrate(C.c_void_p(4096), 1000, 1, None) == -1
     assert lib.dhd_bev_pool_v2_forward(None, None, None, None, None, None, None, None, 64, 10, None) == -1
     assert lib.dhd_bev_pool_v2_forward(None, None, None, None, None, None, None, None, 64, 0, None) == 0  # nothing to do
+    # fused operator: sizes on the host, shapes it does not take, missing workspace
+    fs, fc = C.c_size_t(), C.c_size_t()
+    assert lib.dhd_bev_pool_v2_fused_workspace_bytes(64, 4, 1, 200, 200, 81205, C.byref(fs), C.byref(fc)) == 0
+    assert fs.value >= 4 * (160001 + 81206) and fs.value % 256 == 0 and fc.value >= 4 * (2 * 160000 + 64 * 81206)
+    assert lib.dhd_bev_pool_v2_fused_workspace_bytes(80, 4, 1, 200, 200, 10, C.byref(fs), C.byref(fc)) == -1      # C != 64
+    assert lib.dhd_bev_pool_v2_fused_workspace_bytes(64, 4, 1, 202, 200, 10, C.byref(fs), C.byref(fc)) == -3     # Dy % 4
+    assert lib.dhd_bev_pool_v2_fused_workspace_bytes(64, 4, 1, 200, 260, 10, C.byref(fs), C.byref(fc)) == -3     # Dx > 256
+    assert lib.dhd_bev_pool_v2_fused_workspace_bytes(64, 4, 1, 200, 200, 10, None, None) == -1
+    assert lib.dhd_bev_pool_v2_fused_forward(*([None] * 8), 64, 10, 4, 1, 200, 200, None, 0, None, 0, None) == -1
+    assert lib.dhd_bev_pool_v2_fused_backward(*([None] * 10), 64, 10, 10, 4, 1, 200, 200, None, 0, None, 0, None) == -1
     assert lib.dhd_sfa_channel_mean(None, None, 1, 512, 40000, None) == -1
     assert lib.dhd_height_band(None, 6, 65, 16, 44, None, None, None, None) == -1
     assert lib.dhd_ema_update(None, None, None, 5, 0.5, 0.5, None) == -1

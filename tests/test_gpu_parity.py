@@ -120,6 +120,99 @@ def test_bev_pool_v2_operator_ragged_intervals(gpu, channels):
     np.testing.assert_allclose(ft.grad.cpu().numpy(), fg, atol=3e-5, rtol=1e-5)
 
 
+def _ragged_lists(seed, B, N, D, fh, fw, nz, ny, nx, extra_empty=False):
+    rng = np.random.default_rng(seed)
+    lens = [1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1000] + [1] * 40 + [7] * 40
+    if extra_empty:
+        lens = lens + [0] * 5
+    lens = np.array(lens, dtype=np.int32)[rng.permutation(len(lens))]
+    n_pts = int(lens.sum())
+    assert n_pts <= B * N * D * fh * fw
+    rd = rng.permutation(B * N * D * fh * fw)[:n_pts].astype(np.int32)
+    rf = ((rd // (D * fh * fw)) * (fh * fw) + rd % (fh * fw)).astype(np.int32)
+    st = np.minimum(np.cumsum(lens) - lens, max(n_pts - 1, 0)).astype(np.int32)
+    vox = rng.permutation(B * nz * ny * nx)[:len(lens)].astype(np.int32)        # shuffled voxel order: not sorted by ranks_bev
+    rb = np.repeat(vox, lens).astype(np.int32)
+    return rd, rf, rb, st, lens
+
+
+@pytest.mark.parametrize('case', ['g2b', 'ragged', 'ragged_nz3_empty'])
+def test_bev_pool_v2_fused_equals_the_three_step_operator_bit_for_bit(gpu, case):
+    """bev_pool_v2(..., fused=True): the (B, C, Dz, Dy, Dx) tensor written once by the segment writer and
+    its gradient read once in that layout, against zero-fill + kernel + permute copy (bev_pool.py:27,86-106) -- the same sums
+    in the same order, so every value and both gradients must be IDENTICAL; and against the oracle."""
+    from dhd_amd import bev_pool_v2
+    from dhd_amd.bev_pool_v2 import fused_supported
+    from oracle import mghs_oracle as O
+    C = 64
+    if case == 'g2b':
+        g = golden('g2b_small_dhds')
+        rb, rd, rf, st, ln = (g[n + '0'] for n in ('ranks_bev', 'ranks_depth', 'ranks_feat', 'interval_starts', 'interval_lengths'))
+        B, N, D, fh, fw = 2, 2, 44, 4, 11
+        depth = g['depth'].reshape(B, N, D, fh, fw)
+        shape = (B, 1, 200, 200, C)
+    else:
+        B, N, D, fh, fw = 2, 2, 44, 8, 22
+        nz = 3 if case.endswith('empty') else 1
+        shape = (B, nz, 40, 48, C)
+        rd, rf, rb, st, ln = _ragged_lists(5, B, N, D, fh, fw, nz, 40, 48, extra_empty=case.endswith('empty'))
+        depth = syn.hash_signed(170, (B, N, D, fh, fw))
+    assert fused_supported(shape)
+    feat = syn.hash_signed(171, (B, N, fh, fw, C))
+    idx = [T(a, gpu) for a in (rd, rf, rb)]
+    w = T(syn.hash_signed(172, (shape[0], C) + tuple(shape[1:4])), gpu)
+    res = []
+    for fused in (False, True):
+        dt, ft = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+        out = bev_pool_v2(dt, ft, *idx, shape, T(st, gpu), T(ln, gpu), fused=fused)
+        assert out.shape == (shape[0], C) + tuple(shape[1:4]) and out.is_contiguous()
+        (out * w).sum().backward()
+        res.append((out.detach(), dt.grad, ft.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    keep = ln > 0
+    ref = O.bev_pool_v2(depth, feat, rd, rf, rb, shape, st[keep], ln[keep])
+    np.testing.assert_allclose(res[1][0].cpu().numpy(), ref, atol=3e-5, rtol=1e-5)
+    og = np.ascontiguousarray(w.cpu().numpy().transpose(0, 2, 3, 4, 1))
+    dg, fg = O.bev_pool_v2_backward(og, depth, feat, rd, rf, rb)
+    np.testing.assert_allclose(res[1][1].cpu().numpy(), dg, atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(res[1][2].cpu().numpy(), fg, atol=3e-5, rtol=1e-5)
+
+
+def test_bev_pool_v2_fused_edge_cases(gpu):
+    """Shapes the fused entry points do not take fall back to the three steps (the reference's KAT has C = 2); no interval at
+    all gives zeros; voxels outside the grid are dropped (the reference kernel would write out of bounds: bev_pool_cuda.cu:47)."""
+    from dhd_amd import bev_pool_v2
+    from dhd_amd.bev_pool_v2 import fused_supported
+    depth = torch.tensor([0.3, 0.4, 0.2, 0.1, 0.7, 0.6, 0.8, 0.9], device=gpu).view(1, 1, 2, 2, 2).requires_grad_()
+    feat = torch.ones(1, 1, 2, 2, 2, device=gpu).requires_grad_()
+    I = lambda v: torch.tensor(v, device=gpu).int()
+    assert not fused_supported((1, 1, 2, 2, 2))
+    out = bev_pool_v2(depth, feat, I([0, 4, 1, 6]), I([0, 0, 1, 2]), I([0, 0, 1, 1]), (1, 1, 2, 2, 2), I([0, 2]), I([2, 2]), fused=True)
+    out.sum().backward()
+    assert abs(out.sum().item() - 4.4) < 1e-6
+    assert torch.allclose(depth.grad.flatten().cpu(), torch.tensor([2., 2., 0., 0., 2., 0., 2., 0.]))
+    # C = 64, 4 x 8 grid: two real intervals + one whose voxel is outside the grid
+    B, N, D, fh, fw, C = 1, 1, 2, 2, 2, 64
+    d2 = torch.rand(B, N, D, fh, fw, device=gpu).requires_grad_()
+    f2 = torch.randn(B, N, fh, fw, C, device=gpu).requires_grad_()
+    shape = (1, 1, 4, 8, C)
+    rd, rf, rb = I([0, 4, 1, 6, 3]), I([0, 0, 1, 2, 3]), I([5, 5, 31, 31, 32])
+    out = bev_pool_v2(d2, f2, rd, rf, rb, shape, I([0, 2, 4]), I([2, 2, 1]), fused=True)
+    want = torch.zeros(1, 4 * 8, C, device=gpu)
+    df, ff = d2.detach().flatten(), f2.detach().view(-1, C)
+    want[0, 5] = df[0] * ff[0] + df[4] * ff[0]
+    want[0, 31] = df[1] * ff[1] + df[6] * ff[2]
+    assert torch.allclose(out.view(1, C, 32).transpose(1, 2), want, atol=1e-6)
+    out.sum().backward()
+    assert d2.grad.flatten()[3].item() == 0 and float(f2.grad.view(-1, C)[3].abs().max()) == 0   # the dropped point
+    assert torch.allclose(d2.grad.flatten()[0], ff[0].sum(), atol=1e-5)
+    # no interval at all
+    e = torch.empty(0, device=gpu).int()
+    z = bev_pool_v2(d2.detach(), f2.detach(), e, e, e, shape, e, e, fused=True)
+    assert z.shape == (1, C, 1, 4, 8) and float(z.abs().max()) == 0
+
+
 def test_bev_pool_v2_regroup_vs_argsort(gpu):
     """dhd_bev_pool_v2_regroup (device counting sort by feature pixel, ascending ranks_depth inside a pixel, one interval per
     pixel incl. empty ones) against the reference's formulation (bev_pool.py:47-57: argsort by ranks_feat, run-length scan) on
