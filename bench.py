@@ -176,11 +176,18 @@ def parse():
                    help='hotpath, N = 1: repeat the whole measurement in this many fresh processes (other allocator placement of the 0.7 GB '
                         'outputs: one build differs by up to 11 % on the writer between two processes on one box)')
     p.add_argument('--no-dhdl', action='store_true', help='hotpath: leave out the MGHS-only record at the DHD-L geometry (configs[3]/[4], B = 2)')
+    p.add_argument('--pmc-pass', action='store_true',
+                   help='hotpath: only what a counter-collection pass needs -- one timed loop, the bf16x6 loop and the three-step operator; no '
+                        'DHD-L / fresh-process children, no half-precision or fused-operator launches (they share kernel names with the '
+                        'hot path at other sizes and would be averaged into its per-launch traffic)')
     p.add_argument('--child', action='store_true', help='(internal) a --fresh-procs child: print the timing statistics only')
     p.add_argument('--ddp-graph', action='store_true',
                    help='e2e under DDP: capture the whole step, RCCL all-reduces included, into a HIP graph (N = 1 always does; with N > 1 '
                         'it is opt-in because it cannot be validated on the one-GPU development box: falls back to eager on a capture error)')
-    return p.parse_args()
+    a = p.parse_args()
+    if a.pmc_pass:
+        a.no_dhdl, a.fresh_procs, a.repeats, a.no_e2e, a.cpu_samples = True, 0, 1, True, 0
+    return a
 
 
 class HotPath:
@@ -526,7 +533,7 @@ def mghs_amp_record(hp, steps, warmup, dtype=torch.float16):
     return out
 
 
-def operator_roofline(hp, steps, warmup):
+def operator_roofline(hp, steps, warmup, fused=True):
     """The operator-level drop-in on its own (include/dhd_amd.h section 1 = bev_pool.cpp:30-39,74-85): the full-height
     grid with reference-style index lists (ranks_depth / ranks_feat / ranks_bev sorted by voxel, interval starts /
     lengths; for the backward re-grouped by ranks_feat as bev_pool.py:47-57 does).  Timed region per launch, as the
@@ -613,7 +620,7 @@ def operator_roofline(hp, steps, warmup):
         dt.grad = ft.grad = None
         e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         e[0].record()
-        bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln, fused=True).backward(ogp)
+        bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln, fused=fused).backward(ogp)
         e[1].record()
         if it >= 3:
             fev.append(tuple(e))
@@ -1101,14 +1108,14 @@ def main():
         line['fresh_processes'] = fresh_process_repeats(a)
         print(f'[bench] {a.fresh_procs} fresh-process repeats {time.perf_counter() - t_stage:.1f} s', file=sys.stderr, flush=True)
     t_stage = time.perf_counter()
-    if hp.plan.half_outputs_supported:
+    if hp.plan.half_outputs_supported and not a.pmc_pass:
         with no_gc():
             amp_rec = mghs_amp_record(hp, max(5, min(a.steps, 20)), 3)   # every rank runs it, rank 0 reports
         if rank == 0:
             line['hotpath_amp'] = amp_rec
     if a.geometry == 'dhd-s' and not a.no_operator:
         with no_gc():
-            op_roof = operator_roofline(hp, max(5, min(a.steps, 20)), 3)   # every rank runs it, rank 0 reports
+            op_roof = operator_roofline(hp, max(5, min(a.steps, 20)), 3, fused=not a.pmc_pass)   # every rank runs it, rank 0 reports
         if rank == 0:
             line['roofline_operator'] = op_roof
     if rank == 0 and world == 1 and a.cpu_samples > 0:

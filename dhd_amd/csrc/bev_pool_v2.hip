@@ -660,7 +660,7 @@ int dhd_bev_pool_v2_fused_forward(const float* depth, const float* feat, float* 
   }
   dhd::OutPtrs o;
   fused_view<dhd::OutPtrs, float>(L, out, &o);
-  return dhd::launch_stream_fwd(L, o, kFusedSplit, st);
+  return dhd::launch_stream_fwd(L, o, kFusedSplit, st, true);
 }
 
 int dhd_bev_pool_v2_fused_backward(const float* out_grad, float* depth_grad, float* feat_grad, const float* depth,
@@ -683,7 +683,7 @@ int dhd_bev_pool_v2_fused_backward(const float* out_grad, float* depth_grad, flo
   hipStream_t st = dhd_stream(stream);
   dhd::InPtrs in;
   fused_view<dhd::InPtrs, const float>(L, out_grad, &in);
-  if ((rc = dhd::launch_stream_bwd(L, in, kFusedSplit, st))) return rc;
+  if ((rc = dhd::launch_stream_bwd(L, in, kFusedSplit, st, true))) return rc;
   constexpr int LL = dhd::kTileC / 4;
   hipLaunchKernelGGL((bev_pool_v2_bwd_vec_kernel<LL, 8, 5, true>), dim3(xcd_padded_blocks(dhd_cdiv(n_intervals_bp, kWaves * (DHD_WAVE / LL)))),
                      dim3(kBlock), 0, st, n_intervals_bp, reinterpret_cast<const pf4*>(L.vsum), depth, reinterpret_cast<const pf4*>(feat),

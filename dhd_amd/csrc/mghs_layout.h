@@ -225,7 +225,7 @@ inline int make_views(const Layout& L, T* const bases[DHD_MAX_GRIDS], const dhd_
 // mghs_prepare.hip: count[V] (+ zeroed scan_state) -> offset[V+1], nzoff[V+1], nzvox[slots]
 int launch_scan(const Layout& L, hipStream_t st);
 // mghs_pool.hip: the segment writer / reader of the compact path (vsum[slot][64] <-> dense tensors), `split` channel parts per segment
-int launch_stream_fwd(const Layout& L, const OutPtrs& o, int split, hipStream_t st);
-int launch_stream_bwd(const Layout& L, const InPtrs& in, int split, hipStream_t st);
+int launch_stream_fwd(const Layout& L, const OutPtrs& o, int split, hipStream_t st, bool op = false);
+int launch_stream_bwd(const Layout& L, const InPtrs& in, int split, hipStream_t st, bool op = false);
 
 }  // namespace dhd

@@ -327,7 +327,9 @@ template <> __device__ __forceinline__ void unpack_vox<__bf16>(vfloat4 v, float*
   for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(w[k] << 16); f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
 }
 
-template <class T>
+// OP = 1: the same code instantiated once more for the single-grid operator (dhd_bev_pool_v2_fused_*), so that its launches are
+// their own rows in a kernel profile instead of being averaged into the hot path's.
+template <class T, int OP = 0>
 __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtrs out, int split) {
   constexpr int VPL = VoxVec<T>::n;                // voxels per lane and store: 4 (float32) or 8 (half types)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
 // backward 1: stream out_grad, extract the rows of the non-empty voxels into vsum[slot][64].
 // Segments without any point are skipped: their out_grad is never needed.
 // ---------------------------------------------------------------------------------------
-template <class T>
+template <class T, int OP = 0>
 __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs og_in, int split) {
   constexpr int VPL = VoxVec<T>::n;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -823,8 +825,14 @@ void rows_launch_shape(const Layout& L, int* stride, size_t* smem, dim3* grid) {
 
 }  // namespace
 
-int launch_stream_fwd(const Layout& L, const OutPtrs& o, int split, hipStream_t st) {
+int launch_stream_fwd(const Layout& L, const OutPtrs& o, int split, hipStream_t st, bool op) {
   if (!L.compact || L.n_segs <= 0) return DHD_EINVAL;
+  if (op) {
+    if (o.dtype != DHD_F32) return DHD_EUNSUPPORTED;
+    hipLaunchKernelGGL((mghs_stream_fwd<float, 1>), dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
+    DHD_LAUNCH_CHECK();
+    return DHD_OK;
+  }
   if (o.dtype == DHD_F16) hipLaunchKernelGGL(mghs_stream_fwd<_Float16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
   else if (o.dtype == DHD_BF16) hipLaunchKernelGGL(mghs_stream_fwd<__bf16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
   else hipLaunchKernelGGL(mghs_stream_fwd<float>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, o, split);
@@ -832,8 +840,14 @@ int launch_stream_fwd(const Layout& L, const OutPtrs& o, int split, hipStream_t 
   return DHD_OK;
 }
 
-int launch_stream_bwd(const Layout& L, const InPtrs& in, int split, hipStream_t st) {
+int launch_stream_bwd(const Layout& L, const InPtrs& in, int split, hipStream_t st, bool op) {
   if (!L.compact || L.n_segs <= 0) return DHD_EINVAL;
+  if (op) {
+    if (in.dtype != DHD_F32) return DHD_EUNSUPPORTED;
+    hipLaunchKernelGGL((mghs_stream_bwd<float, 1>), dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, in, split);
+    DHD_LAUNCH_CHECK();
+    return DHD_OK;
+  }
   if (in.dtype == DHD_F16) hipLaunchKernelGGL(mghs_stream_bwd<_Float16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, in, split);
   else if (in.dtype == DHD_BF16) hipLaunchKernelGGL(mghs_stream_bwd<__bf16>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, in, split);
   else hipLaunchKernelGGL(mghs_stream_bwd<float>, dim3(L.n_segs * split), dim3(kStreamBlock), kStreamLds, st, L, in, split);

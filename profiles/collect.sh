@@ -16,7 +16,7 @@ if [[ " $WHAT " == *" hotpath "* ]]; then
 B="python $R/bench.py --steps 20 --warmup 3 --cpu-samples 0 --no-e2e"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hp -o hp -- $B 2>/dev/null | grep '^{' > $OUT/bench_hotpath_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mo -o mo -- $B --no-sfa 2>/dev/null | grep '^{' > $OUT/bench_mghs_only_under_rocprof.json
-P="python $R/bench.py --steps 5 --warmup 2 --cpu-samples 0 --no-e2e"
+P="python $R/bench.py --steps 5 --warmup 2 --pmc-pass"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o pf -- $P > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pw -o pw -- $P > /dev/null 2>&1
 cp $(find $OUT/hp -name 'hp_kernel_stats.csv') $OUT/hotpath_kernel_stats.csv
@@ -66,7 +66,7 @@ for k in sorted(set(f) | set(w)):
     if k.startswith('Cijk') or 'at::native' in k or k.startswith('__amd'): continue
     ks[k] = dict(FETCH_SIZE_KB=f.get(k, 0.0), WRITE_SIZE_KB=w.get(k, 0.0), hbm_bytes_per_launch=int((2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024))
 json.dump(dict(samples_per_gpu=4, source_sha256=kernel_source_sha256(),
-               command='rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 5 --warmup 2 --cpu-samples 0 --no-e2e (two separate passes)',
+               command='rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 5 --warmup 2 --pmc-pass (two separate passes)',
                correction='bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of a wide coalesced read)',
                kernels=ks), open(out + '/pmc_summary.json', 'w'), indent=1)
 print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in ks.items()}, indent=0)[:3000])
