@@ -65,10 +65,16 @@ __device__ __forceinline__ bool decode_segment(const Layout& L, int s, Segment* 
   return true;
 }
 
-// channels handled per pass so that nnz * cp <= kTableFloats (cp in {64,32,...}; kTableFloats >= kSegMaxVox * 4)
+// The LDS patch table of the segment writer / reader holds table[cc * pitch + j] = channel c_lo + cc of the segment's j-th
+// non-empty voxel, pitch = nnz | 1.  (Until round 4 it was [j][cc]: the lanes of a wave work on ONE channel run, i.e. the same cc
+// and different j, so their table accesses met in one LDS bank -- nothing on the band grids, where 3 % of the voxels hold a point,
+// but the full-height grid is half occupied at DHD-S and 90 % at the DHD-L geometry: 30- to 60-way conflicts on its segments.)
+// Neighbouring occupied voxels have neighbouring slots -> neighbouring banks; the fill / write-out side walks cc fastest, an odd
+// pitch spreads it over the banks.
+// channels handled per pass so that pitch * cp <= kTableFloats (cp in {64,32,...,4}; kTableFloats >= (kSegMaxVox + 1) * 4)
 __device__ __forceinline__ int channels_per_pass(int nnz) {
   int cp = kTileC;
-  while (cp > 4 && nnz * cp > kTableFloats) cp >>= 1;
+  while (cp > 4 && (nnz | 1) * cp > kTableFloats) cp >>= 1;
   return cp;
 }
 
@@ -348,16 +354,16 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
   __syncthreads();
   const int k0 = rfl(ctl[0]), nnz = rfl(ctl[1]) - k0;
   for (int j = t; j < nnz; j += kStreamBlock) slot_of[L.nzvox[k0 + j] - sg.v0] = (unsigned short)(j + 1);
-  const int cp = min(channels_per_pass(nnz), c_end - c_begin);
+  const int cp = min(channels_per_pass(nnz), c_end - c_begin), pitch = nnz | 1;
   const int nvec = sg.nvox / VPL;
   T* og = reinterpret_cast<T*>(out.p[sg.g]);
   const long sb = out.sb[sg.g], sz = out.sz[sg.g], sc = out.sc[sg.g];
   for (int c_lo = c_begin; c_lo < c_end; c_lo += cp) {
     __syncthreads();  // slot_of complete / previous pass done with the table
-    // table[j*cp + cc] = vsum[(k0+j)*64 + c_lo + cc]: runs of cp floats, coalesced
+    // table[cc*pitch + j] = vsum[(k0+j)*64 + c_lo + cc]: runs of cp floats, coalesced
     for (int i = t; i < nnz * cp; i += kStreamBlock) {
       const int j = i / cp, cc = i % cp;
-      table[i] = L.vsum[(size_t)(k0 + j) * kTileC + c_lo + cc];
+      table[cc * pitch + j] = L.vsum[(size_t)(k0 + j) * kTileC + c_lo + cc];
     }
     __syncthreads();
     // The cp channel runs of this pass (nvec 16-byte vectors each) are one flat index space: iteration `it` of wave
@@ -389,8 +395,8 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_fwd(Layout L, OutPtr
 #pragma unroll
         for (int k = 0; k < VPL / 2; ++k) {
           const unsigned s0 = sl[k] & 0xffffu, s1 = sl[k] >> 16;
-          if (s0) f[2 * k] = table[(s0 - 1) * cp + cc];
-          if (s1) f[2 * k + 1] = table[(s1 - 1) * cp + cc];
+          if (s0) f[2 * k] = table[cc * pitch + (s0 - 1)];
+          if (s1) f[2 * k + 1] = table[cc * pitch + (s1 - 1)];
         }
       }
       vfloat4* dst = reinterpret_cast<vfloat4*>(base + (size_t)cc * sc) + i;
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
   const int k0 = rfl(ctl[0]), nnz = rfl(ctl[1]) - k0;
   if (nnz == 0) return;
   for (int j = t; j < nnz; j += kStreamBlock) slot_of[L.nzvox[k0 + j] - sg.v0] = (unsigned short)(j + 1);
-  const int cp = min(channels_per_pass(nnz), c_end - c_begin);
+  const int cp = min(channels_per_pass(nnz), c_end - c_begin), pitch = nnz | 1;
   const int nvec = sg.nvox / VPL;
   const T* og = reinterpret_cast<const T*>(og_in.p[sg.g]);
   const long sb = og_in.sb[sg.g], sz = og_in.sz[sg.g], sc = og_in.sc[sg.g];
@@ -483,8 +489,8 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
 #pragma unroll
           for (int u = 0; u < VPL / 2; ++u) {
             const unsigned s0 = sl[k][u] & 0xffffu, s1 = sl[k][u] >> 16;
-            if (s0) table[(s0 - 1) * cp + ccs[k]] = f[2 * u];
-            if (s1) table[(s1 - 1) * cp + ccs[k]] = f[2 * u + 1];
+            if (s0) table[ccs[k] * pitch + (s0 - 1)] = f[2 * u];
+            if (s1) table[ccs[k] * pitch + (s1 - 1)] = f[2 * u + 1];
           }
         }
       }
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(kStreamBlock) void mghs_stream_bwd(Layout L, InPtrs
     __syncthreads();
     for (int i = t; i < nnz * cp; i += kStreamBlock) {
       const int j = i / cp, cc = i % cp;
-      L.vsum[(size_t)(k0 + j) * kTileC + c_lo + cc] = table[i];
+      L.vsum[(size_t)(k0 + j) * kTileC + c_lo + cc] = table[cc * pitch + j];
     }
   }
 }
