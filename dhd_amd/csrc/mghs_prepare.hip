@@ -216,11 +216,7 @@ __device__ __forceinline__ int count_runs(int* __restrict__ count, int key, int 
     // run end: next first, or next invalid lane, above the leader
     const unsigned long long stop = (F | ~V) & ~((2ull << lane) - 1ull);
     const int end = stop ? __builtin_ctzll(stop) : DHD_WAVE;
-#if defined(DHD_EXP_GEOM) && (DHD_EXP_GEOM & 1)
-    base = 0; count[key] = end - lane;          // experiment: no returning atomic
-#else
     base = atomicAdd(&count[key], end - lane);
-#endif
   }
   base = __shfl(base, leader, DHD_WAVE);
   return valid ? base + (lane - leader) : 0;
@@ -264,14 +260,10 @@ __global__ __launch_bounds__(kBlock) void mghs_geom_count(Layout L, dhd_calib ca
   int r0 = 0, r1 = 0;
   if (!BAND_ONLY) r0 = count_runs(L.count, k0, hh, lane);
   if (L.G > 1) r1 = count_runs(L.count, k1, hh, lane);
-#if defined(DHD_EXP_GEOM) && (DHD_EXP_GEOM & 2)
-  if (in_range && (k0 ^ r0 ^ k1 ^ r1) == 0x12345678) L.key[pid] = k0;   // experiment: no stores
-#else
   if (in_range) {
     if (!BAND_ONLY) { L.key[pid] = k0; L.rnk[pid] = r0; }
     L.key[L.P + pid] = k1; L.rnk[L.P + pid] = r1;
   }
-#endif
 }
 
 // Introspection twin of the kernel above: one grid, band-independent, optional ego output.
