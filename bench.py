@@ -627,6 +627,17 @@ def operator_roofline(hp, steps, warmup, fused=True):
     torch.cuda.synchronize()
     py_fused_ms = (time.perf_counter() - t0) / steps * 1e3
     py_fused_gpu_ms = event_mean(fev)
+    # the same with the voxel -> row map and the regrouping rebuilt in every call (index lists that change per call)
+    for it in range(3 + steps):
+        if it == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        dt.grad = ft.grad = None
+        bev_mod._regroup_cache.clear()
+        bev_mod._state_cache.clear()
+        bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln, fused=fused).backward(ogp)
+    torch.cuda.synchronize()
+    py_fused_uncached_ms = (time.perf_counter() - t0) / steps * 1e3
     fwd_ms = event_mean([(e[0], e[1]) for e in ev])
     bwd_ms = event_mean([(e[1], e[2]) for e in ev])
     n_kept = int(rb.numel())
@@ -643,6 +654,7 @@ def operator_roofline(hp, steps, warmup, fused=True):
                 algorithmic_bytes=fwd_bytes + bwd_bytes, forward_bytes=fwd_bytes, backward_bytes=bwd_bytes, kept_points=n_kept,
                 intervals=int(ln.numel()), python_op_fwd_bwd_ms=py_ms, python_op_fwd_bwd_regroup_every_call_ms=py_uncached_ms,
                 python_op_fused_fwd_bwd_ms=py_fused_ms, python_op_fused_fwd_bwd_event_ms=py_fused_gpu_ms,
+                python_op_fused_fwd_bwd_lists_rebuilt_every_call_ms=py_fused_uncached_ms,
                 python_op_fused_frac=(fwd_bytes + bwd_bytes) / (py_fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 note='full-height grid only (Dz=1); traffic = PMC bytes of the two kernels (the zero-fills of the caller-owned outputs are '
                      'torch fills, not counted); python_op_fwd_bwd_ms = dhd_amd.bev_pool_v2(...).backward() incl. zero-fill and permute, with '
@@ -650,7 +662,8 @@ def operator_roofline(hp, steps, warmup, fused=True):
                      'dhd_bev_pool_v2_regroup, a device counting sort) reused while the same index tensors come back; '
                      '..._regroup_every_call_ms redoes it in every backward; python_op_fused_* = bev_pool_v2(..., fused=True): the '
                      '(B, C, Dz, Dy, Dx) tensor written once by the segment writer, its gradient read once in that layout '
-                     '(dhd_bev_pool_v2_fused_forward / _backward), wall clock per call and HIP events around the same calls')
+                     '(dhd_bev_pool_v2_fused_forward / _backward), wall clock per call and HIP events around the same calls, the voxel -> row '
+                     'map and the regrouping reused while the same index tensors come back; ..._lists_rebuilt_every_call_ms redoes both')
 
 
 def cpu_baseline(hp, max_batch, warmups=3, reps=5, budget_s=75.0):

@@ -93,7 +93,7 @@ _PROTOTYPES = {
     'dhd_bev_pool_v2_regroup_scratch_bytes': ([_I, _I], C.c_size_t),
     'dhd_bev_pool_v2_regroup': ([_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, C.c_size_t, _P], _I),
     'dhd_bev_pool_v2_fused_workspace_bytes': ([_I] * 6 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], _I),
-    'dhd_bev_pool_v2_fused_forward': ([_P] * 8 + [_I] * 6 + [_P, C.c_size_t, _P, C.c_size_t, _P], _I),
+    'dhd_bev_pool_v2_fused_forward': ([_P] * 8 + [_I] * 6 + [_P, C.c_size_t, _I, _P, C.c_size_t, _P], _I),
     'dhd_bev_pool_v2_fused_backward': ([_P] * 10 + [_I] * 7 + [_P, C.c_size_t, _P, C.c_size_t, _P], _I),
     'dhd_mghs_workspace_bytes': ([C.POINTER(MghsDesc), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], _I),
     'dhd_height_band': ([_P, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P], _I),

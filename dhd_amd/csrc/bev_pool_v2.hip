@@ -633,7 +633,8 @@ int dhd_bev_pool_v2_fused_workspace_bytes(int c, int batch, int dz, int dy, int 
 int dhd_bev_pool_v2_fused_forward(const float* depth, const float* feat, float* out, const int32_t* ranks_depth,
                                   const int32_t* ranks_feat, const int32_t* ranks_bev, const int32_t* interval_lengths,
                                   const int32_t* interval_starts, int c, int n_intervals, int batch, int dz, int dy, int dx,
-                                  void* state, size_t state_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+                                  void* state, size_t state_bytes, int state_valid, void* scratch, size_t scratch_bytes,
+                                  void* stream) {
   dhd::Layout L;
   size_t sn, cn;
   if (!state || !scratch) return DHD_EINVAL;
@@ -644,13 +645,16 @@ int dhd_bev_pool_v2_fused_forward(const float* depth, const float* feat, float* 
     return DHD_EINVAL;
   if (n_intervals > 0 && (reinterpret_cast<uintptr_t>(feat) & 15)) return DHD_EINVAL;
   hipStream_t st = dhd_stream(stream);
-  DHD_HIP(hipMemsetAsync(L.count, 0, L.zero_bytes, st));
-  if (n_intervals > 0) {
-    hipLaunchKernelGGL(fused_mark_kernel, dim3(dhd_cdiv(n_intervals, kBlock)), dim3(kBlock), 0, st, n_intervals, L.V, ranks_bev,
-                       interval_starts, interval_lengths, L.count);
-    DHD_LAUNCH_CHECK();
+  if (!state_valid) {
+    // voxel -> row map of these index lists (a static rig passes the same lists every call: the caller may keep `state`)
+    DHD_HIP(hipMemsetAsync(L.count, 0, L.zero_bytes, st));
+    if (n_intervals > 0) {
+      hipLaunchKernelGGL(fused_mark_kernel, dim3(dhd_cdiv(n_intervals, kBlock)), dim3(kBlock), 0, st, n_intervals, L.V, ranks_bev,
+                         interval_starts, interval_lengths, L.count);
+      DHD_LAUNCH_CHECK();
+    }
+    if ((rc = dhd::launch_scan(L, st))) return rc;
   }
-  if ((rc = dhd::launch_scan(L, st))) return rc;
   if (n_intervals > 0) {
     constexpr int LL = dhd::kTileC / 4;
     hipLaunchKernelGGL((bev_pool_v2_fwd_vec_kernel<LL, 8, 6, true>), dim3(xcd_padded_blocks(dhd_cdiv(n_intervals, kWaves * (DHD_WAVE / LL)))),

@@ -89,8 +89,10 @@ int dhd_bev_pool_v2_fused_workspace_bytes(int c, int batch, int dz, int dy, int 
 int dhd_bev_pool_v2_fused_forward(const float* depth, const float* feat, float* out /* [dev] (B,C,Dz,Dy,Dx) */,
                                   const int32_t* ranks_depth, const int32_t* ranks_feat, const int32_t* ranks_bev,
                                   const int32_t* interval_lengths, const int32_t* interval_starts, int c, int n_intervals,
-                                  int batch, int dz, int dy, int dx, void* state, size_t state_bytes, void* scratch,
-                                  size_t scratch_bytes, void* stream);
+                                  int batch, int dz, int dy, int dx, void* state, size_t state_bytes,
+                                  int state_valid /* 1: `state` was filled by an earlier forward with the SAME ranks_bev /
+                                                     interval lists (a static rig) and is reused as it is */,
+                                  void* scratch, size_t scratch_bytes, void* stream);
 int dhd_bev_pool_v2_fused_backward(const float* out_grad /* [dev] (B,C,Dz,Dy,Dx) */, float* depth_grad, float* feat_grad,
                                    const float* depth, const float* feat, const int32_t* ranks_depth_bp,
                                    const int32_t* ranks_feat_bp, const int32_t* ranks_bev_bp,

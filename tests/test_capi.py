@@ -108,7 +108,7 @@ def test_argument_validation_happens_on_the_host():
     assert lib.dhd_bev_pool_v2_fused_workspace_bytes(64, 4, 1, 202, 200, 10, C.byref(fs), C.byref(fc)) == -3     # Dy % 4
     assert lib.dhd_bev_pool_v2_fused_workspace_bytes(64, 4, 1, 200, 260, 10, C.byref(fs), C.byref(fc)) == -3     # Dx > 256
     assert lib.dhd_bev_pool_v2_fused_workspace_bytes(64, 4, 1, 200, 200, 10, None, None) == -1
-    assert lib.dhd_bev_pool_v2_fused_forward(*([None] * 8), 64, 10, 4, 1, 200, 200, None, 0, None, 0, None) == -1
+    assert lib.dhd_bev_pool_v2_fused_forward(*([None] * 8), 64, 10, 4, 1, 200, 200, None, 0, 0, None, 0, None) == -1
     assert lib.dhd_bev_pool_v2_fused_backward(*([None] * 10), 64, 10, 10, 4, 1, 200, 200, None, 0, None, 0, None) == -1
     assert lib.dhd_sfa_channel_mean(None, None, 1, 512, 40000, None) == -1
     assert lib.dhd_height_band(None, 6, 65, 16, 44, None, None, None, None) == -1

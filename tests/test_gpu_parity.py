@@ -170,6 +170,18 @@ def test_bev_pool_v2_fused_equals_the_three_step_operator_bit_for_bit(gpu, case)
         res.append((out.detach(), dt.grad, ft.grad))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+    # the voxel -> row map is kept while the same index tensors come back (static rig) and rebuilt when one was written to
+    import importlib
+    bm = importlib.import_module('dhd_amd.bev_pool_v2')
+    stc, lnc = T(st, gpu), T(ln, gpu)
+    dt, ft = T(depth, gpu), T(feat, gpu)
+    first = bev_pool_v2(dt, ft, *idx, shape, stc, lnc, fused=True)
+    kept = bm._state_cache[first.device.index][2]
+    again = bev_pool_v2(dt, ft, *idx, shape, stc, lnc, fused=True)
+    assert bm._state_cache[first.device.index][2] is kept and torch.equal(first, again) and torch.equal(first, res[1][0])
+    idx[2].add_(0)                                            # in-place write: version bump, same values
+    third = bev_pool_v2(dt, ft, *idx, shape, stc, lnc, fused=True)
+    assert bm._state_cache[first.device.index][2] is not kept and torch.equal(third, first)
     keep = ln > 0
     ref = O.bev_pool_v2(depth, feat, rd, rf, rb, shape, st[keep], ln[keep])
     np.testing.assert_allclose(res[1][0].cpu().numpy(), ref, atol=3e-5, rtol=1e-5)
