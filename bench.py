@@ -588,56 +588,46 @@ def operator_roofline(hp, steps, warmup, fused=True):
         once(True)
     torch.cuda.synchronize()
     # the same operator through its Python surface (zero-fill, kernel, permute; backward with the argsort re-grouping)
+    import importlib
+    from dhd_amd.bev_pool_v2 import bev_pool_v2 as bev_pool_v2_op
+    bev_mod = importlib.import_module('dhd_amd.bev_pool_v2')   # the module (dhd_amd.bev_pool_v2 the attribute is the function)
     dt, ft = depth.clone().requires_grad_(), feat.clone().requires_grad_()
     shape = (B, 1, 200, 200, Cc)
     ogp = og.permute(0, 4, 1, 2, 3).contiguous()
-    for it in range(3 + steps):
-        if it == 3:
+
+    def python_op_ms(use_fused, clear=(), events=None):
+        """Wall clock per forward + backward call: 3 warm-up calls, then 5 loops of `steps` calls each (synchronised on both sides),
+        the MEDIAN loop -- one host stall of a few ms inside a single 20-call loop would otherwise be the figure."""
+        loops = []
+        for rep in range(6):
+            n = 3 if rep == 0 else steps
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        dt.grad = ft.grad = None
-        bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln).backward(ogp)
-    torch.cuda.synchronize()
-    py_ms = (time.perf_counter() - t0) / steps * 1e3
+            for _ in range(n):
+                dt.grad = ft.grad = None
+                for cache in clear:
+                    cache.clear()
+                if events is not None and rep > 0:
+                    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                    e[0].record()
+                bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln, fused=use_fused).backward(ogp)
+                if events is not None and rep > 0:
+                    e[1].record()
+                    events.append(tuple(e))
+            torch.cuda.synchronize()
+            if rep > 0:
+                loops.append((time.perf_counter() - t0) / n * 1e3)
+        return float(np.median(loops))
+
+    py_ms = python_op_ms(False)
     # the same with the regrouping redone in every backward (index lists rebuilt per call, as voxel_pooling_v2 does in training)
-    import importlib
-    bev_mod = importlib.import_module('dhd_amd.bev_pool_v2')   # the module (dhd_amd.bev_pool_v2 the attribute is the function)
-    for it in range(3 + steps):
-        if it == 3:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        dt.grad = ft.grad = None
-        bev_mod._regroup_cache.clear()
-        bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln).backward(ogp)
-    torch.cuda.synchronize()
-    py_uncached_ms = (time.perf_counter() - t0) / steps * 1e3
+    py_uncached_ms = python_op_ms(False, clear=(bev_mod._regroup_cache,))
     # fused=True (VERDICT r3 item 7): the (B, C, Dz, Dy, Dx) tensor written once, its gradient read once in that layout
     fev = []
-    for it in range(3 + steps):
-        if it == 3:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        dt.grad = ft.grad = None
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        e[0].record()
-        bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln, fused=fused).backward(ogp)
-        e[1].record()
-        if it >= 3:
-            fev.append(tuple(e))
-    torch.cuda.synchronize()
-    py_fused_ms = (time.perf_counter() - t0) / steps * 1e3
+    py_fused_ms = python_op_ms(fused, events=fev)
     py_fused_gpu_ms = event_mean(fev)
     # the same with the voxel -> row map and the regrouping rebuilt in every call (index lists that change per call)
-    for it in range(3 + steps):
-        if it == 3:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        dt.grad = ft.grad = None
-        bev_mod._regroup_cache.clear()
-        bev_mod._state_cache.clear()
-        bev_pool_v2_op(dt, ft, rd, rf, rb, shape, st, ln, fused=fused).backward(ogp)
-    torch.cuda.synchronize()
-    py_fused_uncached_ms = (time.perf_counter() - t0) / steps * 1e3
+    py_fused_uncached_ms = python_op_ms(fused, clear=(bev_mod._regroup_cache, bev_mod._state_cache))
     fwd_ms = event_mean([(e[0], e[1]) for e in ev])
     bwd_ms = event_mean([(e[1], e[2]) for e in ev])
     n_kept = int(rb.numel())

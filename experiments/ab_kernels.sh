@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for LIB in "$@"; do
   OUT=$R/gpurun_out/abk; rm -rf $OUT; mkdir -p $OUT
-  DHD_AMD_LIB=$R/$LIB rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python $R/bench.py --steps 10 --warmup 2 --repeats 3 --fresh-procs 0 --no-dhdl --cpu-samples 0 --no-e2e --no-sfa --no-operator --geometry $G --batch $B 2>/dev/null | grep '^{' > $OUT/bench.json
+  DHD_AMD_LIB=$R/$LIB rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python $R/bench.py --steps 10 --warmup 2 --repeats 3 --fresh-procs 0 --no-dhdl --cpu-samples 0 --no-e2e ${BENCH_FLAGS:---no-sfa} --no-operator --geometry $G --batch $B 2>/dev/null | grep '^{' > $OUT/bench.json
   echo "== $LIB: $(python -c "import json;d=json.load(open('$OUT/bench.json'));print('ms_per_step', round(d['ms_per_step'],4))")"
   python - "$OUT" "$PAT" <<'PY'
 import csv, glob, re, sys
