@@ -13,7 +13,7 @@ for LIB in "$@"; do
 import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + '/**/k_kernel_stats.csv', recursive=True)[0]
 for r in csv.DictReader(open(f)):
-    if re.search(sys.argv[2], r['Name']):
+    if re.search(sys.argv[2], r['Name']) and float(r['AverageNs']) > 1e3 * float(__import__('os').environ.get('MIN_US', '0')):
         print(f"   {r['Name'][:90]:90s} calls {r['Calls']:>5s} avg_us {float(r['AverageNs'])/1e3:8.1f}")
 PY
 done
