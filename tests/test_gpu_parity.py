@@ -1668,7 +1668,7 @@ def test_batchnorm2d_training_vs_torch(gpu, dtype, tol, shape):
 # SFA stage under nn.SyncBatchNorm (DHD-L.py:308-311 SyncbnControlHook): the phased operator, two ranks sharing cuda:0 over gloo
 # ---------------------------------------------------------------------------------------------
 
-def _syncbn_stage_worker(rank, world, port, q, gemm, sizes=(2, 2)):
+def _syncbn_stage_worker(rank, world, port, q, gemm, sizes=(2, 2), half=False):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1693,20 +1693,26 @@ def _syncbn_stage_worker(rank, world, port, q, gemm, sizes=(2, 2)):
     g = torch.Generator().manual_seed(77)
     x_all = torch.randn(sum(sizes), 2 * c, h, w, generator=g) * 0.7 + 0.1
     w_all = torch.randn(sum(sizes), c, h, w, generator=g)
-    x = x_all[lo:hi].to(dev).requires_grad_()
+    x = x_all[lo:hi].to(dev)
+    if half:                                       # a caller inside an autocast region: half x, half out / gradients (io_dtype)
+        x = x.half()
+    x.requires_grad_()
     assert needs_cross_rank_statistics(st) and fused_stage_supported(st, x)
     out = st(x)                                    # dhd_sfa_stage_forward_phase x 3, two all-reduces of 2C + 1 doubles
-    (out * w_all[lo:hi].to(dev)).sum().backward()
+    assert out.dtype == x.dtype
+    out.backward(w_all[lo:hi].to(dev).to(out.dtype))
+    assert x.grad.dtype == x.dtype
     # plain numpy data: tensors would travel as file descriptors of this process, which is gone by the time the parent reads
-    res = dict(out=out.detach().cpu().numpy(), gx=x.grad.cpu().numpy(), grads={k: p.grad.cpu().numpy() for k, p in st.named_parameters()},
+    res = dict(out=out.detach().float().cpu().numpy(), gx=x.grad.float().cpu().numpy(), grads={k: p.grad.cpu().numpy() for k, p in st.named_parameters()},
                buffers={k: v.cpu().numpy() for k, v in st.named_buffers()})
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('gemm,sizes', [('bf16x6', (2, 2)), ('bf16x3', (2, 2)), ('bf16x6', (3, 1))])
-def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm, sizes):
+@pytest.mark.parametrize('gemm,sizes,half', [('bf16x6', (2, 2), False), ('bf16x3', (2, 2), False), ('bf16x6', (3, 1), False),
+                                             ('bf16x6', (2, 2), True)])
+def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm, sizes, half):
     """core/hook/syncbncontrol.py:18-32 converts every BatchNorm at epoch 0 of DHD-L.py (:308-311), the stage's two included.
     The fused operator then runs cut at its statistics points (dhd_sfa_stage_forward_phase / backward_phase) with the
     (2C + 1) float64 sums all-reduced in between.  Two ranks (sharing the GPU over gloo) with two samples each -- or
@@ -1723,7 +1729,7 @@ def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm, sizes):
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_syncbn_stage_worker, args=(r, world, port, q, gemm, sizes)) for r in range(world)]
+    procs = [ctx.Process(target=_syncbn_stage_worker, args=(r, world, port, q, gemm, sizes, half)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))
@@ -1745,8 +1751,12 @@ def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm, sizes):
     ref.spacial_leanring = plain
     ref = ref.double().train()
     g = torch.Generator().manual_seed(77)
-    x_all = (torch.randn(sum(sizes), 2 * c, h, w, generator=g) * 0.7 + 0.1).double().requires_grad_()
-    w_all = torch.randn(sum(sizes), c, h, w, generator=g).double()
+    x_all = torch.randn(sum(sizes), 2 * c, h, w, generator=g) * 0.7 + 0.1
+    w_all = torch.randn(sum(sizes), c, h, w, generator=g)
+    if half:    # the operator sees the rounded input and output gradient; its own results are rounded once more on the way out
+        x_all, w_all = x_all.half(), w_all.half()
+    x_all, w_all = x_all.double().requires_grad_(), w_all.double()
+    hr = 2.0 ** -10 if half else 0.0          # half rounding of the returned tensors (relative)
     a = ref.fc(x_all.mean(dim=(2, 3)))[..., None, None]
     xb, xv = x_all[:, :c], x_all[:, c:]
     gate = torch.sigmoid(ref.spacial_leanring(a * xb + (1 - a) * xv))
@@ -1755,9 +1765,9 @@ def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm, sizes):
     f = GEMM_MODES[gemm]
     for r in range(world):
         sl = slice(sum(sizes[:r]), sum(sizes[:r + 1]))
-        np.testing.assert_allclose(res[r]['out'], out[sl].detach().numpy(), atol=2e-5 * min(f, 5.0), rtol=1e-4)
+        np.testing.assert_allclose(res[r]['out'], out[sl].detach().numpy(), atol=2e-5 * min(f, 5.0), rtol=1e-4 + hr)
         gref = x_all.grad[sl].numpy()
-        np.testing.assert_allclose(res[r]['gx'], gref, atol=1e-4 * f * np.abs(gref).max(), rtol=1e-3)
+        np.testing.assert_allclose(res[r]['gx'], gref, atol=1e-4 * f * np.abs(gref).max(), rtol=1e-3 + hr)
     names = {k: k for k, _ in ref.named_parameters()}
     for k, p in ref.named_parameters():
         got = sum(res[r]['grads'][k].astype(np.float64) for r in range(world))
