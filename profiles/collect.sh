@@ -4,6 +4,7 @@
 #   1. kernel stats of the default bench (MGHS + SFA stage) and of --no-sfa
 #   2. PMC passes (counters only, FETCH_SIZE and WRITE_SIZE separately) of the default bench
 #   3. a plain bench line outside the profiler (run last, after the PMC summary has been written)
+#   3b. `bench.py --gpus 2 --dist-backend gloo`: the N > 1 path with two ranks sharing the GPU
 #   4. kernel stats + the two PMC passes of `bench.py --workload ema` (its kernel is merged into pmc_summary.json)
 # Usage: collect.sh [hotpath] [ema]   (default: both)
 set -u
@@ -75,5 +76,7 @@ PY
 if [[ " $WHAT " == *" hotpath "* ]]; then
 mkdir -p $R/profiles/$ROUND && cp $OUT/pmc_summary.json $R/profiles/$ROUND/pmc_summary.json
 cd $R && python bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err
+# the N > 1 code path on the one-GPU box: two ranks sharing the GPU over gloo (bench.py spawns its own ranks)
+python bench.py --gpus 2 --dist-backend gloo --steps 3 --warmup 1 --batch 1 --cpu-samples 0 --no-operator --no-e2e --no-dhdl 2>$OUT/bench_two_ranks.err | grep '^{' > $OUT/bench_two_ranks_one_gpu_gloo.json
 fi
 ls -la $OUT
