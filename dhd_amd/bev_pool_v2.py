@@ -9,6 +9,7 @@ remove the argsort the reference repeats in every backward (bev_pool.py:47-57).
 import torch
 
 from . import _lib
+from .trace import traced
 
 __all__ = ['bev_pool_v2', 'QuickCumsumCuda']
 
@@ -38,6 +39,7 @@ class QuickCumsumCuda(torch.autograd.Function):
     """Name kept from the reference (bev_pool.py:11)."""
 
     @staticmethod
+    @traced('dhd.bev_pool_v2.forward')
     def forward(ctx, depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
                 interval_lengths):
         lib = _lib.load()
@@ -63,6 +65,7 @@ class QuickCumsumCuda(torch.autograd.Function):
         return out
 
     @staticmethod
+    @traced('dhd.bev_pool_v2.backward')
     def backward(ctx, out_grad):
         lib = _lib.load()
         ranks_bev, depth, feat, ranks_feat, ranks_depth = ctx.saved_tensors
@@ -126,6 +129,7 @@ class _FusedPool(torch.autograd.Function):
     written once, zeros included, and its gradient is read once in that layout (dhd_bev_pool_v2_fused_forward / _backward)."""
 
     @staticmethod
+    @traced('dhd.bev_pool_v2.fused.forward')
     def forward(ctx, depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts, interval_lengths):
         lib = _lib.load()
         if not depth.is_cuda:
@@ -166,6 +170,7 @@ class _FusedPool(torch.autograd.Function):
         return out
 
     @staticmethod
+    @traced('dhd.bev_pool_v2.fused.backward')
     def backward(ctx, out_grad):
         lib = _lib.load()
         ranks_bev, depth, feat, ranks_feat, ranks_depth, state = ctx.saved_tensors

@@ -10,6 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .trace import traced
 
 
 def grid_struct(lower, interval, size):
@@ -190,6 +191,7 @@ def _nhwc_to_nchw(x):
     return out
 
 
+@traced('dhd.mghs.prepare')
 def prepare(plan, calib, band, workspace):
     lib = _lib.load()
     dev = workspace.device
@@ -207,6 +209,7 @@ def _range_arrays(height_range, mask_range):
     return hr, mr
 
 
+@traced('dhd.mghs.lift')
 def lift(plan, calib, height, height_range, mask_range, tran_feat, workspace, static=False):
     """The lift side of MGHS.view_transform in one C call (dhd_mghs_lift: band ids from the height distribution, the
     context re-laid out to (B*N,fH,fW,C), geometry + grouping).  height may be None for a single-grid plan.  `static`:
@@ -339,6 +342,7 @@ class _MGHSPool(torch.autograd.Function):
     re-laid-out context the lift produced for `workspace` (mghs_op.lift); tran_feat itself only carries the gradient."""
 
     @staticmethod
+    @traced('dhd.mghs.pool.forward')
     def forward(ctx, depth, tran_feat, plan, workspace, feat_nhwc, layout='collapsed', out_dtype=torch.float32):
         # float32 inputs: callers cast outside the node (see mghs_pool) so that autograd casts the gradients back to whatever
         # dtype an autocast region produced.  out_dtype float16 / bfloat16: the writer rounds its float32 sums on the way out
@@ -357,6 +361,7 @@ class _MGHSPool(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    @traced('dhd.mghs.pool.backward')
     def backward(ctx, *grads):
         depth, feat_nhwc, state = ctx.saved_tensors
         plan, layout = ctx.plan, ctx.layout

@@ -17,6 +17,7 @@ import torch.nn as nn
 from . import _lib
 from .batchnorm import BatchNorm2d
 from .registry import NECKS
+from .trace import traced
 
 
 def _call(fn_name, *args):
@@ -28,6 +29,7 @@ class _AttentionStage(torch.autograd.Function):
     """x (B,2C,H,W) -> x_fuse (B,C,H,W); `stage` owns fc / spacial_leanring."""
 
     @staticmethod
+    @traced('dhd.sfa.blend_stage.forward')
     def forward(ctx, x, stage, *params):
         x = _lib.require_gpu_tensor(x.contiguous(), torch.float32, 'SFA input')  # cast happens outside the node
         if x.data_ptr() % 16:
@@ -62,6 +64,7 @@ class _AttentionStage(torch.autograd.Function):
         return out
 
     @staticmethod
+    @traced('dhd.sfa.blend_stage.backward')
     def backward(ctx, go):
         x, a1d, s2d = ctx.saved_tensors
         s_in, a1, u_in, s2 = ctx.inner
@@ -140,6 +143,7 @@ class _FusedStage(torch.autograd.Function):
     the f32 MFMA with the blends, BatchNorm and ReLU fused into their operand paths."""
 
     @staticmethod
+    @traced('dhd.sfa.stage.forward')
     def forward(ctx, x, stage, *params):
         # A half x (a caller inside an autocast region: the concatenated encoder outputs) is widened once for the operator, whose
         # arithmetic, saved tensors and parameters are float32; the stage's result then leaves in x's dtype (dhd_sfa_weights.
@@ -200,6 +204,7 @@ class _FusedStage(torch.autograd.Function):
         return out
 
     @staticmethod
+    @traced('dhd.sfa.stage.backward')
     def backward(ctx, go):
         x, saved = ctx.saved_tensors[:2]
         ps = ctx.saved_tensors[2:]

@@ -1780,3 +1780,26 @@ def test_fused_sfa_stage_under_syncbatchnorm_two_ranks(gpu, gemm, sizes, half):
             assert np.array_equal(res[0]['buffers'][k], res[1]['buffers'][k])
     # the convolution-bias gradients vanish only as a SUM over ranks: each rank's own contribution is non-zero
     assert np.abs(res[0]['grads']['spacial_leanring.0.bias']).max() > 1e-4
+
+
+def test_trace_ranges_on_the_gpu(gpu):
+    """DHD_AMD_TRACE / dhd_amd.trace.enable(): the operators run inside roctx ranges (torch.cuda.nvtx on ROCm) and give the same
+    results as without."""
+    from dhd_amd import bev_pool_v2, trace
+    depth = torch.rand(1, 1, 2, 2, 2, device=gpu).requires_grad_()
+    feat = torch.randn(1, 1, 2, 2, 64, device=gpu).requires_grad_()
+    I = lambda v: torch.tensor(v, device=gpu).int()
+    args = (I([0, 4, 1, 6]), I([0, 0, 1, 2]), I([5, 5, 31, 31]), (1, 1, 4, 8, 64), I([0, 2]), I([2, 2]))
+    was = trace.enabled()
+    res = []
+    try:
+        for on in (False, True):
+            trace.enable(on)
+            depth.grad = feat.grad = None
+            out = bev_pool_v2(depth, feat, *args, fused=True)
+            out.sum().backward()
+            res.append((out.detach().clone(), depth.grad.clone(), feat.grad.clone()))
+    finally:
+        trace.enable(was)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

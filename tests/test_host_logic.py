@@ -452,3 +452,37 @@ def test_cu_gemm_lds_tile_swizzle_is_bank_conflict_free():
                         for w in range(2):
                             banks[(a // 4 + w) % 32] = banks.get((a // 4 + w) % 32, 0) + 1
                     assert max(banks.values()) == 1, (c, wv, e)
+
+
+def test_trace_ranges_wrap_the_operators_only_when_enabled(monkeypatch):
+    """dhd_amd.trace: named roctx ranges (torch.cuda.nvtx) around the operators, off by default (a disabled range is one
+    global check); the decorated autograd functions keep their names and signatures."""
+    import torch
+    from dhd_amd import trace, mghs_op, mix, bev_pool_v2 as _  # noqa: F401
+    import importlib
+    bp = importlib.import_module('dhd_amd.bev_pool_v2')
+    calls = []
+    monkeypatch.setattr(torch.cuda.nvtx, 'range_push', lambda name: calls.append(('push', name)))
+    monkeypatch.setattr(torch.cuda.nvtx, 'range_pop', lambda: calls.append(('pop',)))
+
+    @trace.traced('unit.range')
+    def f(a, b=2):
+        if a < 0:
+            raise ValueError('neg')
+        return a + b
+
+    was = trace.enabled()
+    try:
+        trace.enable(False)
+        assert f(1) == 3 and calls == []
+        trace.enable(True)
+        assert f(1, b=5) == 6 and calls == [('push', 'unit.range'), ('pop',)]
+        with pytest.raises(ValueError):
+            f(-1)
+        assert calls[-1] == ('pop',) and len(calls) == 4          # the range is closed on the way out of an exception
+    finally:
+        trace.enable(was)
+    assert f.__name__ == 'f'
+    for fn in (mghs_op._MGHSPool.forward, mghs_op._MGHSPool.backward, mix._FusedStage.forward, mix._FusedStage.backward,
+               bp._FusedPool.forward, bp.QuickCumsumCuda.backward, mghs_op.lift):
+        assert hasattr(fn, '__wrapped__')
