@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from .trace import traced
 
-__all__ = ['bev_pool_v2', 'QuickCumsumCuda']
+__all__ = ['bev_pool_v2', 'QuickCumsumCuda', 'fused_supported', 'clear_caches']
 
 
 def _as(t, dtype):
@@ -218,6 +218,14 @@ def _scratch_for(dev, stream, nbytes):
     if buf is None or buf.numel() < nbytes:
         buf = _fused_scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     return buf
+
+
+def clear_caches():
+    """Drop what the wrapper keeps between calls per device: the last regrouping of the backward, the last voxel -> row map of
+    the fused forward (each holds its index tensors alive) and the fused operator's scratch buffers."""
+    _regroup_cache.clear()
+    _state_cache.clear()
+    _fused_scratch.clear()
 
 
 def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
