@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$G
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/g -o g -- python $R/bench.py --steps 20 --warmup 3 --cpu-samples 0 --no-e2e --no-sfa --no-operator --geometry $G --batch $B 2>/dev/null | grep '^{' > $OUT/bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/g -o g -- python $R/bench.py --steps 20 --warmup 3 --cpu-samples 0 --no-e2e --no-sfa --no-operator --fresh-procs 0 --no-dhdl --geometry $G --batch $B 2>/dev/null | grep '^{' > $OUT/bench.json
 cp $(find $OUT/g -name 'g_kernel_stats.csv') $OUT/kernel_stats.csv
 rm -rf $OUT/g
 python - "$OUT" <<'PY'
