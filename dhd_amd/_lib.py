@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DHD_AMD_LIB', os.path.join(_HERE, 'csrc', 'libdhd_amd.so'))
 
 DHD_MAX_GRIDS = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _ERRORS = {-1: 'DHD_EINVAL (bad argument)', -2: 'DHD_ENOSPACE (workspace too small)',
            -3: 'DHD_EUNSUPPORTED (size outside supported range)'}
@@ -72,7 +72,7 @@ class SfaWeights(C.Structure):
                   'conv2_w', 'conv2_b', 'bn2_w', 'bn2_b', 'bn2_mean', 'bn2_var')] +
                 [('hidden', C.c_int32), ('training', C.c_int32), ('eps1', C.c_float), ('eps2', C.c_float),
                  ('momentum1', C.c_float), ('momentum2', C.c_float), ('gemm', C.c_int32),
-                 ('bn1_batches', C.c_void_p), ('bn2_batches', C.c_void_p), ('io_dtype', C.c_int32)])
+                 ('bn1_batches', C.c_void_p), ('bn2_batches', C.c_void_p), ('io_dtype', C.c_int32), ('storage_dtype', C.c_int32)])
 
 
 SFA_GEMM = {'default': 0, 'bf16x6': 1, 'f32': 2, 'bf16x3': 3}   # dhd_sfa_weights.gemm
@@ -123,6 +123,8 @@ _PROTOTYPES = {
     'dhd_sfa_blend1_backward': ([_P] * 5 + [_I, _I, _I, _P], _I),
     'dhd_sfa_mean_backward': ([_P, _P, _I, _I, _I, _P], _I),
     'dhd_sfa_stage_supported': ([_I, _I], _I),
+    'dhd_sfa_stage_half_storage_supported': ([_I, _I], _I),
+    'dhd_sfa_stage_workspace_bytes': ([_I] * 5 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], _I),
     'dhd_sfa_stage_saved_bytes': ([_I, _I, _I, _I], C.c_size_t),
     'dhd_sfa_stage_scratch_bytes': ([_I, _I, _I, _I], C.c_size_t),
     'dhd_sfa_stage_forward': ([_P, C.POINTER(SfaWeights), _P, _P, _P, _I, _I, _I, _P], _I),

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_cu_kernel(const float* 
           for (int e = 0; e < 4; ++e) o[e] = __int_as_float(__float_as_int(o[e]) & __builtin_amdgcn_sbfe(w4, e, 1));
         }
         const int soff = (32 * mt + 8 * k) * row_bytes + p0 * 4;
-        if (!(ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, voff_st, soff, SAUX);
+        if (!(ABL & 2)) store_b128_guarded<SAUX>(__builtin_bit_cast(u32x4, o), ry, voff_st, soff);
       }
     }
     };
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_cu_kernel(const float* 
       const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, 16, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 4 * MT; ++i)
-        if (!(ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, ry, 0x7ffffff0, 0, SAUX);
+        if (!(ABL & 2)) store_b128_guarded<SAUX>(u32x4{0u, 0u, 0u, 0u}, ry, 0x7ffffff0, 0);
     };
     issue(std::integral_constant<int, 0>{}, t0);
     if (R == 2) {

@@ -54,6 +54,19 @@ __device__ __forceinline__ int write_lane(int word, int sval) {
   return word;
 }
 
+// buffer_store_dwordx4 whose write-data registers stay untouched for the wait states the hardware needs.  hipcc lets a VALU
+// instruction overwrite the data VGPRs of a MUBUF store of more than 8 bytes in the very next issue slot when the store's
+// soffset is an SGPR (LLVM GCNHazardRecognizer::createsVALUHazard assumes the hazard away in that case); on gfx950 the store
+// then sends the NEW values -- measured in round 5 with pw_gemm_cuh_kernel<_Float16> (experiments/gemm_cuh_bench.hip): 1.6 % of
+// the 16-byte stores carried four bytes of the next channel row until a wait state followed the store.  The asm "uses" the data
+// register, so the allocator cannot recycle it before, and spends two wait states.  experiments/lint_store_hazard.py checks the
+// generated code for the pattern (tests/test_build_lint.py).
+template <int AUX>
+__device__ __forceinline__ void store_b128_guarded(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, AUX);
+  asm volatile("s_nop 1" : "+v"(v) : : "memory");
+}
+
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
   (f(std::integral_constant<int, I>{}), ...);

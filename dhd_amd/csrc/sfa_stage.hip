@@ -39,6 +39,7 @@
 #include <stdlib.h>
 
 #include "sfa_gemm_cu.h"
+#include "sfa_half.h"
 #include "sfa_mfma.h"
 
 using namespace dhd_sfa;
@@ -1412,7 +1413,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void pw_gemm_res_kernel(const float*
         for (int k = 0; k < 2; ++k) {
           const f32x4 w = *reinterpret_cast<const f32x4*>(tr + ((lane >> 3) + 8 * k) * kTrPitch + 4 * (lane & 7));
           const int srow = (g * 32 * COB + 32 * t + 16 * ph + 8 * k) * row_bytes;   // scalar
-          if (st_ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), ry, vst, srow, 0);
+          if (st_ok) store_b128_guarded<0>(__builtin_bit_cast(u32x4, w), ry, vst, srow);
         }
       }
       if (kWaveStats) {
@@ -2469,6 +2470,17 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
   return DHD_OK;
 }
 
+#include "sfa_stage_half.h"
+
+// dhd_sfa_weights.storage_dtype of a call: DHD_F32, or the half type every tensor of the stage is stored in (== io_dtype)
+inline int storage_of(const dhd_sfa_weights* w, int c, int hw, int* storage) {
+  *storage = w->storage_dtype;
+  if (*storage == DHD_F32) return DHD_OK;
+  if (*storage != DHD_F16 && *storage != DHD_BF16) return DHD_EINVAL;
+  if (w->io_dtype != *storage) return DHD_EINVAL;
+  return half_storage_supported(c, hw) ? DHD_OK : DHD_EUNSUPPORTED;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2486,13 +2498,30 @@ size_t dhd_sfa_stage_scratch_bytes(int b, int c, int hw, int hidden) {
   return scratch_layout(b, c, hw, hidden).total * sizeof(float);
 }
 
+int dhd_sfa_stage_half_storage_supported(int c, int hw) { return half_storage_supported(c, hw) ? 1 : 0; }
+
+int dhd_sfa_stage_workspace_bytes(int b, int c, int hw, int hidden, int storage_dtype, size_t* saved_bytes, size_t* scratch_bytes) {
+  if (b <= 0 || hidden <= 0 || !saved_bytes || !scratch_bytes) return DHD_EINVAL;
+  if (storage_dtype == DHD_F32) {
+    if (!stage_supported(c, hw)) return DHD_EUNSUPPORTED;
+    *saved_bytes = saved_layout(b, c, hw, hidden).total * sizeof(float);
+    *scratch_bytes = scratch_layout(b, c, hw, hidden).total * sizeof(float);
+    return DHD_OK;
+  }
+  if (storage_dtype != DHD_F16 && storage_dtype != DHD_BF16) return DHD_EINVAL;
+  if (!half_storage_supported(c, hw)) return DHD_EUNSUPPORTED;
+  *saved_bytes = saved_layout_h(b, c, hw, hidden).total;
+  *scratch_bytes = scratch_layout_h(b, c, hw, hidden).total;
+  return DHD_OK;
+}
+
 // Forward in up to three phases, cut at the two BatchNorm statistics points.  sync == nullptr: all phases in one call with
 // this call's own statistics.  sync != nullptr (nn.SyncBatchNorm): phases [lo, hi]; a phase that ends at a statistics point
 // leaves this rank's sums in `sync` ((2C + 1) doubles: [sum (y - bias)][C] | [sum (y - bias)^2][C] | count), the next phase
 // starts from the caller's all-reduced vector in the same place.
-static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch, int b, int c, int hw,
+static int stage_forward_impl(const void* xv, const dhd_sfa_weights* w, void* out, void* saved, void* scratch, int b, int c, int hw,
                               int lo, int hi, double* sync, void* stream) {
-  if (!x || !w || !saved || !scratch || b <= 0 || (hi == 2 && !out)) return DHD_EINVAL;
+  if (!xv || !w || !saved || !scratch || b <= 0 || (hi == 2 && !out)) return DHD_EINVAL;
   if (!stage_supported(c, hw) || w->hidden <= 0) return DHD_EUNSUPPORTED;
   if (!w->fc1_w || !w->fc1_b || !w->fc2_w || !w->fc2_b || !w->conv1_w || !w->conv1_b || !w->bn1_w || !w->bn1_b || !w->conv2_w ||
       !w->conv2_b || !w->bn2_w || !w->bn2_b)
@@ -2501,6 +2530,11 @@ static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, void* ou
   if (set_call_mode(w->gemm) != DHD_OK) return DHD_EINVAL;
   if (w->io_dtype != DHD_F32 && w->io_dtype != DHD_F16 && w->io_dtype != DHD_BF16) return DHD_EINVAL;
   hipStream_t st = dhd_stream(stream);
+  int storage;
+  if (int rcs = storage_of(w, c, hw, &storage); rcs != DHD_OK) return rcs;
+  if (storage == DHD_F16) return stage_forward_half<_Float16>(xv, w, out, saved, scratch, b, c, hw, lo, hi, sync, st);
+  if (storage == DHD_BF16) return stage_forward_half<__bf16>(xv, w, out, saved, scratch, b, c, hw, lo, hi, sync, st);
+  const float* x = static_cast<const float*>(xv);
   const int r = w->hidden;
   const SavedLayout S = saved_layout(b, c, hw, r);
   const ScratchLayout T = scratch_layout(b, c, hw, r);
@@ -2604,18 +2638,23 @@ static int stage_forward_impl(const float* x, const dhd_sfa_weights* w, void* ou
 
 // Backward in up to three phases, cut where the two BatchNorm backward passes need their sums (sum g, sum g (y - mu)); `sync`
 // as in stage_forward_impl ((2C + 1) doubles: [sum g][C] | [sum g (y - mu)][C] | count).
-static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const void* saved, const void* gout, void* gx,
+static int stage_backward_impl(const void* xv, const dhd_sfa_weights* w, const void* saved, const void* gout, void* gx,
                                const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw, int lo, int hi, double* sync,
                                void* stream) {
-  if (!x || !w || !saved || !gout || !grads || !scratch || b <= 0 || (hi == 2 && !gx)) return DHD_EINVAL;
+  if (!xv || !w || !saved || !gout || !grads || !scratch || b <= 0 || (hi == 2 && !gx)) return DHD_EINVAL;
   if (!stage_supported(c, hw) || w->hidden <= 0) return DHD_EUNSUPPORTED;
   if (!grads->fc1_w || !grads->fc1_b || !grads->fc2_w || !grads->fc2_b || !grads->conv1_w || !grads->conv1_b || !grads->bn1_w ||
       !grads->bn1_b || !grads->conv2_w || !grads->conv2_b || !grads->bn2_w || !grads->bn2_b)
     return DHD_EINVAL;
   if (set_call_mode(w->gemm) != DHD_OK) return DHD_EINVAL;
   if (w->io_dtype != DHD_F32 && w->io_dtype != DHD_F16 && w->io_dtype != DHD_BF16) return DHD_EINVAL;
-  if (sync && !(w->training && g_gemm_mode >= 1)) return DHD_EUNSUPPORTED;
   hipStream_t st = dhd_stream(stream);
+  int storage;
+  if (int rcs = storage_of(w, c, hw, &storage); rcs != DHD_OK) return rcs;
+  if (storage == DHD_F16) return stage_backward_half<_Float16>(xv, w, saved, gout, gx, grads, scratch, b, c, hw, lo, hi, sync, st);
+  if (storage == DHD_BF16) return stage_backward_half<__bf16>(xv, w, saved, gout, gx, grads, scratch, b, c, hw, lo, hi, sync, st);
+  if (sync && !(w->training && g_gemm_mode >= 1)) return DHD_EUNSUPPORTED;
+  const float* x = static_cast<const float*>(xv);
   const int r = w->hidden;
   const SavedLayout S = saved_layout(b, c, hw, r);
   const ScratchLayout T = scratch_layout(b, c, hw, r);
@@ -2701,23 +2740,23 @@ static int stage_backward_impl(const float* x, const dhd_sfa_weights* w, const v
   return DHD_OK;
 }
 
-int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch, int b, int c, int hw,
+int dhd_sfa_stage_forward(const void* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch, int b, int c, int hw,
                           void* stream) {
   return stage_forward_impl(x, w, out, saved, scratch, b, c, hw, 0, 2, nullptr, stream);
 }
 
-int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void* saved, const void* gout, void* gx,
+int dhd_sfa_stage_backward(const void* x, const dhd_sfa_weights* w, const void* saved, const void* gout, void* gx,
                            const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw, void* stream) {
   return stage_backward_impl(x, w, saved, gout, gx, grads, scratch, b, c, hw, 0, 2, nullptr, stream);
 }
 
-int dhd_sfa_stage_forward_phase(const float* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch, int b, int c, int hw,
+int dhd_sfa_stage_forward_phase(const void* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch, int b, int c, int hw,
                                 int phase, double* sync_sums, void* stream) {
   if (phase < 0 || phase > 2 || !sync_sums || (reinterpret_cast<uintptr_t>(sync_sums) & 7)) return DHD_EINVAL;
   return stage_forward_impl(x, w, out, saved, scratch, b, c, hw, phase, phase, sync_sums, stream);
 }
 
-int dhd_sfa_stage_backward_phase(const float* x, const dhd_sfa_weights* w, const void* saved, const void* gout, void* gx,
+int dhd_sfa_stage_backward_phase(const void* x, const dhd_sfa_weights* w, const void* saved, const void* gout, void* gx,
                                  const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw, int phase, double* sync_sums,
                                  void* stream) {
   if (phase < 0 || phase > 2 || !sync_sums || (reinterpret_cast<uintptr_t>(sync_sums) & 7)) return DHD_EINVAL;

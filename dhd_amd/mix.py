@@ -150,11 +150,20 @@ class _FusedStage(torch.autograd.Function):
         # io_dtype: rounded to nearest even, what the next convolution's cast would make of a float32 result), the gradient comes
         # back in that dtype and the input gradient is returned in it -- no float32 round trips of (B,C,H,W) / (B,2C,H,W) tensors
         io_dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else torch.float32
-        x = _lib.require_gpu_tensor(x.float().contiguous(), torch.float32, 'SFA input')
-        if x.data_ptr() % 16:
-            x = x.clone()
         b, c2, h, w = x.shape
         c, hw = c2 // 2, h * w
+        # HALF STORAGE (dhd_sfa_weights.storage_dtype, ABI 4): a half x is read as it is and every (B,C,H,W) tensor the operator
+        # keeps or passes between its kernels stays in that type -- the reference's own formulation under autocast (mix.py:37-59
+        # with DHD-S.py:281); float32 arithmetic, statistics, parameters and parameter gradients.  C == 128 / 256, hw % 8 == 0;
+        # otherwise (or with stage.half_storage = False) x is widened once and only the edges are half (ABI 3 behaviour)
+        half_storage = (io_dtype != torch.float32 and stage.half_storage
+                        and bool(_lib.load().dhd_sfa_stage_half_storage_supported(c, hw)))
+        if half_storage:
+            x = _lib.require_gpu_tensor(x.contiguous(), io_dtype, 'SFA input')
+        else:
+            x = _lib.require_gpu_tensor(x.float().contiguous(), torch.float32, 'SFA input')
+        if x.data_ptr() % 16:
+            x = x.clone()
         dev = x.device
         lib = _lib.load()
         bn1, bn2 = stage.spacial_leanring[1], stage.spacial_leanring[4]
@@ -174,14 +183,18 @@ class _FusedStage(torch.autograd.Function):
         wts.hidden, wts.training = hidden, training
         wts.gemm = _lib.SFA_GEMM[stage.gemm or default_gemm()]   # per call; backward reuses this struct
         wts.io_dtype = _lib.dtype_code(io_dtype)
+        wts.storage_dtype = wts.io_dtype if half_storage else 0
         wts.eps1, wts.eps2 = bn1.eps, bn2.eps
         (wts.momentum1, wts.bn1_batches), (wts.momentum2, wts.bn2_batches) = _bn_momentum(bn1, training), _bn_momentum(bn2, training)
         if training and not bn1.training:
             wts.bn1_mean = wts.bn1_var = wts.bn2_mean = wts.bn2_var = None
         group = _sync_group(stage)   # None, or the process group whose ranks share BatchNorm statistics (nn.SyncBatchNorm)
         with torch.cuda.device(dev):
-            saved = torch.empty(lib.dhd_sfa_stage_saved_bytes(b, c, hw, hidden), dtype=torch.uint8, device=dev)
-            scratch = _stage_scratch(dev, lib.dhd_sfa_stage_scratch_bytes(b, c, hw, hidden))
+            nsaved, nscratch = C.c_size_t(), C.c_size_t()
+            _lib.check(lib.dhd_sfa_stage_workspace_bytes(b, c, hw, hidden, wts.storage_dtype, C.byref(nsaved), C.byref(nscratch)),
+                       'dhd_sfa_stage_workspace_bytes')
+            saved = torch.empty(nsaved.value, dtype=torch.uint8, device=dev)
+            scratch = _stage_scratch(dev, nscratch.value)
             out = torch.empty((b, c, h, w), dtype=io_dtype, device=dev)
             if group is None:
                 _lib.check(lib.dhd_sfa_stage_forward(_lib.ptr(x), C.byref(wts), _lib.ptr(out), _lib.ptr(saved), _lib.ptr(scratch),
@@ -201,6 +214,7 @@ class _FusedStage(torch.autograd.Function):
             ctx.dims = (b, c, hw)
             ctx.group = group
             ctx.io_dtype = io_dtype
+            ctx.nscratch = nscratch.value
         return out
 
     @staticmethod
@@ -218,7 +232,7 @@ class _FusedStage(torch.autograd.Function):
             grads = _lib.SfaGrads()
             for n, g in zip(_STAGE_PARAMS, gps):
                 setattr(grads, n, g.data_ptr())
-            scratch = _stage_scratch(dev, lib.dhd_sfa_stage_scratch_bytes(b, c, hw, ctx.wts.hidden))
+            scratch = _stage_scratch(dev, ctx.nscratch)
             if ctx.group is None:
                 _lib.check(lib.dhd_sfa_stage_backward(_lib.ptr(x), C.byref(ctx.wts), _lib.ptr(saved), _lib.ptr(go), _lib.ptr(gx),
                                                       C.byref(grads), _lib.ptr(scratch), b, c, hw, _lib.stream_ptr(dev)),
@@ -298,6 +312,7 @@ class channel_spatial_stage(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     fused = True  # set False to force the generic path (library convolutions between the blend kernels)
+    half_storage = True   # a half x (autocast region): keep every tensor of the fused stage in that type (see _FusedStage.forward)
     gemm = None   # 'bf16x3' | 'bf16x6' | 'f32': precision of the fused stage's C x C GEMMs; None = default_gemm()
 
     def forward(self, x):

@@ -11,8 +11,11 @@
  *   - Return value: 0 on success, a positive hipError_t if a launch failed, or one of the
  *     negative DHD_E* codes for argument errors.  (The reference validates nothing and
  *     returns void: ops/bev_pool_v2/src/bev_pool.cpp:30-57.)
- *   - All floating point data is float32, all indices int32, exactly as in the reference
- *     (ops/bev_pool_v2/bev_pool.py:19-25).
+ *   - Floating point data is float32 and indices int32, exactly as in the reference
+ *     (ops/bev_pool_v2/bev_pool.py:19-25), unless an argument says otherwise: since ABI 3 the large tensors at the
+ *     edges of the MGHS and SFA operators may be float16 / bfloat16 (dhd_tensor_view.dtype, dhd_sfa_weights.io_dtype),
+ *     since ABI 4 every tensor of the SFA stage may be (dhd_sfa_weights.storage_dtype) -- what a caller inside an
+ *     autocast region holds.  Arithmetic and accumulation are float32 in every case.
  *
  * File:line citations are into /root/reference/projects/mmdet3d_plugin/.
  */
@@ -31,7 +34,7 @@ extern "C" {
 #define DHD_ENOSPACE (-2)   /* workspace too small */
 #define DHD_EUNSUPPORTED (-3)
 
-#define DHD_ABI_VERSION 3
+#define DHD_ABI_VERSION 4
 int dhd_abi_version(void);
 
 /* ------------------------------------------------------------------------------------ *
@@ -337,9 +340,11 @@ int dhd_sfa_mean_backward(const float* gs, float* gx, int b, int c2, int hw, voi
 /* ------------------------------------------------------------------------------------ *
  * 4. The whole SFA attention stage as one operator (models/necks/mix.py:8-59,
  *    channel_spatial_stage): channel mean -> fc -> blend1 -> conv1x1 -> BatchNorm -> ReLU ->
- *    conv1x1 -> BatchNorm -> sigmoid -> blend2, forward and backward, float32.  The two 1x1
- *    convolutions run on the f32 MFMA with the blends / BatchNorm / ReLU fused into their operand
- *    paths (csrc/sfa_stage.hip); only conv outputs y1, y2 are kept for backward.
+ *    conv1x1 -> BatchNorm -> sigmoid -> blend2, forward and backward.  The two 1x1 convolutions
+ *    run on the matrix cores (bf16 MFMA on exact bf16 splits of the float32 operands by default,
+ *    dhd_sfa_weights.gemm; single half products under dhd_sfa_weights.storage_dtype) with the
+ *    blends / BatchNorm / ReLU fused into their operand paths (csrc/sfa_stage.hip, sfa_gemm_cu.h,
+ *    sfa_half.h); only the conv outputs y1, y2 and one ReLU pass bit per activation are kept for backward.
  *    Supported: C == 128 or C % 256 == 0, hw % 4 == 0, 2*C*hw*4 bytes < 4 GiB (dhd_sfa_stage_supported); other shapes
  *    return DHD_EUNSUPPORTED and callers use the section-3 kernels around library convolutions.
  * ------------------------------------------------------------------------------------ */
@@ -372,6 +377,13 @@ typedef struct dhd_sfa_weights { /* [dev] float32 */
                            tensor the operator keeps are float32.  Half types are for a caller inside an autocast region: it hands a
                            half x (which it widens once for the operator), gets the stage's result rounded to nearest even -- what the
                            next convolution's cast of a float32 result would produce -- and passes the half gradient straight back */
+  int32_t storage_dtype; /* ABI 4.  DHD_F32 (0): as above.  DHD_F16 / DHD_BF16 (must equal io_dtype; C == 128 or 256 and hw % 8 == 0,
+                           dhd_sfa_stage_half_storage_supported): HALF STORAGE -- x is read in that type (no widened copy), and every
+                           (B,C,H,W) tensor the stage keeps or passes between its kernels (y1, y2, g2, g1, du) is stored in it, as the
+                           reference's own formulation does under autocast (mix.py:37-59 with DHD-S.py:281); each 1x1 convolution is ONE
+                           half product per a*b accumulated in float32 (`gemm` is ignored); prologues, BatchNorm statistics (of the
+                           stored values), coefficient tables, parameters and parameter gradients stay float32.  `saved` / `scratch`
+                           sizes: dhd_sfa_stage_workspace_bytes */
 } dhd_sfa_weights;
 
 typedef struct dhd_sfa_grads { /* [dev] float32 outputs, shapes as in dhd_sfa_weights, overwritten */
@@ -381,6 +393,7 @@ typedef struct dhd_sfa_grads { /* [dev] float32 outputs, shapes as in dhd_sfa_we
 } dhd_sfa_grads;
 
 int dhd_sfa_stage_supported(int c, int hw);
+int dhd_sfa_stage_half_storage_supported(int c, int hw);   /* storage_dtype = DHD_F16 / DHD_BF16 (ABI 4) */
 /* dhd_sfa_weights.gemm: how the stage's C x C GEMMs are computed in THIS call (forward and backward of one stage must
  * pass the same value; nothing is process-wide).  Every float32 operand is cut into bfloat16 parts (round-to-nearest-even,
  * exact: h + m + l == x) for the bf16 MFMA:
@@ -400,12 +413,14 @@ int dhd_sfa_stage_supported(int c, int hw);
  * `scratch` is reusable between calls on one stream.  0 if the shape is unsupported. */
 size_t dhd_sfa_stage_saved_bytes(int b, int c, int hw, int hidden);
 size_t dhd_sfa_stage_scratch_bytes(int b, int c, int hw, int hidden);
+/* The same two sizes for a given dhd_sfa_weights.storage_dtype (ABI 4; DHD_F32 gives the values above). */
+int dhd_sfa_stage_workspace_bytes(int b, int c, int hw, int hidden, int storage_dtype, size_t* saved_bytes, size_t* scratch_bytes);
 
-/* x (B,2C,H,W) -> out (B,C,H,W) = x_fuse of mix.py:58. */
-int dhd_sfa_stage_forward(const float* x, const dhd_sfa_weights* w, void* out /* w->io_dtype */, void* saved,
+/* x (B,2C,H,W) -> out (B,C,H,W) = x_fuse of mix.py:58.  x is float32, or w->storage_dtype when that is a half type. */
+int dhd_sfa_stage_forward(const void* x, const dhd_sfa_weights* w, void* out /* w->io_dtype */, void* saved,
                           void* scratch, int b, int c, int hw, void* stream);
 /* gout (B,C,H,W) -> gx (B,2C,H,W) and every parameter gradient. */
-int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void* saved,
+int dhd_sfa_stage_backward(const void* x, const dhd_sfa_weights* w, const void* saved,
                            const void* gout, void* gx /* both w->io_dtype */, const dhd_sfa_grads* grads, void* scratch,
                            int b, int c, int hw, void* stream);
 
@@ -424,9 +439,9 @@ int dhd_sfa_stage_backward(const float* x, const dhd_sfa_weights* w, const void*
  * gradients are this rank's contributions (the caller's DDP averages parameter gradients), exactly as torch's
  * SyncBatchNorm.  Training mode and the bf16 GEMM precisions only (DHD_EUNSUPPORTED otherwise).  With one rank and no
  * all-reduce the three phases reproduce dhd_sfa_stage_forward / backward. */
-int dhd_sfa_stage_forward_phase(const float* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch,
+int dhd_sfa_stage_forward_phase(const void* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch,
                                 int b, int c, int hw, int phase, double* sync_sums /*[dev] 2C+1*/, void* stream);
-int dhd_sfa_stage_backward_phase(const float* x, const dhd_sfa_weights* w, const void* saved, const void* gout,
+int dhd_sfa_stage_backward_phase(const void* x, const dhd_sfa_weights* w, const void* saved, const void* gout,
                                  void* gx, const dhd_sfa_grads* grads, void* scratch, int b, int c, int hw,
                                  int phase, double* sync_sums /*[dev] 2C+1*/, void* stream);
 

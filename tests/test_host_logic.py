@@ -454,6 +454,69 @@ def test_cu_gemm_lds_tile_swizzle_is_bank_conflict_free():
                     assert max(banks.values()) == 1, (c, wv, e)
 
 
+def test_half_gemm_lds_layouts_are_bank_conflict_free():
+    """dhd_amd/csrc/sfa_half.h.  (1) pw_gemm_cuh_kernel: the 64-pixel activation tile [pixel p][k] of a half type, 16-byte unit
+    u of a row at u ^ swz(p), swz(p) = ((p >> 3) & 7 ^ (p & 1) << 2) | ((p >> 1) & 1) << 3: staging stores (ds_write_b64, lane =
+    8 g + q: rows 4g..4g+3, pixel 8q + e) and fragment reads (ds_read_b128, lane = (pixel n, k half h), rows n and n + 32) touch
+    every bank once per lane group.  (2) pw_wgrad_h_kernel: a row's eight fragments (ds_write_b128, 8 contiguous lanes) land in
+    eight different 16-byte slots once unit u of fragment (ks, hh) is stored at u ^ (2 ks + hh), and the fragment reads stay
+    conflict free.  Rules: MI355X_MICROARCH.md, LDS."""
+    def swz(p):
+        return (((p >> 3) & 7) ^ ((p & 1) << 2)) | (((p >> 1) & 1) << 3)
+
+    assert all(swz(8 * q + e) == swz(8 * q) ^ swz(e) for q in range(8) for e in range(8)) and swz(32) == 4
+    g0 = [0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27]
+    g1 = [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]
+    read_groups = [g0, g1, [x + 32 for x in g0], [x + 32 for x in g1]]
+    for c, waves in ((256, 8), (128, 4)):
+        rowb = 2 * c
+        for ks in range(c // 16):
+            for half in range(2):
+                for grp in read_groups:
+                    banks = {}
+                    for lane in grp:
+                        n, h = lane & 31, lane >> 5
+                        p = n + 32 * half
+                        a = p * rowb + (((2 * ks + h) ^ swz(p)) << 4)
+                        for w in range(4):
+                            banks[(a // 4 + w) % 64] = banks.get((a // 4 + w) % 64, 0) + 1
+                    assert max(banks.values()) == 1, (c, ks, half)
+        for wv in range(waves):
+            kbase = wv * 32
+            for e in range(8):
+                for l0 in range(0, 64, 16):
+                    banks = {}
+                    for lane in range(l0, l0 + 16):
+                        g, q = lane >> 3, lane & 7
+                        p, kq = 8 * q + e, (kbase >> 2) + g
+                        a = p * rowb + (((kq >> 1) ^ swz(p)) << 4) + ((kq & 1) << 3)
+                        for w in range(2):
+                            banks[(a // 4 + w) % 32] = banks.get((a // 4 + w) % 32, 0) + 1
+                    assert max(banks.values()) == 1, (c, wv, e)
+    # (2) weight-gradient staging: unit index within one (k-step, operand) image = tile * 64 + ((row & 31) + 32 hh) ^ ch8
+    for ot in (256, 128):
+        for wv in range(8):
+            for j in range(ot // 64):
+                for l0 in range(0, 64, 8):      # ds_write_b128: groups of 8 contiguous lanes, 32 banks
+                    slots = set()
+                    for lane in range(l0, l0 + 8):
+                        row, ch8 = 64 * j + 8 * wv + (lane >> 3), lane & 7
+                        ks, hh = ch8 >> 1, ch8 & 1
+                        unit = (ks * 2) * (ot // 32) * 64 + (row >> 5) * 64 + (((row & 31) + 32 * hh) ^ ch8)
+                        slots.add(unit % 8)
+                    assert len(slots) == 8
+        for ks in range(4):
+            for grp in read_groups:
+                slots = set()
+                for lane in grp:
+                    slots.add(((lane ^ (lane >> 5)) ^ (2 * ks)) % 16)
+                assert len(slots) == 16
+            # the read finds what the write put there: lane (r, h) of k-step ks reads fragment (row r, half h)
+            for lane in range(64):
+                r, h = lane & 31, lane >> 5
+                assert ((lane ^ h) ^ (2 * ks)) == ((r + 32 * h) ^ (2 * ks + h))
+
+
 def test_trace_ranges_wrap_the_operators_only_when_enabled(monkeypatch):
     """dhd_amd.trace: named roctx ranges (torch.cuda.nvtx) around the operators, off by default (a disabled range is one
     global check); the decorated autograd functions keep their names and signatures."""
