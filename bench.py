@@ -507,7 +507,11 @@ def mghs_amp_record(hp, steps, warmup, dtype=torch.float16):
         # the SFA stage operator in the same two regimes: x arrives in half (the concatenated encoder outputs of an autocast region)
         xh = hp.x.detach().to(dtype).requires_grad_()
         gyh = hp.gy.to(dtype)
-        for mode in ('f32_nodes_plus_casts', 'half_io'):
+        out['half_edges'] = dict(out['half_io'])     # the MGHS part is the same measurement; the stage differs (below)
+        for mode in ('f32_nodes_plus_casts', 'half_edges', 'half_io'):
+            # half_edges = round 4's form (ABI 3: out / gout / gx in half, float32 storage inside), half_io = the default since
+            # round 5: HALF STORAGE (dhd_sfa_weights.storage_dtype, ABI 4) -- x read in half, y1 / y2 / g2 / g1 / du kept in half
+            hp.stage.half_storage = mode == 'half_io'
             ev = []
             for it in range(warmup + steps):
                 xh.grad = None
@@ -524,12 +528,15 @@ def mghs_amp_record(hp, steps, warmup, dtype=torch.float16):
             torch.cuda.synchronize()
             out[mode]['sfa_stage_ms'] = event_mean(ev)
             out[mode]['hot_path_ms'] = out[mode]['mghs_step_ms'] + out[mode]['sfa_stage_ms']
+        hp.stage.half_storage = True
         del xh, gyh
     out['dtype'] = str(dtype).replace('torch.', '')
     out['writer_half_GBps'] = hp.pool_fwd_bytes / 2 / (out['half_io']['writer_ms'] * 1e-3) / 1e9   # half the output bytes (+ the 1 % of inputs)
     out['note'] = ('MGHS part of the hot path only (lift + pooling forward + backward), B = %d; writer_ms = the streaming writer alone '
                    '(half: 352 MB instead of 704 MB at B = 4); sfa_stage_ms = the stage operator forward + backward with a half x: widened and '
-                   'narrowed around a float32 node, or dhd_sfa_weights.io_dtype (out / gout / gx in half, x widened once inside)' % hp.B)
+                   'narrowed around a float32 node (f32_nodes_plus_casts), dhd_sfa_weights.io_dtype only (half_edges: out / gout / gx in half, x '
+                   'widened once, float32 storage inside), or dhd_sfa_weights.storage_dtype (half_io: every tensor of the stage in half, single-'
+                   'product half GEMMs with float32 accumulation, float32 statistics and parameter gradients)' % hp.B)
     return out
 
 
