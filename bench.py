@@ -1078,10 +1078,14 @@ def main():
             line['value_bf16x6'] = a.batch * world * a.steps / elapsed_x6
         bwd_ms = part_stats['mghs_bwd_ms']['median']
         bwd_ach = hp.pool_bwd_bytes / (bwd_ms * 1e-3) / 1e9
+        bwd_traffic = (lambda p: None if None in p else int(sum(p)))([pmc_traffic(k, a.batch) for k in ('mghs_stream_bwd', 'mghs_pixel_bwd')])
+        # `frac_effective`: ALGORITHMIC bytes (the whole out_grad, 177.7 MB/sample) over the time -- the kernels skip the out_grad lines
+        # that hold no point, so this is a rate of useful work, not of HBM traffic; `frac_hbm`: the bytes the counters saw over the same
+        # time (null without a PMC record of these sources).  (round 4 called the first one `frac`.)
         line['roofline_bwd'] = dict(bound='hbm', kernel='mghs_stream_bwd + mghs_pixel_bwd (dhd_mghs_backward)', achieved=bwd_ach,
-                                    peak=HBM_PEAK_GBPS, unit='GB/s', frac=bwd_ach / HBM_PEAK_GBPS,
-                                    traffic=(lambda p: None if None in p else int(sum(p)))([pmc_traffic(k, a.batch) for k in ('mghs_stream_bwd', 'mghs_pixel_bwd')]),
-                                    launch_ms=bwd_ms, algorithmic_bytes=hp.pool_bwd_bytes)
+                                    peak=HBM_PEAK_GBPS, unit='GB/s', frac_effective=bwd_ach / HBM_PEAK_GBPS,
+                                    frac_hbm=None if bwd_traffic is None else bwd_traffic / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                    traffic=bwd_traffic, launch_ms=bwd_ms, algorithmic_bytes=hp.pool_bwd_bytes)
         if 'sfa_fwd_ms' in part_stats:
             # second roofline, for the SFA stage operator as a whole (a dozen kernels per call): SURVEY 8(d) gives its forward
             # algorithmic traffic as x read twice + u/out written + the two 1x1 convs reading and writing (B,C,H,W) once each

@@ -118,15 +118,21 @@ def _regrouped(lib, ranks_depth, ranks_feat, ranks_bev, n_pixels):
 _fused_scratch = {}   # (device index, stream) -> uint8 scratch of the fused operator (reusable between calls on a stream)
 
 
-def fused_supported(bev_feat_shape):
-    """Shapes dhd_bev_pool_v2_fused_* takes (include/dhd_amd.h): C == 64, Dy % 4 == 0, Dx % 4 == 0, Dx <= 256."""
-    _, _, dy, dx, c = (int(v) for v in bev_feat_shape)
-    return c == 64 and dy % 4 == 0 and dx % 4 == 0 and dx <= 256
+def fused_supported(bev_feat_shape, n_intervals=1):
+    """Whether dhd_bev_pool_v2_fused_* takes this shape.  The library is asked (dhd_bev_pool_v2_fused_workspace_bytes returns
+    DHD_EUNSUPPORTED otherwise: C == 64, Dy % 4 == 0, Dx % 4 == 0, Dx <= 256, B*Dz*Dy*Dx <= 2^30 today), so the gate cannot
+    drift from the C side."""
+    import ctypes as C
+    b, dz, dy, dx, c = (int(v) for v in bev_feat_shape)
+    sb, cb = C.c_size_t(), C.c_size_t()
+    return _lib.load().dhd_bev_pool_v2_fused_workspace_bytes(c, b, dz, dy, dx, max(int(n_intervals), 1), C.byref(sb), C.byref(cb)) == 0
 
 
 class _FusedPool(torch.autograd.Function):
     """bev_pool_v2 + `permute(0, 4, 1, 2, 3).contiguous()` (bev_pool.py:86-106) as one node: the (B, C, Dz, Dy, Dx) tensor is
     written once, zeros included, and its gradient is read once in that layout (dhd_bev_pool_v2_fused_forward / _backward)."""
+
+    cache = True   # set per call by bev_pool_v2(..., cache=...)
 
     @staticmethod
     @traced('dhd.bev_pool_v2.fused.forward')
@@ -152,7 +158,7 @@ class _FusedPool(torch.autograd.Function):
         with _on(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             stamp = tuple((t.data_ptr(), t._version, t.numel()) for t in srcs) + (b, dz, dy, dx, stream)   # filled on this stream
-            hit = _state_cache.get(dev.index)
+            hit = _state_cache.get(dev.index) if _FusedPool.cache else None
             valid = hit is not None and hit[0] == stamp
             out = torch.empty((b, c, dz, dy, dx), dtype=f32, device=dev)
             state = hit[2] if valid else torch.empty(sizes[0], dtype=torch.uint8, device=dev)
@@ -163,7 +169,7 @@ class _FusedPool(torch.autograd.Function):
                 state.data_ptr(), sizes[0], 1 if valid else 0, scratch.data_ptr(), scratch.numel(), stream)
         if rc:
             _lib.check(rc, 'dhd_bev_pool_v2_fused_forward')
-        if not valid:
+        if not valid and _FusedPool.cache:
             _state_cache[dev.index] = (stamp, srcs, state)   # srcs kept alive: their addresses cannot be recycled for other lists
         ctx.save_for_backward(ranks_bev, depth, feat, ranks_feat, ranks_depth, state)
         ctx.dims = (b, dz, dy, dx, c, n_iv, sizes)
@@ -229,7 +235,7 @@ def clear_caches():
 
 
 def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
-                interval_lengths, fused=False):
+                interval_lengths, fused=False, cache=True):
     """
     Args (identical to the reference, bev_pool.py:86-106):
         depth: (B, N, D, fH, fW)
@@ -238,14 +244,24 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
         bev_feat_shape: (B, D_Z, D_Y, D_X, C)
         interval_starts, interval_lengths: (N_pillar,)
         fused (not in the reference): write the returned (B, C, Dz, Dy, Dx) tensor directly, once, zeros included, instead
-            of zero-fill + kernel + permute copy; same values bit for bit.  Shapes outside `fused_supported` take the
-            reference's three steps.
+            of zero-fill + kernel + permute copy; same values bit for bit.  Shapes the library's fused entry points do not
+            take (`fused_supported`, which asks the library) run the reference's three steps.
+        cache (fused only): keep the voxel -> row map of the last call per device and reuse it while the SAME index tensors
+            come back unmodified -- recognised by (data_ptr, torch's version counter, numel) of ranks_bev / interval_starts /
+            interval_lengths.  CONTRACT: while cached, those tensors must only be modified through torch operations (which bump
+            the version counter); writes through `.data`, raw-pointer kernels or other libraries are invisible and would reuse
+            a stale map.  The cache keeps the three tensors and the map alive until `clear_caches()`.  cache=False rebuilds the
+            map on every call (+ ~10 us) and pins nothing.
     Returns:
         bev feature (B, C, Dz, Dy, Dx)
     """
-    if fused and fused_supported(bev_feat_shape):
-        return _FusedPool.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
-                                interval_lengths)
+    if fused and fused_supported(bev_feat_shape, interval_lengths.numel()):
+        _FusedPool.cache = bool(cache)
+        try:
+            return _FusedPool.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
+                                    interval_lengths)
+        finally:
+            _FusedPool.cache = True
     x = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
                               interval_starts, interval_lengths)
     return x.permute(0, 4, 1, 2, 3).contiguous()

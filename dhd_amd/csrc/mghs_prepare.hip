@@ -574,7 +574,11 @@ int dhd_mghs_debug_keys(const dhd_mghs_desc* desc, const dhd_mghs_workspace* ws,
   if (!ws || !keys) return DHD_EINVAL;
   int rc = make_layout(desc, ws, &L);
   if (rc) return rc;
-  DHD_HIP(hipMemcpyAsync(keys, L.key, (size_t)2 * L.P * sizeof(int32_t), hipMemcpyDeviceToDevice, dhd_stream(stream)));
+  DHD_HIP(hipMemcpyAsync(keys, L.key, (size_t)L.P * sizeof(int32_t), hipMemcpyDeviceToDevice, dhd_stream(stream)));
+  // a single-grid plan has no band grids: the counting kernel never writes row 1, so the hook reports "no key" there instead of
+  // whatever the scratch held
+  if (L.G > 1) DHD_HIP(hipMemcpyAsync(keys + L.P, L.key + L.P, (size_t)L.P * sizeof(int32_t), hipMemcpyDeviceToDevice, dhd_stream(stream)));
+  else DHD_HIP(hipMemsetAsync(keys + L.P, 0xff, (size_t)L.P * sizeof(int32_t), dhd_stream(stream)));
   return DHD_OK;
 }
 

@@ -91,12 +91,14 @@ def rank_report(**mine):
     -- rank, local rank, device index / name / PCI bus id, RCCL's version, plus whatever the caller measured on that rank
     (`mine`: e.g. its own step time next to the MAX over ranks that defines the headline).  Identical on every rank."""
     rank, local, world_env = env_world()
-    rec = dict(rank=rank, local_rank=local, pid=os.getpid())
+    import socket
+    rec = dict(rank=rank, local_rank=local, pid=os.getpid(), host=socket.gethostname())
     if torch.cuda.is_available():
         i = torch.cuda.current_device()
         prop = torch.cuda.get_device_properties(i)
         rec.update(device=i, device_name=prop.name, visible_devices=torch.cuda.device_count(),
-                   pci_bus_id=getattr(prop, 'pci_bus_id', None), hbm_bytes=prop.total_memory)
+                   pci_bus_id=getattr(prop, 'pci_bus_id', None), pci_domain_id=getattr(prop, 'pci_domain_id', None),
+                   pci_device_id=getattr(prop, 'pci_device_id', None), hbm_bytes=prop.total_memory)
     rec.update(mine)
     live = dist.is_initialized()
     out = dict(backend=dist.get_backend() if live else None, world_size=dist.get_world_size() if live else 1, world_size_env=world_env,
@@ -109,8 +111,13 @@ def rank_report(**mine):
         got = [None] * dist.get_world_size()
         dist.all_gather_object(got, rec)
         out['ranks'] = got
-        devs = [(r.get('pci_bus_id') or r.get('device')) for r in got]
-        out['distinct_devices'] = len(set(devs))
+        # one key type per device: (host, PCI domain, bus, device) where the runtime reports a bus id (0 is a valid bus), else
+        # (host, local device index) -- bus numbers repeat across hosts and PCI domains
+        def dev_key(r):
+            if r.get('pci_bus_id') is not None:
+                return (r.get('host'), r.get('pci_domain_id'), r.get('pci_bus_id'), r.get('pci_device_id'))
+            return (r.get('host'), 'index', r.get('device'))
+        out['distinct_devices'] = len({dev_key(r) for r in got})
     else:
         out['ranks'] = [rec]
         out['distinct_devices'] = 1

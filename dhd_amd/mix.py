@@ -319,7 +319,9 @@ class channel_spatial_stage(nn.Module):
         if self.fused and fused_stage_supported(self, x):
             return _FusedStage.apply(x, self, *_stage_params(self))
         params = list(self.fc.parameters()) + list(self.spacial_leanring.parameters())
-        return _AttentionStage.apply(x.float(), self, *params)
+        out = _AttentionStage.apply(x.float(), self, *params)
+        # the same dtype as the fused path returns for a half x (and as the reference returns under autocast)
+        return out.to(x.dtype) if x.dtype in (torch.float16, torch.bfloat16) else out
 
 
 @NECKS.register_module()

@@ -289,11 +289,14 @@ int dhd_mghs_backward(const dhd_mghs_desc* desc, const float* depth, const float
 int dhd_mghs_voxel_index(const dhd_mghs_desc* desc, const dhd_calib* calib, int grid_index,
                          int32_t* rank_map, float* ego, void* stream);
 
-/* Parity hook: the voxel keys the PRODUCT kernels (mghs_geom_count of dhd_mghs_prepare / dhd_mghs_lift) computed in the
+/* TEST-ONLY entry point (as the DHD_MGHS_DEBUG_SCAN_SELF_SERVE flag: part of the ABI so that the parity tests reach the product's
+ * own kernels through it, of no use to a caller and free to change with the kernels).
+ * Parity hook: the voxel keys the PRODUCT kernels (mghs_geom_count of dhd_mghs_prepare / dhd_mghs_lift) computed in the
  * last prepare on `ws`: keys[p] = global voxel id of point p in grid 0, keys[P + p] = in the grid of its pixel's height
  * band (P = B*N*D*fH*fW), -1 = dropped; the global id of voxel r of grid g is r + sum over g' < g of B*nz*ny*nx.  These are
  * the words the grouping is built from; dhd_mghs_voxel_index is a separate kernel over the same device functions.
- * Valid from a prepare to the next use of the scratch.  keys is [dev] 2P int32. */
+ * Valid from a prepare to the next use of the scratch.  keys is [dev] 2P int32; with a single-grid plan (no band grids) the second
+ * row reads -1 everywhere. */
 int dhd_mghs_debug_keys(const dhd_mghs_desc* desc, const dhd_mghs_workspace* ws, int32_t* keys, void* stream);
 
 /* Number of pooled (point, grid) pairs of the last prepare, per grid: n_kept[g] points,

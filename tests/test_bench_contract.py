@@ -37,7 +37,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields(gpu):
     for name in ('roofline', 'roofline_bwd', 'roofline_operator', 'roofline_sfa_stage'):
         r = d[name]
         assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
-        assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.02 < r['frac'] < 1.0, (name, r['frac'])
+        frac = r['frac_effective'] if name == 'roofline_bwd' else r['frac']   # (algorithmic bytes over time; frac_hbm = counter bytes)
+        assert abs(frac - r['achieved'] / r['peak']) < 1e-9 and 0.02 < frac < 1.0, (name, frac)
+        if name == 'roofline_bwd':
+            assert 'frac' not in r and (r['frac_hbm'] is None or 0.02 < r['frac_hbm'] < 1.0)
         assert r['traffic'] is None or r['traffic'] > 0
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'samples/s' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c

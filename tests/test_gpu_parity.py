@@ -223,6 +223,19 @@ def test_bev_pool_v2_fused_edge_cases(gpu):
     e = torch.empty(0, device=gpu).int()
     z = bev_pool_v2(d2.detach(), f2.detach(), e, e, e, shape, e, e, fused=True)
     assert z.shape == (1, C, 1, 4, 8) and float(z.abs().max()) == 0
+    # cache=False: the voxel -> row map is rebuilt per call and nothing is pinned; an index list rewritten behind torch's version
+    # counter (the documented hole of the cached form) is then seen
+    from dhd_amd import bev_pool_v2 as bp_mod
+    import dhd_amd.bev_pool_v2 as bp
+    bp.clear_caches()
+    iv_s, iv_l = I([0, 2, 4]), I([2, 2, 1])
+    a = bev_pool_v2(d2.detach(), f2.detach(), rd, rf, rb, shape, iv_s, iv_l, fused=True, cache=False)
+    assert not bp._state_cache and torch.equal(a, out.detach())
+    rb.data.copy_(I([6, 6, 30, 30, 32]))          # no version bump
+    b = bev_pool_v2(d2.detach(), f2.detach(), rd, rf, rb, shape, iv_s, iv_l, fused=True, cache=False)
+    assert torch.allclose(b.view(1, C, 32)[0, :, 6], want[0, 5], atol=1e-6) and float(b.view(1, C, 32)[0, :, 5].abs().max()) == 0
+    # the gate is the library's: more voxels than the fused entry points index fall back (here only asked, not run)
+    assert not fused_supported((2, 8192, 512, 256, 64)) and fused_supported((1, 8192, 512, 256, 64))
 
 
 def test_bev_pool_v2_regroup_vs_argsort(gpu):
@@ -778,7 +791,7 @@ class gemm_mode:
         return False
 
 
-def _check_stage_against_torch(st, x, tol_x=1e-4, tol_p=5e-4, tol_out=1e-4, tie=_TIE):
+def _check_stage_against_torch(st, x, tol_x=1e-4, tol_p=5e-4, tol_out=1e-4, tie=_TIE, rel_l2=None):
     """Forward + backward of `st` (HIP) on x against plain PyTorch fp32 on a copy of the module.
 
     A pre-ReLU activation within rounding of zero (measured: 1.4e-7 at the one or two pixels that
@@ -803,8 +816,14 @@ def _check_stage_against_torch(st, x, tol_x=1e-4, tol_p=5e-4, tol_out=1e-4, tie=
 
     def close(mine, ra, rb, tol, what):
         scale = max(1.0, ra.abs().max().item())
-        excess = ((mine - ra).abs() - 1.01 * (ra - rb).abs()).max().item()
+        over = (mine - ra).abs() - 1.01 * (ra - rb).abs()
+        excess = over.max().item()
         assert excess <= tol * scale, (what, excess, scale)
+        # next to the element-wise maximum (x 20 for bf16x3, see GEMM_MODES): the relative L2 error of the whole tensor, which is
+        # what DESIGN.md section 6 quotes (1.5e-3 for dW1 at full size in bf16x3) -- tie elements excluded as above
+        if rel_l2 is not None and ra.norm().item() > 1e-3 * max(1.0, float(ra.numel()) ** 0.5 * 1e-3):
+            rel = (over.clamp_min(0).norm() / ra.norm()).item()
+            assert rel <= rel_l2, (what, 'relative L2', rel)
     close(out.detach(), o_a, o_a, tol_out, 'out')
     close(x.grad, gx_a, gx_b, tol_x, 'gx')
     for (k, p), qa, qb in zip(st.named_parameters(), gp_a, gp_b):
@@ -821,7 +840,8 @@ def test_sfa_stage_full_size_vs_torch(gpu, gemm):
     st = channel_spatial_stage(512).to(gpu)
     x = torch.randn(1, 512, 200, 200, device=gpu, requires_grad=True)
     with gemm_mode(gemm) as f:
-        _check_stage_against_torch(st, x, tol_x=1e-4 * f, tol_p=5e-4 * f, tol_out=1e-4 * min(f, 3.0), tie=_TIE * f)
+        _check_stage_against_torch(st, x, tol_x=1e-4 * f, tol_p=5e-4 * f, tol_out=1e-4 * min(f, 3.0), tie=_TIE * f,
+                                   rel_l2=3e-3 if f > 1.0 else 1e-4)
 
 
 @pytest.mark.parametrize('gemm', list(GEMM_MODES))
@@ -847,7 +867,8 @@ def test_sfa_stage_vs_torch(gpu, c, b, h, w, train, gemm):
     x = (torch.randn(b, 2 * c, h, w, device=gpu) * 0.7 + 0.1).requires_grad_()
     assert fused_stage_supported(st, x) == (c != 64)
     with gemm_mode(gemm) as f:
-        _check_stage_against_torch(st, x, tol_x=1e-4 * f, tol_p=5e-4 * f, tol_out=1e-4 * min(f, 3.0), tie=_TIE * f)
+        _check_stage_against_torch(st, x, tol_x=1e-4 * f, tol_p=5e-4 * f, tol_out=1e-4 * min(f, 3.0), tie=_TIE * f,
+                                   rel_l2=3e-3 if f > 1.0 else 1e-4)
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
@@ -995,6 +1016,15 @@ def test_sfa_stage_half_storage_falls_back_where_unsupported(gpu):
     out = st(x)
     out.sum().backward()
     assert out.dtype == torch.float16 and x.grad.dtype == torch.float16
+    # and the generic path (C = 64: blend kernels around library convolutions) returns x's dtype too (it returned float32)
+    from dhd_amd.mix import fused_stage_supported
+    for dt in (torch.float16, torch.bfloat16, torch.float32):
+        st64 = channel_spatial_stage(128).to(gpu).train()
+        x64 = torch.randn(2, 128, 12, 12, device=gpu).to(dt).requires_grad_()
+        assert not fused_stage_supported(st64, x64)
+        o64 = st64(x64)
+        o64.float().sum().backward()
+        assert o64.dtype == dt and x64.grad.dtype == dt
 
 
 @pytest.mark.parametrize('c,b,h,w', [(128, 2, 20, 28), (256, 2, 36, 40), (512, 1, 24, 40)])
@@ -1081,6 +1111,15 @@ def test_single_grid_view_transform_core_compact_path(gpu):
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=1e-5, rtol=1e-5)
     out.sum().backward()
     assert torch.isfinite(dt.grad).all() and ft.grad.abs().sum() > 0
+    # the parity hook on a single-grid plan: row 0 = the keys, row 1 (no band grids) = -1, not stale scratch
+    from dhd_amd import mghs_op
+    plan1, axes1 = make_plan(cfg, 1, 3, n_grids=1)
+    calib1, _ = device_calib(calib_np, axes1, gpu)
+    ws1 = plan1.new_workspace(gpu, private_scratch=True)
+    ws1.scratch.fill_(7)
+    mghs_op.prepare(plan1, calib1, None, ws1)
+    keys = mghs_op.debug_keys(plan1, ws1)
+    assert bool((keys[1] == -1).all()) and int((keys[0] >= 0).sum()) > 0
 
 
 def test_uncollapsed_layouts_match_collapsed(gpu):
@@ -1280,6 +1319,49 @@ def test_static_lift_full_size_is_bit_identical_to_a_full_lift(gpu):
                 assert kept[0] > 400000
             else:
                 assert k_now[0] == kept[0] and k_now[1:] != kept[1:]      # grid 0's grouping is the static part, the bands moved
+
+
+def test_static_lift_column_form_equals_a_full_lift(gpu):
+    """dhd_mghs_lift_static at the DHD-L geometry (32 x 88 maps, D = 88, B = 2) under DEFAULT flags: fH = 32 takes the column
+    form of the grid-0 sums (mghs_col_sums; grid 0's sorted entry list is not built), which round 4 left without a static-lift
+    test.  After one full lift, two frames with new height maps / depth / context redo only the band grids' grouping: the keys
+    of the product's counting kernel and the whole `state` block (voxel -> slot maps, per-point slots) are identical to those of a
+    full lift on a fresh workspace, the pooled tensors equal up to the summation order of the atomics."""
+    from dhd_amd import mghs_op
+    from oracle import mghs_oracle as O
+    cfg = syn.dhd_s_config()
+    cfg['grid_config'] = dict(cfg['grid_config'], depth=[1.0, 45.0, 0.5])
+    cfg['input_size'] = (512, 1408)
+    B, N, D, fh, fw = 2, 6, 88, 32, 88
+    calib_np = syn.make_calibration(431, B, N, cfg['input_size'])
+    axes = O.frustum_axes(cfg['grid_config']['depth'], cfg['input_size'], cfg['downsample'])
+    grids = [mghs_op.grid_from_cfg(g) for g in grid_cfgs(cfg)]
+    plan = mghs_op.Plan(B, N, D, fh, fw, 64, grids)
+    calib, keep = device_calib(calib_np, axes, gpu)
+    ws_static = plan.new_workspace(gpu, private_scratch=True)
+    kept = None
+    with torch.no_grad():
+        for frame in range(3):
+            depth, feat, hidx = syn.lift_inputs(440 + 5 * frame, B, N, D, fh, fw, 64, 65)
+            height = T(syn.height_probs_from_index(hidx, 65), gpu)
+            ws_full = plan.new_workspace(gpu, private_scratch=True)
+            ws_full.state.zero_()
+            if frame == 0:
+                ws_static.state.zero_()      # (alignment gaps of the block are never written: make them comparable)
+            a = mghs_op.mghs_lift_pool(plan, calib, height, cfg['height_range'], cfg['mask_range'], T(depth, gpu), T(feat, gpu),
+                                       ws_static, static=frame > 0)
+            b = mghs_op.mghs_lift_pool(plan, calib, height, cfg['height_range'], cfg['mask_range'], T(depth, gpu), T(feat, gpu), ws_full)
+            assert torch.equal(mghs_op.debug_keys(plan, ws_static), mghs_op.debug_keys(plan, ws_full)), frame
+            assert torch.equal(ws_static.state, ws_full.state), frame
+            for k, (x, y) in enumerate(zip(a, b)):
+                assert torch.allclose(x, y, atol=2e-4, rtol=1e-5), (frame, k, (x - y).abs().max().item())
+                assert int((x != 0).sum()) == int((y != 0).sum())
+            k_now, _ = mghs_op.stats(plan, ws_static)
+            if frame == 0:
+                kept = k_now
+                assert kept[0] > 2000000
+            else:
+                assert k_now[0] == kept[0] and k_now[1:] != kept[1:]
 
 
 def test_static_lift_with_unaligned_grid0_counters_equals_a_full_lift(gpu):

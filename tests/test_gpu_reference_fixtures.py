@@ -295,6 +295,47 @@ def test_mghs_depth_view_transform_dhdl_size_b2_vs_reference(gpu):
         assert abs(a.double().sum().item() - s[0]) < 2e-6 * s[1] + 1e-3, name
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_mghs_depth_view_transform_dhdl_size_b2_half_outputs_vs_reference(gpu, dtype):
+    """Golden G15 once more through the configuration BASELINE configs[3] / [4] actually run: MGHS_Depth.view_transform under
+    torch.autocast (bf16 there; fp16 too) with DEFAULT flags -- 32-row maps take the column form of the grid-0 sums and the writer
+    emits half tensors (round 4 pinned that combination only against its own float32 twin in deterministic mode, which switches
+    the column form off).  Sampled voxels against the reference's float32 values at half-precision tolerance, the sums, the
+    non-zero counts exactly (a pooled value is a sum of products >= 1e-5: nothing underflows in fp16), sampled gradients."""
+    from dhd_amd import MGHS_Depth
+    g = golden('g15_mghs_depth_dhdl_b2')
+    cfg = syn.dhd_s_config()
+    cfg['grid_config'] = dict(cfg['grid_config'], depth=[1.0, 45.0, 0.5])
+    cfg['input_size'] = (512, 1408)
+    cfg['collapse_z'] = False
+    _, s_in, s_w = (int(v) for v in g['seeds'])
+    B, N, fh, fw = 2, 6, 32, 88
+    depth, feat, hidx = syn.lift_inputs(s_in, B, N, 88, fh, fw, 64, 65)
+    hn = dict(use_dcn=False, use_aspp=False)
+    m = MGHS_Depth(**dict(cfg, heightnet_cfg=hn, depthnet_cfg=hn)).to(gpu)
+    assert m.amp_outputs
+    inject_reference_matrices(m, g, gpu)
+    calib = [T(a, gpu) for a in golden_calib(g)]
+    x = torch.zeros(B, N, 1, fh, fw, device=gpu)
+    dt, ft = T(depth, gpu).requires_grad_(), T(feat, gpu).requires_grad_()
+    with torch.autocast('cuda', dtype=dtype):
+        bev, bev_w_z, _, _ = m.view_transform([x] + calib, dt, ft, T(syn.height_probs_from_index(hidx, 65), gpu))
+    assert bev.dtype == dtype and bev_w_z.dtype == dtype
+    assert bev.shape == (B, 64, 1, 200, 200) and bev_w_z.shape == (B, 64, 16, 200, 200) and bev_w_z.is_contiguous()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11      # half an ulp, relative
+    ((bev.float() * T(syn.hash_signed(s_w, tuple(bev.shape)), gpu)).sum()
+     + (bev_w_z.float() * T(syn.hash_signed(s_w + 1, tuple(bev_w_z.shape)), gpu)).sum()).backward()
+    for k, o in enumerate((bev, bev_w_z)):
+        o = o.detach().float().cpu().numpy()
+        np.testing.assert_allclose(o.reshape(-1)[g[f'out_pos{k}']], g[f'out_val{k}'], atol=1e-4, rtol=1.01 * eps)
+        s = g[f'out_sum{k}']
+        assert abs(o.astype(np.float64).sum() - s[0]) < eps * s[1] + 1e-3
+        assert int(np.count_nonzero(o)) == int(s[2])
+    # the loss weights above are float32, so the gradients arrive as float32 and only the forward was rounded: same bounds as G15
+    np.testing.assert_allclose(dt.grad.cpu().numpy().reshape(-1)[g['depth_grad_pos']], g['depth_grad_val'], atol=3e-4, rtol=1e-5)
+    np.testing.assert_allclose(ft.grad.cpu().numpy().reshape(-1)[g['feat_grad_pos']], g['feat_grad_val'], atol=6e-4, rtol=1e-5)
+
+
 def test_stereo_cost_volume_dhdl_size_vs_reference(gpu):
     """Golden G16 = the reference's DepthNet.calculate_cost_volumn (depthnet.py:307-361) at the DHD-L stereo size:
     12 views (B = 2 x 6 cameras), 128-channel stereo features on 128 x 352 maps (MGHS_Stereo's cv_frustum, downsample 4),
