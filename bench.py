@@ -30,11 +30,26 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# MIOpen's user find-db (dhd_amd/miopen_db/: built once by experiments/miopen_find_job.py -- an exhaustive FIND over the convolution
+# problems of the DHD-S step on an MI355X; this image ships no gfx950 find-db, so without it every convolution runs the solver a
+# heuristic picks).  Must be in the environment before MIOpen initialises; DHD_NO_MIOPEN_DB=1 leaves MIOpen on its defaults (A/B).
+# A scratch copy is used so that MIOpen's own write-backs never touch the tracked files.
+if 'MIOPEN_USER_DB_PATH' not in os.environ and not os.environ.get('DHD_NO_MIOPEN_DB'):
+    _src = os.path.join(ROOT, 'dhd_amd', 'miopen_db')
+    if os.path.isdir(_src) and any(f.endswith('.ufdb.txt') for f in os.listdir(_src)):
+        import shutil
+        import tempfile
+        _dst = os.path.join(tempfile.gettempdir(), 'dhd_amd_miopen_db_%d' % os.getuid())
+        os.makedirs(_dst, exist_ok=True)
+        for _f in os.listdir(_src):
+            if _f.endswith('.txt') and not os.path.exists(os.path.join(_dst, _f)):
+                shutil.copy(os.path.join(_src, _f), _dst)
+        os.environ['MIOPEN_USER_DB_PATH'] = _dst
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from dhd_amd import _lib, dist as ddist, mghs_op, synthetic as syn  # noqa: E402
 from dhd_amd.mix import channel_spatial_stage  # noqa: E402
@@ -755,6 +770,115 @@ def cpu_baseline(hp, max_batch, warmups=3, reps=5, budget_s=75.0):
                 by_batch={str(b): r for b, r in res.items()}, leg_seconds=time.perf_counter() - t_leg)
 
 
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA peak of MI355X (MI355X_MICROARCH.md: ~2.5 PF dense, 2 495 TF measured)
+
+
+def e2e_module_utilisation(job, reps=4):
+    """Where the dense 98 % of BASELINE.json's metric goes: every top-level module of the detector run ALONE,
+    forward + backward, on the inputs it receives in a real step (captured by hooks in one eager forward), under the job's
+    autocast dtype.  Per module: analytic FLOPs of its convolutions / linear layers (2 x MACs, counted by hooks from the actual
+    shapes; x 3 for forward + data gradient + weight gradient), the time of forward + backward by HIP events, achieved TFLOP/s
+    and the fraction of the dense half-precision MFMA peak.  The HIP nodes (img_view_transformer = MGHS + depth_net /
+    HeightNet, mix = SFA) carry their dense sub-layers' FLOPs only; their pooling / blending work is HBM-bound by design."""
+    import torch.nn as nn
+    model = job.model
+    tops = [(n, m) for n, m in model.named_children() if sum(p.numel() for p in m.parameters()) > 0 or n in ('mix',)]
+    captured = {}
+    hooks = []
+
+    def det(x):
+        if torch.is_tensor(x):
+            return x.detach()
+        if isinstance(x, (list, tuple)):
+            return type(x)(det(v) for v in x)
+        return x
+
+    for name, m in tops:
+        hooks.append(m.register_forward_pre_hook(lambda mod, args, kwargs, name=name: captured.setdefault(name, (det(args), det(kwargs))), with_kwargs=True))
+    with torch.autocast('cuda', dtype=job.amp, enabled=job.amp is not None):
+        model(return_loss=True, **job.kw)
+    for h in hooks:
+        h.remove()
+    flops = {}
+
+    def count(mod, args, out, owner):
+        x = args[0]
+        if isinstance(mod, (nn.Conv2d, nn.Conv3d)):
+            macs = out.numel() * (mod.in_channels // mod.groups) * int(np.prod(mod.kernel_size))
+        elif isinstance(mod, (nn.ConvTranspose2d, nn.ConvTranspose3d)):
+            macs = x.numel() * (mod.out_channels // mod.groups) * int(np.prod(mod.kernel_size))
+        else:
+            macs = out.numel() * mod.in_features
+        flops[owner] = flops.get(owner, 0) + 2 * macs
+
+    def leaves(x):
+        if torch.is_tensor(x):
+            return [x] if x.is_floating_point() else []
+        if isinstance(x, (list, tuple)):
+            return [t for v in x for t in leaves(v)]
+        if isinstance(x, dict):
+            return [t for v in x.values() for t in leaves(v)]
+        return []
+
+    def with_grad(x):
+        if torch.is_tensor(x):
+            return x.clone().requires_grad_() if x.is_floating_point() and x.numel() > 4096 else x
+        if isinstance(x, (list, tuple)):
+            return type(x)(with_grad(v) for v in x)
+        return x
+
+    rec, total_ms, total_flop = {}, 0.0, 0.0
+    for name, m in tops:
+        if name not in captured:
+            continue
+        args, kwargs = captured[name]
+        fh = [mm.register_forward_hook(lambda mod, a_, o_, owner=name: count(mod, a_, o_, owner))
+              for mm in m.modules() if isinstance(mm, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d, nn.ConvTranspose3d, nn.Linear))]
+        grads = None
+        times = []
+        try:
+            for it in range(reps + 2):
+                ins = with_grad(args)
+                for p_ in m.parameters():
+                    p_.grad = None
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                with torch.autocast('cuda', dtype=job.amp, enabled=job.amp is not None):
+                    out = m(*ins, **kwargs)
+                outs = [o for o in leaves(out) if o.requires_grad]
+                if grads is None:
+                    grads = [torch.ones_like(o) for o in outs]
+                if outs:
+                    torch.autograd.backward(outs, grads)
+                e1.record()
+                if it == 0:
+                    for h in fh:
+                        h.remove()
+                if it >= 2:
+                    times.append((e0, e1))
+                del out, outs, ins
+            torch.cuda.synchronize()
+            ms = float(np.median([a_.elapsed_time(b_) for a_, b_ in times]))
+        except Exception as exc:  # noqa: BLE001 -- a module that cannot run alone is reported, not fatal
+            for h in fh:
+                h.remove()
+            rec[name] = dict(error=f'{type(exc).__name__}: {exc}'[:160])
+            continue
+        f3 = 3.0 * flops.get(name, 0)
+        rec[name] = dict(gflop_fwd_bwd=round(f3 / 1e9, 1), ms_fwd_bwd=round(ms, 3), tflops=round(f3 / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
+                         frac_of_mfma_peak=round(f3 / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if ms > 0 else None)
+        total_ms += ms
+        total_flop += f3
+        for p_ in m.parameters():
+            p_.grad = None
+    del captured
+    torch.cuda.empty_cache()
+    return dict(modules=rec, sum_ms=round(total_ms, 2), sum_gflop=round(total_flop / 1e9, 1), peak_tflops=MFMA_PEAK_TFLOPS,
+                note='each top-level module alone, forward + backward on the inputs of a real step, eager, HIP events; FLOPs = 3 x 2 x MACs '
+                     'of its Conv / ConvTranspose / Linear layers from the actual shapes; peak = dense fp16 MFMA (2.5 PF); the kernel-category '
+                     'shares (layout transposes, casts, fp32 kernels) of the same step: profiles/r5/e2e_dhds_fp16_kernel_categories.txt')
+
+
 def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
     """north_star's target number, observed by the driver inside the default line: the whole DHD-S detector
     (forward_train + backward + grad clip + AdamW + weight EMA) in fp32 and under fp16 autocast, B samples per GPU,
@@ -826,6 +950,14 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
             rec['allreduce_bytes'] = 4 * job.n_params
             rec['bucket_mb'] = a.bucket_mb
             rec['static_graph'] = bool(a.ddp_static_graph)
+        if tag == 'fp16' and world == 1:
+            try:
+                util = e2e_module_utilisation(job)
+                util['whole_step_tflops'] = round(util['sum_gflop'] / rec['ms_per_step'], 1)          # GFLOP / ms = TFLOP/s
+                util['whole_step_frac_of_mfma_peak'] = round(util['sum_gflop'] / rec['ms_per_step'] / MFMA_PEAK_TFLOPS, 4)
+                rec['mfma_utilisation'] = util
+            except Exception as exc:  # noqa: BLE001
+                rec['mfma_utilisation'] = dict(error=f'{type(exc).__name__}: {exc}'[:300])
         out[tag] = rec
         del job
         torch.cuda.empty_cache()

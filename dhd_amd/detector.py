@@ -219,6 +219,21 @@ class CustomResNet(nn.Module):
         return feats
 
 
+class Upsample(nn.Upsample):
+    """nn.Upsample that stays in the autocast dtype.  torch.autocast runs upsample_bilinear2d in float32 (it is on autocast's
+    float32 list): a half input comes back as a float32 tensor four / sixteen times its size, the `cat` behind it promotes its
+    other operand, and the convolution that follows casts everything back to half -- 3 % of the DHD-S fp16 step in
+    `upsample_bilinear2d_out_frame<float>` plus the casts (profiles/r4/e2e_dhds_fp16_steady_state.txt).  The half kernel
+    interpolates in float32 registers and rounds once on the way out, which is what the consumer's cast of the float32 result
+    produces up to one unit in the last place (bf16: identical; tests/test_detector.py)."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and torch.is_autocast_enabled():
+            with torch.autocast('cuda', enabled=False):
+                return super().forward(x)
+        return super().forward(x)
+
+
 @NECKS.register_module()
 class FPN_LSS(nn.Module):
     def __init__(self, in_channels, out_channels, scale_factor=4, input_feature_index=(0, 2), norm_cfg=None,
@@ -226,14 +241,14 @@ class FPN_LSS(nn.Module):
         super().__init__()
         self.input_feature_index = input_feature_index
         self.extra_upsample = extra_upsample is not None
-        self.up = nn.Upsample(scale_factor=scale_factor, mode='bilinear', align_corners=True)
+        self.up = Upsample(scale_factor=scale_factor, mode='bilinear', align_corners=True)
         f = 2 if self.extra_upsample else 1
         self.conv = nn.Sequential(
             nn.Conv2d(in_channels, out_channels * f, 3, padding=1, bias=False), BatchNorm2d(out_channels * f), nn.ReLU(inplace=True),
             nn.Conv2d(out_channels * f, out_channels * f, 3, padding=1, bias=False), BatchNorm2d(out_channels * f), nn.ReLU(inplace=True))
         if self.extra_upsample:
             self.up2 = nn.Sequential(
-                nn.Upsample(scale_factor=extra_upsample, mode='bilinear', align_corners=True),
+                Upsample(scale_factor=extra_upsample, mode='bilinear', align_corners=True),
                 nn.Conv2d(out_channels * f, out_channels, 3, padding=1, bias=False), BatchNorm2d(out_channels), nn.ReLU(inplace=True),
                 nn.Conv2d(out_channels, out_channels, 1, padding=0))
         self.lateral = lateral is not None
@@ -272,7 +287,7 @@ class _Up(nn.Module):
     def __init__(self, cin, cout, bilinear):
         super().__init__()
         if bilinear:
-            self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+            self.up = Upsample(scale_factor=2, mode='bilinear', align_corners=True)
             self.conv = _DoubleConv(cin, cout, cin // 2)
         else:
             self.up = nn.ConvTranspose2d(cin, cin // 2, kernel_size=2, stride=2)

@@ -223,6 +223,42 @@ def test_hip_nodes_under_autocast(gpu, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_upsample_stays_in_the_autocast_dtype_and_feeds_identical_convolutions(gpu, dtype):
+    """detector.Upsample: under autocast a half input is interpolated by the half kernel (float32 arithmetic, one rounding)
+    instead of autocast's float32 upsample.  What the convolution behind it receives differs from the half cast of autocast's
+    float32 tensor by at most one unit in the last place of the half type (the two kernel instantiations order their float32
+    operations differently; bf16: measured identical), so FPN_LSS gives the same output and gradients up to that rounding."""
+    import copy
+    from dhd_amd.detector import FPN_LSS, Upsample
+    torch.manual_seed(3)
+    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    x = torch.randn(2, 24, 9, 13, device=gpu)
+    up = Upsample(scale_factor=4, mode='bilinear', align_corners=True)
+    with torch.autocast('cuda', dtype=dtype):
+        a = up(x.to(dtype))
+        b = torch.nn.Upsample(scale_factor=4, mode='bilinear', align_corners=True)(x.to(dtype))
+    assert a.dtype == dtype and b.dtype == torch.float32
+    assert ((a.float() - b).abs() <= ulp * b.abs().clamp_min(2.0 ** -14)).all()
+    assert up(x).dtype == torch.float32 and torch.equal(up(x), torch.nn.functional.interpolate(x, scale_factor=4, mode='bilinear', align_corners=True))
+    neck = FPN_LSS(in_channels=16 + 24, out_channels=8, scale_factor=4, input_feature_index=(0, 1), extra_upsample=2).to(gpu).train()
+    ref = copy.deepcopy(neck)
+    ref.up = torch.nn.Upsample(scale_factor=4, mode='bilinear', align_corners=True)
+    ref.up2[0] = torch.nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+    f0 = torch.randn(2, 16, 36, 52, device=gpu)
+    outs = []
+    for m in (neck, ref):
+        i0, i1 = f0.clone().requires_grad_(), x.clone().requires_grad_()
+        with torch.autocast('cuda', dtype=dtype):
+            y = m([i0 * 1.0, i1 * 1.0])
+        y.float().square().mean().backward()
+        outs.append((y.detach().float(), i0.grad, i1.grad))
+    tol = 16 * ulp
+    for u, v in zip(outs[0], outs[1]):
+        assert (u - v).abs().max().item() <= tol * max(1e-6, v.abs().max().item())
+
+
+@pytest.mark.gpu
 def test_stereo_detector_under_autocast_trains_the_shared_weights(gpu):
     """DHD_stereo runs the adjacent / reference frames first and under no_grad; autocast would cache their
     weight casts (no grad_fn) and hand them to the key frame.  Every module both passes share must still get
