@@ -219,6 +219,9 @@ class CustomResNet(nn.Module):
         return feats
 
 
+_PLAIN_UPSAMPLE = bool(__import__('os').environ.get('DHD_PLAIN_UPSAMPLE'))   # A/B switch: autocast's float32 upsample
+
+
 class Upsample(nn.Upsample):
     """nn.Upsample that stays in the autocast dtype.  torch.autocast runs upsample_bilinear2d in float32 (it is on autocast's
     float32 list): a half input comes back as a float32 tensor four / sixteen times its size, the `cat` behind it promotes its
@@ -228,7 +231,7 @@ class Upsample(nn.Upsample):
     produces up to one unit in the last place (bf16: identical; tests/test_detector.py)."""
 
     def forward(self, x):
-        if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and torch.is_autocast_enabled():
+        if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and torch.is_autocast_enabled() and not _PLAIN_UPSAMPLE:
             with torch.autocast('cuda', enabled=False):
                 return super().forward(x)
         return super().forward(x)

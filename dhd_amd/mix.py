@@ -312,7 +312,9 @@ class channel_spatial_stage(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     fused = True  # set False to force the generic path (library convolutions between the blend kernels)
-    half_storage = True   # a half x (autocast region): keep every tensor of the fused stage in that type (see _FusedStage.forward)
+    # a half x (autocast region): keep every tensor of the fused stage in that type (see _FusedStage.forward); DHD_SFA_HALF_STORAGE=0
+    # in the environment makes round 4's form (half edges, float32 inside) the default, for A/B runs
+    half_storage = __import__('os').environ.get('DHD_SFA_HALF_STORAGE', '1') != '0'
     gemm = None   # 'bf16x3' | 'bf16x6' | 'f32': precision of the fused stage's C x C GEMMs; None = default_gemm()
 
     def forward(self, x):
