@@ -350,8 +350,15 @@ class EndToEnd:
         self.B = batch
         self.graphed = None
         self.graph_error = None
-        # N > 1: the captured step would contain the RCCL all-reduces (capturable in principle); opt-in, see --ddp-graph
+        # N > 1: the captured step would contain the RCCL all-reduces (capturable in principle); opt-in, see --ddp-graph.  gloo's
+        # collectives are staged through the host by its own threads: a capture attempt invalidates the stream's capture and, on
+        # this runtime, leaves the context unusable for the eager fallback (profiles/r5/two_ranks: "operation failed due to a
+        # previous error during capture") -- so with a non-RCCL backend the capture is not attempted and the line says why
         self.want_graph = bool(graph) and (world == 1 or bool(ddp_graph))
+        if self.want_graph and world > 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() != 'nccl':
+            self.want_graph = False
+            self.graph_error = (f'not attempted: --ddp-graph needs RCCL (backend "nccl"); "{torch.distributed.get_backend()}" stages its '
+                                'collectives through the host and cannot be captured into a HIP graph')
 
     def capture(self):
         """After the eager warm-up: the whole step as one HIP graph (dhd_amd/graph.py); falls back to eager on failure."""
