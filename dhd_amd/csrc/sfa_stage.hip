@@ -529,77 +529,6 @@ __global__ __launch_bounds__(kEwBlock) void pair_sums_kernel(const float* __rest
 // fused blends
 // ------------------------------------------------------------------------------------------------
 
-// bn_stats_finalize_kernel's work for ONE channel, done at the start of every workgroup of the pass that consumes the result
-// (blend2_bn: the last BatchNorm of the forward has no GEMM behind it that would need a coefficient table, so its finalize launch
-// -- 8 us of latency chain on the stage's critical path -- is folded away).  Same per-thread row order, the same
-// double-precision tree over the 256 threads and the same formulas as the kernel: bit-identical statistics.  All workgroups of
-// a channel compute the same numbers; `writer` (one of them) stores mean / rstd / scale / shift and updates the running statistics.
-struct BnFinalizeJob {
-  const float* part;     // statistics rows [n][2][c] of the GEMM epilogues; nullptr: the coefficients are already in scsh
-  int n;
-  const float* shift;    // the convolution's bias (the rows are sums of y - bias)
-  const float* gamma;
-  const float* beta;
-  float* run_mean;
-  float* run_var;
-  float momentum, eps;
-  float* mean;
-  float* rstd;
-  float* scsh;
-  int nb, hw;
-  long long* batches_tracked;
-};
-__device__ __forceinline__ void bn_finalize_channel(const BnFinalizeJob& J, int ch, int c, bool writer, double (*sm)[2], float* sc_out,
-                                                    float* sh_out) {
-  const int t = threadIdx.x;
-  const float* __restrict__ part = J.part;
-  const size_t row = (size_t)2 * c;
-  float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
-  int i = t;
-  for (; i + kEwBlock < J.n; i += 2 * kEwBlock) {
-    a1 += part[(size_t)i * row + ch];
-    a2 += part[(size_t)i * row + c + ch];
-    b1 += part[(size_t)(i + kEwBlock) * row + ch];
-    b2 += part[(size_t)(i + kEwBlock) * row + c + ch];
-  }
-  if (i < J.n) {
-    a1 += part[(size_t)i * row + ch];
-    a2 += part[(size_t)i * row + c + ch];
-  }
-  sm[t][0] = (double)a1 + (double)b1;
-  sm[t][1] = (double)a2 + (double)b2;
-  __syncthreads();
-  for (int s = kEwBlock / 2; s > 0; s >>= 1) {
-    if (t < s) {
-      sm[t][0] += sm[t + s][0];
-      sm[t][1] += sm[t + s][1];
-    }
-    __syncthreads();
-  }
-  const double s1 = sm[0][0], s2 = sm[0][1];
-  const double cnt = (double)J.nb * (double)J.hw;
-  const double md = s1 / cnt;
-  double var = s2 / cnt - md * md;
-  if (var < 0.0) var = 0.0;
-  const double mu = (double)J.shift[ch] + md;
-  const float rs = (float)(1.0 / sqrt(var + (double)J.eps));
-  const float sc = J.gamma[ch] * rs, shf = J.beta[ch] - (float)mu * sc;
-  *sc_out = sc;
-  *sh_out = shf;
-  if (writer && t == 0) {
-    if (ch == 0 && J.batches_tracked) *J.batches_tracked += 1;
-    J.mean[ch] = (float)mu;
-    J.rstd[ch] = rs;
-    J.scsh[ch] = sc;
-    J.scsh[c + ch] = shf;
-    if (J.run_mean) {
-      const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-      J.run_mean[ch] = (float)((1.0 - (double)J.momentum) * (double)J.run_mean[ch] + (double)J.momentum * mu);
-      J.run_var[ch] = (float)((1.0 - (double)J.momentum) * (double)J.run_var[ch] + (double)J.momentum * unb);
-    }
-  }
-}
-
 // Four consecutive elements of the stage's edge tensors (out, gout, gx: dhd_sfa_weights.io_dtype) as float32: 16 bytes of
 // float32, 8 bytes of a half type (widened exactly / rounded to nearest even).
 template <class T> __device__ __forceinline__ f32x4 ld4(const T* base, size_t i4);
@@ -634,13 +563,9 @@ template <> __device__ __forceinline__ void st4<__bf16>(__bf16* base, size_t i4,
 template <class TO>
 __global__ __launch_bounds__(kEwBlock) void blend2_bn_kernel(const float* __restrict__ x, const float* __restrict__ a1,
                                                              const float* __restrict__ y2, const float* __restrict__ scsh,
-                                                             TO* __restrict__ out, int c, int hw, BnFinalizeJob fin) {
-  __shared__ double fin_sm[kEwBlock][2];
+                                                             TO* __restrict__ out, int c, int hw) {
   const int plane = blockIdx.y, b = plane / c, ch = plane % c;
-  float sc, sh;
-  if (fin.part != nullptr) bn_finalize_channel(fin, ch, c, b == 0 && blockIdx.x == 0, fin_sm, &sc, &sh);   // block-uniform
-  else { sc = scsh[ch]; sh = scsh[c + ch]; }
-  const float a = a1[plane], na = 1.0f - a;
+  const float a = a1[plane], na = 1.0f - a, sc = scsh[ch], sh = scsh[c + ch];
   const f32x4* b4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + ch) * hw);
   const f32x4* v4 = reinterpret_cast<const f32x4*>(x + ((size_t)b * 2 * c + c + ch) * hw);
   const f32x4* y4 = reinterpret_cast<const f32x4*>(y2 + (size_t)plane * hw);
@@ -1050,11 +975,8 @@ __global__ __launch_bounds__(kWgBlock, 1) void pw_wgrad3_kernel(const float* __r
 // gw[i] = sum over workers of partial[w][i].  A workgroup covers 64 consecutive elements x 4 worker phases: wave
 // p sums workers p, p+4, ... with 16 loads in flight per lane, the four phase sums meet in LDS (fixed order:
 // deterministic).  One thread per element with four loads in flight left the 64 MB of partials at 3 TB/s.
-// (blockIdx.y selects one of two (partial, gw) pairs: the backward reduces dW2 and dW1 in ONE launch at its end)
 __global__ __launch_bounds__(kEwBlock) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int n,
-                                                                int n_workers, const float* __restrict__ partial_b = nullptr,
-                                                                float* __restrict__ gw_b = nullptr) {
-  if (blockIdx.y == 1) { partial = partial_b; gw = gw_b; }
+                                                                int n_workers) {
   __shared__ float sm[kEwBlock];
   constexpr int kPhases = kEwBlock / DHD_WAVE;
   const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
@@ -1113,7 +1035,7 @@ SavedLayout saved_layout(int b, int c, int hw, int r) {
 }
 
 struct ScratchLayout {
-  size_t wp1, wp2, part, da1, da2, tab_g2, tab_g1, dpre2, dh, ds, mean_part, stat_part, g2, g1, du, wpart, wpart2, total;
+  size_t wp1, wp2, part, da1, da2, tab_g2, tab_g1, dpre2, dh, ds, mean_part, stat_part, g2, g1, du, wpart, total;
 };
 ScratchLayout scratch_layout(int b, int c, int hw, int r) {
   ScratchLayout L;
@@ -1133,7 +1055,6 @@ ScratchLayout scratch_layout(int b, int c, int hw, int r) {
   L.mean_part = take((size_t)b * 2 * c * kPlaneChunks);
   L.g2 = take(plane); L.g1 = take(plane); L.du = take(plane);
   L.wpart = take((size_t)kWgWorkers * cc);
-  L.wpart2 = take((size_t)kWgWorkers * cc);   // dW2's partial matrices wait here for the backward's single reduce launch
   L.total = o;
   return L;
 }
@@ -1429,7 +1350,7 @@ int launch_pw_gemm(const float* in0, const float* in1, size_t in_bstride, int in
 
 int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t a_bs, const float* b0, const float* b1,
                     const float* bcoef, size_t b_bs, bool b_relu, float* partial, float* gw, int b, int c, int hw,
-                    hipStream_t st, int* n_workers_out = nullptr) {
+                    hipStream_t st) {
   // (tried at C = 256 in the bf16x3 mode: 128 x 128 tiles, two workgroups per CU, operands read twice through L2: 233 / 189 us
   // against 166 / 138 us for one 256 x 256 tile per CU)
   const int ot = c == 128 ? 128 : 256;
@@ -1495,18 +1416,8 @@ int launch_pw_wgrad(const float* a0, const float* a1, const float* acoef, size_t
   }
 #undef DHD_WG
   DHD_LAUNCH_CHECK();
-  if (n_workers_out) *n_workers_out = workers;
-  if (gw == nullptr) return DHD_OK;      // the caller reduces the partial matrices later (launch_wgrad_reduce2)
   const int n = c * c;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dhd_cdiv(n, DHD_WAVE)), dim3(kEwBlock), 0, st, partial, gw, n, workers, nullptr, nullptr);
-  DHD_LAUNCH_CHECK();
-  return DHD_OK;
-}
-
-// the two weight gradients of a backward pass, reduced from their per-worker partial matrices in one launch
-int launch_wgrad_reduce2(const float* partial_a, float* gw_a, const float* partial_b, float* gw_b, int c, int workers, hipStream_t st) {
-  const int n = c * c;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dhd_cdiv(n, DHD_WAVE), 2), dim3(kEwBlock), 0, st, partial_a, gw_a, n, workers, partial_b, gw_b);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dhd_cdiv(n, DHD_WAVE)), dim3(kEwBlock), 0, st, partial, gw, n, workers);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
@@ -1652,14 +1563,8 @@ static int stage_forward_impl(const void* xv, const dhd_sfa_weights* w, void* ou
   }
   if (hi <= 1) return DHD_OK;
   float* tab_unused = sc + T.tab_g2;  // bn2 has no consumer GEMM in forward; table slot reused as a sink
-  // the last BatchNorm's statistics are finalized inside blend2_bn (BnFinalizeJob) when they come from this call's own GEMM
-  // epilogue rows; cross-rank statistics (sync) start from the all-reduced sums and keep the separate launch
-  BnFinalizeJob fin = {};
   if (w->training) {
-    if (fused_stats && sync == nullptr) {
-      fin = BnFinalizeJob{sc + T.stat_part, stat_rows, w->conv2_b, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2,
-                          sv + S.mean2, sv + S.rstd2, sv + S.scsh2, b, hw, reinterpret_cast<long long*>(w->bn2_batches)};
-    } else if (fused_stats) {  // the GEMM epilogue left per-(sample, wave tile) sums shifted by the bias
+    if (fused_stats) {  // the GEMM epilogue left per-(sample, wave tile) sums shifted by the bias
       hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, sc + T.stat_part, stat_rows, w->conv2_b, w->bn2_w,
                          w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, sv + S.mean2, sv + S.rstd2, sv + S.scsh2,
                          tab_unused, b, c, hw, nullptr, nullptr, sync, reinterpret_cast<long long*>(w->bn2_batches));
@@ -1674,11 +1579,11 @@ static int stage_forward_impl(const void* xv, const dhd_sfa_weights* w, void* ou
                        sv + S.mean2, sv + S.rstd2, sv + S.scsh2, tab_unused, b, c);
   }
   if (w->io_dtype == DHD_F16)
-    hipLaunchKernelGGL(blend2_bn_kernel<_Float16>, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, static_cast<_Float16*>(out), c, hw, fin);
+    hipLaunchKernelGGL(blend2_bn_kernel<_Float16>, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, static_cast<_Float16*>(out), c, hw);
   else if (w->io_dtype == DHD_BF16)
-    hipLaunchKernelGGL(blend2_bn_kernel<__bf16>, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, static_cast<__bf16*>(out), c, hw, fin);
+    hipLaunchKernelGGL(blend2_bn_kernel<__bf16>, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, static_cast<__bf16*>(out), c, hw);
   else
-    hipLaunchKernelGGL(blend2_bn_kernel<float>, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, static_cast<float*>(out), c, hw, fin);
+    hipLaunchKernelGGL(blend2_bn_kernel<float>, planes, dim3(kEwBlock), 0, st, x, sv + S.a1, sv + S.y2, sv + S.scsh2, static_cast<float*>(out), c, hw);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
@@ -1738,9 +1643,8 @@ static int stage_backward_impl(const void* xv, const dhd_sfa_weights* w, const v
                          reinterpret_cast<const double*>(sv + S.loc2), w->conv2_b);
     DHD_LAUNCH_CHECK();
     // dW2 = dy2 . z1^T
-    // (its per-worker partial matrices stay in wpart2 until the single reduce launch at the end of the backward)
-    rc = launch_pw_wgrad(sc + T.g2, sv + S.y2, sc + T.tab_g2, cs, sv + S.y1, nullptr, sv + S.tab1, cs, true, sc + T.wpart2,
-                         nullptr, b, c, hw, st);
+    rc = launch_pw_wgrad(sc + T.g2, sv + S.y2, sc + T.tab_g2, cs, sv + S.y1, nullptr, sv + S.tab1, cs, true, sc + T.wpart,
+                         grads->conv2_w, b, c, hw, st);
     if (rc != DHD_OK) return rc;
     // g1 = (W2^T dy2) * [z1 > 0]
     rc = launch_pw_gemm(sc + T.g2, sv + S.y2, cs, c, sc + T.tab_g2, false, sv + S.wp2t, nullptr, sv + S.y1, sv + S.scsh1,
@@ -1763,9 +1667,8 @@ static int stage_backward_impl(const void* xv, const dhd_sfa_weights* w, const v
                        reinterpret_cast<const double*>(sv + S.loc1), w->conv1_b);
   DHD_LAUNCH_CHECK();
   // dW1 = dy1 . u^T
-  int wg_workers = 0;
-  rc = launch_pw_wgrad(sc + T.g1, sv + S.y1, sc + T.tab_g1, cs, x, x + cs, sv + S.tab_a, 2 * cs, false, sc + T.wpart, nullptr,
-                       b, c, hw, st, &wg_workers);
+  rc = launch_pw_wgrad(sc + T.g1, sv + S.y1, sc + T.tab_g1, cs, x, x + cs, sv + S.tab_a, 2 * cs, false, sc + T.wpart, grads->conv1_w,
+                       b, c, hw, st);
   if (rc != DHD_OK) return rc;
   // du = W1^T dy1
   rc = launch_pw_gemm(sc + T.g1, sv + S.y1, cs, c, sc + T.tab_g1, false, sv + S.wp1t, nullptr, nullptr, nullptr, nullptr, nullptr, sc + T.du, 2, b, c,
@@ -1786,8 +1689,7 @@ static int stage_backward_impl(const void* xv, const dhd_sfa_weights* w, const v
   else DHD_GX(float);
 #undef DHD_GX
   DHD_LAUNCH_CHECK();
-  // dW2 and dW1 from their per-worker partial matrices: one launch (was one 64 MB reduce behind each weight-gradient GEMM)
-  return launch_wgrad_reduce2(sc + T.wpart2, grads->conv2_w, sc + T.wpart, grads->conv1_w, c, wg_workers, st);
+  return DHD_OK;
 }
 
 int dhd_sfa_stage_forward(const void* x, const dhd_sfa_weights* w, void* out, void* saved, void* scratch, int b, int c, int hw,

@@ -54,13 +54,9 @@ __global__ __launch_bounds__(kEwBlock) void plane_mean_pack_h_kernel(const TS* _
 template <class TS>
 __global__ __launch_bounds__(kEwBlock) void blend2_bn_h_kernel(const TS* __restrict__ x, const float* __restrict__ a1,
                                                                const TS* __restrict__ y2, const float* __restrict__ scsh,
-                                                               TS* __restrict__ out, int c, int hw, BnFinalizeJob fin) {
-  __shared__ double fin_sm[kEwBlock][2];
+                                                               TS* __restrict__ out, int c, int hw) {
   const int plane = blockIdx.y, b = plane / c, ch = plane % c;
-  float sc, sh;
-  if (fin.part != nullptr) bn_finalize_channel(fin, ch, c, b == 0 && blockIdx.x == 0, fin_sm, &sc, &sh);   // block-uniform
-  else { sc = scsh[ch]; sh = scsh[c + ch]; }
-  const float a = a1[plane], na = 1.0f - a;
+  const float a = a1[plane], na = 1.0f - a, sc = scsh[ch], sh = scsh[c + ch];
   const TS* xb = x + ((size_t)b * 2 * c + ch) * hw;
   const TS* xv = x + ((size_t)b * 2 * c + c + ch) * hw;
   const TS* yp = y2 + (size_t)plane * hw;
@@ -263,7 +259,7 @@ inline SavedLayoutH saved_layout_h(int b, int c, int hw, int r) {
   return L;
 }
 struct ScratchLayoutH {
-  size_t wp1, wp2, part, stat_part, da1, da2, tab_g2, tab_g1, dpre2, dh, ds, mean_part, g2, g1, du, wpart, wpart2, total;
+  size_t wp1, wp2, part, stat_part, da1, da2, tab_g2, tab_g1, dpre2, dh, ds, mean_part, g2, g1, du, wpart, total;
 };
 inline ScratchLayoutH scratch_layout_h(int b, int c, int hw, int r) {
   ScratchLayoutH L;
@@ -280,7 +276,6 @@ inline ScratchLayoutH scratch_layout_h(int b, int c, int hw, int r) {
   L.mean_part = f((size_t)b * 2 * c * kPlaneChunks);
   L.g2 = take(plane); L.g1 = take(plane); L.du = take(plane);
   L.wpart = f((size_t)kWgWorkers * c * c);
-  L.wpart2 = f((size_t)kWgWorkers * c * c);   // dW2's partial matrices until the backward's single reduce launch
   L.total = o;
   return L;
 }
@@ -362,9 +357,8 @@ int launch_pw_wgrad_h(const TS* a0, const TS* a1, const float* acoef, size_t a_b
   }
 #undef DHD_WGH
   DHD_LAUNCH_CHECK();
-  if (gw == nullptr) return DHD_OK;      // reduced later, together with the other weight gradient (launch_wgrad_reduce2)
   const int n = c * c;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dhd_cdiv(n, DHD_WAVE)), dim3(kEwBlock), 0, st, partial, gw, n, workers, nullptr, nullptr);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dhd_cdiv(n, DHD_WAVE)), dim3(kEwBlock), 0, st, partial, gw, n, workers);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
@@ -437,18 +431,14 @@ int stage_forward_half(const void* xv, const dhd_sfa_weights* w, void* outv, voi
   }
   if (hi <= 1) return DHD_OK;
   float* tab_unused = TF(T.tab_g2);   // bn2 has no consumer GEMM in the forward
-  BnFinalizeJob fin = {};             // this call's own statistics rows: finalized inside blend2_bn_h (see BnFinalizeJob)
-  if (training && sync == nullptr)
-    fin = BnFinalizeJob{TF(T.stat_part), stat_rows, w->conv2_b, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2,
-                        SF(S.mean2), SF(S.rstd2), SF(S.scsh2), b, hw, reinterpret_cast<long long*>(w->bn2_batches)};
-  else if (training)
+  if (training)
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c / 4), dim3(kEwBlock), 0, st, TF(T.stat_part), stat_rows, w->conv2_b, w->bn2_w,
                        w->bn2_b, w->bn2_mean, w->bn2_var, w->momentum2, w->eps2, SF(S.mean2), SF(S.rstd2), SF(S.scsh2), tab_unused, b, c, hw,
                        nullptr, nullptr, sync, reinterpret_cast<long long*>(w->bn2_batches));
   else
     hipLaunchKernelGGL(bn_eval_coef_kernel, per_ch, dim3(kEwBlock), 0, st, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, w->eps2, SF(S.mean2),
                        SF(S.rstd2), SF(S.scsh2), tab_unused, b, c);
-  hipLaunchKernelGGL(blend2_bn_h_kernel<TS>, planes, dim3(kEwBlock), 0, st, x, SF(S.a1), y2, SF(S.scsh2), out, c, hw, fin);
+  hipLaunchKernelGGL(blend2_bn_h_kernel<TS>, planes, dim3(kEwBlock), 0, st, x, SF(S.a1), y2, SF(S.scsh2), out, c, hw);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
@@ -495,7 +485,7 @@ int stage_backward_half(const void* xv, const dhd_sfa_weights* w, const void* sa
                          reinterpret_cast<const double*>(sv + S.loc2), w->conv2_b);
     DHD_LAUNCH_CHECK();
     // dW2 = dy2 . z1^T
-    rc = launch_pw_wgrad_h<TS>(g2, y2, TF(T.tab_g2), cs, y1, nullptr, SF(S.tab1), cs, true, TF(T.wpart2), nullptr, b, c, hw, st);
+    rc = launch_pw_wgrad_h<TS>(g2, y2, TF(T.tab_g2), cs, y1, nullptr, SF(S.tab1), cs, true, TF(T.wpart), grads->conv2_w, b, c, hw, st);
     if (rc != DHD_OK) return rc;
     // g1 = (W2^T dy2) * [z1 > 0]
     rc = launch_pw_gemm_cuh<TS>(g2, y2, cs, c, TF(T.tab_g2), false, sv + S.wp2t, nullptr, reinterpret_cast<unsigned*>(sv + S.mask), nullptr,
@@ -517,7 +507,7 @@ int stage_backward_half(const void* xv, const dhd_sfa_weights* w, const void* sa
                        reinterpret_cast<const double*>(sv + S.loc1), w->conv1_b);
   DHD_LAUNCH_CHECK();
   // dW1 = dy1 . u^T
-  rc = launch_pw_wgrad_h<TS>(g1, y1, TF(T.tab_g1), cs, x, x + cs, SF(S.tab_a), 2 * cs, false, TF(T.wpart), nullptr, b, c, hw, st);
+  rc = launch_pw_wgrad_h<TS>(g1, y1, TF(T.tab_g1), cs, x, x + cs, SF(S.tab_a), 2 * cs, false, TF(T.wpart), grads->conv1_w, b, c, hw, st);
   if (rc != DHD_OK) return rc;
   // du = W1^T dy1
   rc = launch_pw_gemm_cuh<TS>(g1, y1, cs, c, TF(T.tab_g1), false, sv + S.wp1t, nullptr, nullptr, nullptr, du, 2, b, c, hw, st, nullptr);
@@ -532,5 +522,5 @@ int stage_backward_half(const void* xv, const dhd_sfa_weights* w, const void* sa
   hipLaunchKernelGGL(stage_gx_h_kernel<TS>, planes_fc, dim3(kEwBlock), 0, st, SF(S.a1), y2, SF(S.scsh2), gout, du, TF(T.ds), gx, c, hw, fc_rows,
                      fcj);
   DHD_LAUNCH_CHECK();
-  return launch_wgrad_reduce2(TF(T.wpart2), grads->conv2_w, TF(T.wpart), grads->conv1_w, c, kWgWorkers, st);
+  return DHD_OK;
 }
