@@ -68,8 +68,16 @@ class BatchNorm2d(nn.BatchNorm2d):
     1M,256,16M)."""
 
     use_hip = True
-    _DEFAULT_ROUTING = (1 << 24, 128, 1 << 26)
+    # (round 5: re-measured UNDER THE HIP GRAPH, where the operator's host time does not count -- experiments/e2e_bn_routing_ab.sh,
+    # DHD-S fp16 step, two alternating rounds: 16M,128,64M 67.85 / 67.69 ms, 4M,128,32M 67.06 / 67.06, 1M,256,16M 67.31 / 67.35,
+    # 256k,4096,4M 68.55 / 68.57, everything 68.49 / 68.50)
+    _DEFAULT_ROUTING = (1 << 22, 128, 1 << 25)
     _routing = None
+    # `num_batches_tracked += 1` is one 5 us launch per layer and step (191 of them in a DHD-S step: 1.3 % of it).  With a fixed
+    # momentum the counter is pure bookkeeping, so a caller that owns the step (detector.DHD) may set defer_counter on its layers:
+    # forward then only counts its calls on the host and `flush_counters(model)` adds them in ONE multi-tensor launch per step.
+    defer_counter = False
+    _pending = 0
 
     @classmethod
     def routing(cls):
@@ -103,15 +111,44 @@ class BatchNorm2d(nn.BatchNorm2d):
         return bool(_lib.load().dhd_bn_supported(_DTYPES[x.dtype], n, c, x[0, 0].numel()))
 
     def forward(self, x):
+        defer = (self.defer_counter and self.training and self.track_running_stats and self.momentum is not None
+                 and self.num_batches_tracked is not None)
         if not self._hip_ok(x):
+            if defer:   # nn.BatchNorm2d.forward in training mode with running statistics, minus the counter launch
+                self._check_input_dim(x)
+                self._pending += 1
+                return nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
             return super().forward(x)
         self._check_input_dim(x)
         factor = 0.0 if self.momentum is None else self.momentum
         rm = rv = None
         if self.track_running_stats:
             rm, rv = self.running_mean, self.running_var
-            if self.num_batches_tracked is not None:
+            if defer:
+                self._pending += 1
+            elif self.num_batches_tracked is not None:
                 self.num_batches_tracked.add_(1)
                 if self.momentum is None:
                     factor = 1.0 / float(self.num_batches_tracked)
         return _BNTrain.apply(x.contiguous(), self.weight, self.bias, rm, rv, float(factor), float(self.eps))
+
+
+def defer_counters(model, on=True):
+    """Switch the per-layer `num_batches_tracked` launches of every dhd_amd BatchNorm2d under `model` to host-side counting
+    (see BatchNorm2d.defer_counter); the owner of the step then calls flush_counters(model) once per step."""
+    for m in model.modules():
+        if isinstance(m, BatchNorm2d):
+            m.defer_counter = bool(on)
+
+
+def flush_counters(model):
+    """num_batches_tracked += (calls since the last flush) for every deferring layer, in one multi-tensor launch.  Inside a HIP
+    graph the captured increments are those of the captured step -- the same every replay."""
+    ts, ns = [], []
+    for m in model.modules():
+        if isinstance(m, BatchNorm2d) and m._pending:
+            ts.append(m.num_batches_tracked)
+            ns.append(m._pending)
+            m._pending = 0
+    if ts:
+        torch._foreach_add_(ts, ns)

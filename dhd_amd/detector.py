@@ -532,6 +532,9 @@ class DHD(nn.Module):
         self.img_voxel_neck2 = build_neck(img_voxel_encoder2_neck)
         self.mix = build_neck(mix)
         self.upsample = upsample
+        # one launch per step for all `num_batches_tracked` counters instead of one per layer (batchnorm.BatchNorm2d.defer_counter)
+        from .batchnorm import defer_counters
+        defer_counters(self)
 
     @property
     def with_img_neck(self):
@@ -612,7 +615,13 @@ class DHD(nn.Module):
         return self.occ_head.get_occ(outs, img_metas)
 
     def forward(self, return_loss=True, **kwargs):
-        return self.forward_train(**kwargs) if return_loss else self.simple_test(**kwargs)
+        if not return_loss:
+            return self.simple_test(**kwargs)
+        losses = self.forward_train(**kwargs)
+        if self.training:
+            from .batchnorm import flush_counters
+            flush_counters(self)
+        return losses
 
 
 @DETECTORS.register_module()

@@ -338,6 +338,37 @@ def test_batchnorm2d_subclass_is_transparent_off_the_gpu():
     assert isinstance(conv[0], torch.nn.SyncBatchNorm)
 
 
+def test_batchnorm_deferred_counters_match_the_per_layer_updates():
+    """batchnorm.defer_counters / flush_counters (the detector's one-launch-per-step update of every `num_batches_tracked`): outputs,
+    running statistics and the counters after a flush equal those of plain nn.BatchNorm2d behaviour -- also for a layer that is
+    called twice per step -- and eval mode / momentum=None keep the parent's path."""
+    import copy
+    from dhd_amd.batchnorm import BatchNorm2d, defer_counters, flush_counters
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), BatchNorm2d(8), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 1), BatchNorm2d(8))
+    ref = copy.deepcopy(net)
+    defer_counters(net)
+    x = torch.randn(2, 3, 6, 6)
+    for step in range(3):
+        a = net(x) + net[4](net[3](net(x).relu()))       # net[4] runs three times per step, net[1] twice
+        b = ref(x) + ref[4](ref[3](ref(x).relu()))
+        assert torch.equal(a, b)
+        assert int(net[1].num_batches_tracked) == 2 * step and int(ref[1].num_batches_tracked) == 2 * (step + 1)   # not yet flushed
+        flush_counters(net)
+        for m, r in ((net[1], ref[1]), (net[4], ref[4])):
+            assert int(m.num_batches_tracked) == int(r.num_batches_tracked)
+            assert torch.equal(m.running_mean, r.running_mean) and torch.equal(m.running_var, r.running_var)
+    assert int(net[4].num_batches_tracked) == 9
+    net.eval(); ref.eval()
+    assert torch.equal(net(x), ref(x))
+    flush_counters(net)
+    assert int(net[4].num_batches_tracked) == 9
+    cum = BatchNorm2d(4, momentum=None).train()           # cumulative average: the counter is an input, never deferred
+    defer_counters(cum)
+    cum(torch.randn(2, 4, 3, 3))
+    assert int(cum.num_batches_tracked) == 1 and cum._pending == 0
+
+
 def _g13_case(name, device='cpu'):
     """Build the mirrored HeightNet / DepthNet with golden G13's hashed parameters and inputs."""
     from dhd_amd.depthnet import DepthNet, HeightNet
