@@ -27,6 +27,20 @@ cp $(find $OUT/pw -name 'pw_counter_collection.csv') $OUT/pmc_write_size.csv
 rm -rf $OUT/hp $OUT/mo $OUT/pf $OUT/pw
 fi
 cd /tmp
+if [[ " $WHAT " == *" hotpath "* ]]; then
+# round 5: the half-storage SFA stage alone (its kernels have their own names: no clash with the float32 hot path)
+H="python $R/experiments/sfa_half.py 4 6 fp16 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hs -o hs -- python $R/experiments/sfa_half.py 4 20 fp16 1 > $OUT/sfa_half_fp16.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hb -o hb -- python $R/experiments/sfa_half.py 4 20 bf16 1 > $OUT/sfa_half_bf16.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/hf -o hf -- $H > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/hw -o hw -- $H > /dev/null 2>&1
+cp $(find $OUT/hs -name 'hs_kernel_stats.csv') $OUT/sfa_half_fp16_kernel_stats.csv
+cp $(find $OUT/hb -name 'hb_kernel_stats.csv') $OUT/sfa_half_bf16_kernel_stats.csv
+head -1 $(find $OUT/hf -name 'hf_counter_collection.csv') > $OUT/pmc_sfa_half.csv
+grep -h "_h_kernel\|cuh_kernel\|wgrad_h\|wgrad_reduce\|fc_forward\|fc_backward\|bn_stats_finalize" $(find $OUT/hf -name 'hf_counter_collection.csv') $(find $OUT/hw -name 'hw_counter_collection.csv') >> $OUT/pmc_sfa_half.csv
+rm -rf $OUT/hs $OUT/hb $OUT/hf $OUT/hw
+fi
+cd /tmp
 if [[ " $WHAT " == *" ema "* ]]; then
 # counters only for the EMA kernel: the detector's construction launches ~30 k kernels, each of which
 # would otherwise be serialised for counter collection (35 min)
@@ -39,8 +53,8 @@ head -1 $(find $OUT/ef -name 'ef_counter_collection.csv') > $OUT/pmc_ema.csv
 grep -h ema_update_kernel $(find $OUT/ef -name 'ef_counter_collection.csv') $(find $OUT/ew -name 'ew_counter_collection.csv') >> $OUT/pmc_ema.csv
 rm -rf $OUT/es $OUT/ef $OUT/ew
 fi
-PREV=${PREV_PROFILES:-$R/profiles/r3}
-ROUND=${ROUND:-r4}
+PREV=${PREV_PROFILES:-$R/profiles/r4}
+ROUND=${ROUND:-r5}
 [ -f $OUT/pmc_fetch_size.csv ] || cp $PREV/pmc_fetch_size.csv $PREV/pmc_write_size.csv $OUT/
 [ -f $OUT/pmc_ema.csv ] || cp $PREV/pmc_ema.csv $OUT/ 2>/dev/null || head -1 $OUT/pmc_fetch_size.csv > $OUT/pmc_ema.csv
 cd $R
@@ -71,6 +85,22 @@ json.dump(dict(samples_per_gpu=4, source_sha256=kernel_source_sha256(),
                correction='bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of a wide coalesced read)',
                kernels=ks), open(out + '/pmc_summary.json', 'w'), indent=1)
 print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in ks.items()}, indent=0)[:3000])
+if os.path.exists(out + '/pmc_sfa_half.csv'):
+    import subprocess
+    def demangle(n):
+        return subprocess.run(['c++filt', n], capture_output=True, text=True).stdout.strip() if n.startswith('_Z') else n
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(out + '/pmc_sfa_half.csv')):
+        acc[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+    hs = {}
+    for k, d in acc.items():
+        fz = sum(d.get('FETCH_SIZE', [0])) / max(1, len(d.get('FETCH_SIZE', [0])))
+        wz = sum(d.get('WRITE_SIZE', [0])) / max(1, len(d.get('WRITE_SIZE', [0])))
+        hs[demangle(k)[:160]] = dict(FETCH_SIZE_KB=fz, WRITE_SIZE_KB=wz, hbm_bytes_per_launch=int((2 * fz + wz) * 1024))
+    json.dump(dict(samples_per_gpu=4, dtype='float16', source_sha256=kernel_source_sha256(),
+                   command='rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python experiments/sfa_half.py 4 6 fp16 1 (two separate passes)',
+                   correction='bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024', kernels=hs), open(out + '/pmc_sfa_half_summary.json', 'w'), indent=1)
+    print(json.dumps({k[:70]: v['hbm_bytes_per_launch'] for k, v in hs.items()}, indent=0)[:3000])
 PY
 # the plain bench line last, with the fresh PMC summary in place (bench.py reports `traffic` only for a matching source hash)
 if [[ " $WHAT " == *" hotpath "* ]]; then
