@@ -66,6 +66,23 @@ struct Layout {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Index of frustum point (camera bn, depth bin d, row h, column w) in the scratch arrays `key` and `rnk`.  Since round 5
+// COLUMN-major inside a depth plane (h fastest): the counting kernel's lanes run along h (a wave holds whole pixel columns so that
+// a run of equal keys shares one atomic), and with the natural order (w fastest, the reference's `ranks_depth`) each of its four
+// stores per point touched 64 lines per wave -- 40 of mghs_geom_count's 70 us at the DHD-L geometry together with the returning
+// atomics (round 4's ablation).  mghs_scatter_planes and mghs_col_sums read the arrays in the same order (coalesced too).  `p_slot`
+// (state, read by mghs_pixel_bwd next to depth / depth_grad) stays in the natural order pt_natural: the scatter turns a depth plane
+// through LDS.  (Measured with p_slot column-major as well: the pixel kernel loses 9 of the 14 us the lift gains -- its waves walk
+// the pixels w-fastest and then no longer share p_slot lines.)  -DDHD_KEYS_ROWMAJOR: the round-4 order, for A/B builds.
+__host__ __device__ inline int pt_natural(const Layout& L, int bn, int d, int h, int w) { return bn * L.dhw + (d * L.fh + h) * L.fw + w; }
+__host__ __device__ inline int pt_index(const Layout& L, int bn, int d, int h, int w) {
+#ifdef DHD_KEYS_ROWMAJOR
+  return pt_natural(L, bn, d, h, w);
+#else
+  return bn * L.dhw + (d * L.fw + w) * L.fh + h;
+#endif
+}
+
 // Fills *L from the description; with `ws` also carves the device pointers and checks the sizes.  state_bytes /
 // scratch_bytes (optional) receive the sizes needed.
 inline int make_layout(const dhd_mghs_desc* d, const dhd_mghs_workspace* ws, Layout* L, size_t* state_bytes = nullptr,

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void mghs_col_sums(Layout L, const float* _
   for (int k = 0; k < kDepthChunk; ++k) {
     const int d = min(d0 + k, L.D - 1);
     const int p = ((bn * L.D + d) * FH + hl) * L.fw + w;
-    key[k] = d0 + k < L.D ? L.key[p] : -1;
+    key[k] = d0 + k < L.D ? L.key[pt_index(L, bn, d, hl, w)] : -1;   // (column-major: the lanes of a column read adjacent words)
     dv[k] = depth[p];
   }
 #pragma unroll

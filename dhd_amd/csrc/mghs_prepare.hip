@@ -241,8 +241,7 @@ __global__ __launch_bounds__(kBlock) void mghs_geom_count(Layout L, dhd_calib ca
   const int w = in_range ? col % L.fw : 0, d = in_range ? col / L.fw : 0, h = in_range ? hh : 0;
   float e[3];
   frustum_to_ego(cam, cal.frustum_u[w], cal.frustum_v[h], cal.frustum_d[d], e);
-  const int i = (d * L.fh + h) * L.fw + w;
-  const int pid = bn * L.dhw + i;
+  const int pid = pt_index(L, bn, d, h, w);   // where this point's key / rank go (column-major: the lanes of a column are adjacent)
   int k0 = -1, k1 = -1;
   if (in_range) {
     if (!BAND_ONLY) {
@@ -399,6 +398,8 @@ __global__ __launch_bounds__(kBlock) void mghs_scan(Layout L) {
 }
 
 // J0 = 1: only the band grid's entries (static rig: grid 0's part of the sorted lists is already in place)
+// Element-wise form: one thread per point in the natural order (key / rnk in the natural order too: -DDHD_KEYS_ROWMAJOR, and depth
+// planes too large for the LDS turn of mghs_scatter_planes).
 template <int J0>
 __global__ __launch_bounds__(kBlock) void mghs_scatter(Layout L, int blocks_per_bn) {
   // workgroups go round-robin over the XCDs: XCD x takes the x-th eighth of the points, so that the 4-byte
@@ -411,16 +412,50 @@ __global__ __launch_bounds__(kBlock) void mghs_scatter(Layout L, int blocks_per_
   if (i >= L.dhw) return;
   const int pid = bn * L.dhw + i;
   const int pix = bn * L.hw + (i % L.hw);
+  const int d = i / L.hw, r = i - d * L.hw, h = r / L.fw, w = r - h * L.fw;
+  const int cix = pt_index(L, bn, d, h, w);
 #pragma unroll
   for (int j = J0; j < 2; ++j) {
-    int k = L.key[j * L.P + pid];
+    int k = L.key[j * L.P + cix];
     int slot = -1;
     if (k >= 0) {
       slot = L.nzoff[k];
       if (j == 1 || !L.columns)   // column form: nobody reads grid 0's sorted entries (forward by column, backward by p_slot)
-        L.s_ent[L.offset[k] + L.rnk[j * L.P + pid]] = make_int4(pid, pix, slot, 0);
+        L.s_ent[L.offset[k] + L.rnk[j * L.P + cix]] = make_int4(pid, pix, slot, 0);
     }
     L.p_slot[j * L.P + pid] = slot;
+  }
+}
+
+// The same work per (camera, depth bin) PLANE: the plane's keys / ranks are read in their column-major order (coalesced), the
+// entries scattered, the slots turned through LDS and written to p_slot in the natural order (coalesced).  Dynamic LDS: 2 hw ints.
+template <int J0>
+__global__ __launch_bounds__(kBlock) void mghs_scatter_planes(Layout L) {
+  extern __shared__ int sl[];   // [class 2][h * fw + w]
+  const int per_xcd = gridDim.x >> 3;
+  const int plane = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // XCD x takes the x-th eighth of the planes (see above)
+  if (plane >= L.B * L.N * L.D) return;
+  const int bn = plane / L.D, d = plane - bn * L.D;
+  const int base = bn * L.dhw + d * L.hw;          // the plane's first point in either order
+  for (int i = threadIdx.x; i < L.hw; i += kBlock) {
+    const int w = i / L.fh, h = i - w * L.fh;       // i-th word of the plane in key / rnk: (d * fw + w) * fh + h
+    const int nat = h * L.fw + w;
+    const int pid = base + nat, pix = bn * L.hw + nat;
+#pragma unroll
+    for (int j = J0; j < 2; ++j) {
+      const int k = L.key[j * L.P + base + i];
+      int slot = -1;
+      if (k >= 0) {
+        slot = L.nzoff[k];
+        if (j == 1 || !L.columns) L.s_ent[L.offset[k] + L.rnk[j * L.P + base + i]] = make_int4(pid, pix, slot, 0);
+      }
+      sl[j * L.hw + nat] = slot;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L.hw; i += kBlock) {
+#pragma unroll
+    for (int j = J0; j < 2; ++j) L.p_slot[j * L.P + base + i] = sl[j * L.hw + i];
   }
 }
 
@@ -434,11 +469,29 @@ __global__ __launch_bounds__(kBlock) void mghs_rank_by_pid(Layout L, int t0) {
   if (t >= 2 * L.P) return;
   const int k = L.key[t];
   if (k < 0) return;
-  const int pid = t < L.P ? t : t - L.P;
+  const int cix = t < L.P ? t : t - L.P;
+#ifdef DHD_KEYS_ROWMAJOR
+  const int pid = cix;
+#else
+  const int bn = cix / L.dhw, i = cix - bn * L.dhw;
+  const int colm = i / L.fh, h = i - colm * L.fh, d = colm / L.fw, w = colm - d * L.fw;
+  const int pid = pt_natural(L, bn, d, h, w);
+#endif
   const int lo = L.offset[k], hi = L.offset[k + 1];
   int r = 0;
   for (int e = lo; e < hi; ++e) r += L.s_ent[e].x < pid;
   L.rnk[t] = r;
+}
+
+// parity hook (dhd_mghs_debug_keys): the two key rows in the natural point order
+__global__ __launch_bounds__(kBlock) void mghs_keys_natural(Layout L, int* __restrict__ out) {
+  const int pid = blockIdx.x * kBlock + threadIdx.x;
+  if (pid >= L.P) return;
+  const int bn = pid / L.dhw, i = pid - bn * L.dhw;
+  const int d = i / L.hw, r = i - d * L.hw, h = r / L.fw, w = r - h * L.fw;
+  const int cix = pt_index(L, bn, d, h, w);
+  out[pid] = L.key[cix];
+  out[L.P + pid] = L.G > 1 ? L.key[L.P + cix] : -1;
 }
 
 }  // namespace
@@ -512,14 +565,28 @@ int lift_impl(const dhd_mghs_desc* desc, const dhd_calib* calib, const float* he
   DHD_LAUNCH_CHECK();
   if ((rc = launch_scan(L, st))) return rc;
   const dim3 gs(dhd_cdiv((long)gp.x * gp.y, 8) * 8);
-  if (static_rig) hipLaunchKernelGGL(mghs_scatter<1>, gs, dim3(kBlock), 0, st, L, (int)gp.x);
-  else hipLaunchKernelGGL(mghs_scatter<0>, gs, dim3(kBlock), 0, st, L, (int)gp.x);
+  const dim3 gpl(dhd_cdiv((long)L.B * L.N * L.D, 8) * 8);
+  const size_t plane_lds = (size_t)2 * L.hw * sizeof(int);
+#ifdef DHD_KEYS_ROWMAJOR
+  const bool by_plane = false;
+#else
+  const bool by_plane = plane_lds <= 48 * 1024;
+#endif
+  auto scatter = [&]() {
+    if (by_plane) {
+      if (static_rig) hipLaunchKernelGGL(mghs_scatter_planes<1>, gpl, dim3(kBlock), plane_lds, st, L);
+      else hipLaunchKernelGGL(mghs_scatter_planes<0>, gpl, dim3(kBlock), plane_lds, st, L);
+    } else {
+      if (static_rig) hipLaunchKernelGGL(mghs_scatter<1>, gs, dim3(kBlock), 0, st, L, (int)gp.x);
+      else hipLaunchKernelGGL(mghs_scatter<0>, gs, dim3(kBlock), 0, st, L, (int)gp.x);
+    }
+  };
+  scatter();
   DHD_LAUNCH_CHECK();
   if (L.flags & DHD_MGHS_DETERMINISTIC) {
     const int t0 = static_rig ? L.P : 0;
     hipLaunchKernelGGL(mghs_rank_by_pid, dim3(dhd_cdiv(2L * L.P - t0, kBlock)), dim3(kBlock), 0, st, L, t0);
-    if (static_rig) hipLaunchKernelGGL(mghs_scatter<1>, gs, dim3(kBlock), 0, st, L, (int)gp.x);
-    else hipLaunchKernelGGL(mghs_scatter<0>, gs, dim3(kBlock), 0, st, L, (int)gp.x);
+    scatter();
     DHD_LAUNCH_CHECK();
   }
   return DHD_OK;
@@ -574,11 +641,11 @@ int dhd_mghs_debug_keys(const dhd_mghs_desc* desc, const dhd_mghs_workspace* ws,
   if (!ws || !keys) return DHD_EINVAL;
   int rc = make_layout(desc, ws, &L);
   if (rc) return rc;
-  DHD_HIP(hipMemcpyAsync(keys, L.key, (size_t)L.P * sizeof(int32_t), hipMemcpyDeviceToDevice, dhd_stream(stream)));
+  // keys[] is in the natural point order (the reference's ranks_depth); the product keeps its per-point arrays in pt_index order
   // a single-grid plan has no band grids: the counting kernel never writes row 1, so the hook reports "no key" there instead of
   // whatever the scratch held
-  if (L.G > 1) DHD_HIP(hipMemcpyAsync(keys + L.P, L.key + L.P, (size_t)L.P * sizeof(int32_t), hipMemcpyDeviceToDevice, dhd_stream(stream)));
-  else DHD_HIP(hipMemsetAsync(keys + L.P, 0xff, (size_t)L.P * sizeof(int32_t), dhd_stream(stream)));
+  hipLaunchKernelGGL(mghs_keys_natural, dim3(dhd_cdiv(L.P, kBlock)), dim3(kBlock), 0, dhd_stream(stream), L, keys);
+  DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
 
