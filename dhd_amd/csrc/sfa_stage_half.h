@@ -96,12 +96,12 @@ __global__ __launch_bounds__(kEwBlock) void blend2_bn_bwd_h_kernel(const TS* __r
   int lo, hi;
   chunk_range8(hw, &lo, &hi);
   float s1 = 0.f, s2 = 0.f, sa = 0.f;
-  for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
+  auto body = [&](const u32x4 wp, const u32x4 wq, const u32x4 ws, const u32x4 wo, int i) {
     float p[8], q[8], s[8], o[8], r[8];
-    ld8<TS>(xb, i, p);
-    ld8<TS>(xv, i, q);
-    ld8<TS>(yp, i, s);
-    ld8<TS>(gp, i, o);
+    widen8<TS>(wp, p);
+    widen8<TS>(wq, q);
+    widen8<TS>(ws, s);
+    widen8<TS>(wo, o);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float g = sigmoidf_(fmaf(sc, s[j], sh));
@@ -116,7 +116,16 @@ __global__ __launch_bounds__(kEwBlock) void blend2_bn_bwd_h_kernel(const TS* __r
       s1 += r[j];
       s2 = fmaf(r[j], s[j] - mu, s2);
     }
+  };
+  auto ldv = [](const TS* base, int i) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base) + i); };
+  int i = lo + threadIdx.x;
+  for (; i + kEwBlock < hi; i += 2 * kEwBlock) {   // two 16-byte vectors of each of the four streams in flight per thread
+    const u32x4 p0 = ldv(xb, i), q0 = ldv(xv, i), y0 = ldv(yp, i), o0 = ldv(gp, i);
+    const u32x4 p1 = ldv(xb, i + kEwBlock), q1 = ldv(xv, i + kEwBlock), y1v = ldv(yp, i + kEwBlock), o1 = ldv(gp, i + kEwBlock);
+    body(p0, q0, y0, o0, i);
+    body(p1, q1, y1v, o1, i + kEwBlock);
   }
+  if (i < hi) body(ldv(xb, i), ldv(xv, i), ldv(yp, i), ldv(gp, i), i);
   s1 = block_sum(s1, sm);
   s2 = block_sum(s2, sm);
   sa = block_sum(sa, sm);
@@ -214,11 +223,11 @@ __global__ __launch_bounds__(kEwBlock) void stage_gx_h_kernel(const float* __res
   TS* gv = gx + ((size_t)b * 2 * c + c + ch) * hw;
   int lo, hi;
   chunk_range8(hw, &lo, &hi);
-  for (int i = lo + threadIdx.x; i < hi; i += kEwBlock) {
+  auto body = [&](const u32x4 ws, const u32x4 wo, const u32x4 wd, int i) {
     float s[8], o[8], d[8], rb[8], rv[8];
-    ld8<TS>(yp, i, s);
-    ld8<TS>(gp, i, o);
-    ld8<TS>(dp, i, d);
+    widen8<TS>(ws, s);
+    widen8<TS>(wo, o);
+    widen8<TS>(wd, d);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float g = sigmoidf_(fmaf(sc, s[j], sh));
@@ -227,7 +236,16 @@ __global__ __launch_bounds__(kEwBlock) void stage_gx_h_kernel(const float* __res
     }
     st8<TS>(gb, i, rb);
     st8<TS>(gv, i, rv);
+  };
+  auto ldv = [](const TS* base, int i) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base) + i); };
+  int i = lo + threadIdx.x;
+  for (; i + kEwBlock < hi; i += 2 * kEwBlock) {   // two vectors of each stream in flight per thread
+    const u32x4 s0 = ldv(yp, i), o0 = ldv(gp, i), d0 = ldv(dp, i);
+    const u32x4 s1 = ldv(yp, i + kEwBlock), o1 = ldv(gp, i + kEwBlock), d1 = ldv(dp, i + kEwBlock);
+    body(s0, o0, d0, i);
+    body(s1, o1, d1, i + kEwBlock);
   }
+  if (i < hi) body(ldv(yp, i), ldv(gp, i), ldv(dp, i), i);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
