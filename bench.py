@@ -169,6 +169,9 @@ def parse():
     p.add_argument('--amp', choices=['off', 'bf16', 'fp16'], default='off', help='autocast dtype of the dense modules (e2e)')
     p.add_argument('--model', choices=['dhd-s', 'dhd-m', 'dhd-l'], default='dhd-s',
                    help='e2e: DHD-S (single frame), DHD-M (temporal stereo) or DHD-L (Swin-B, 512x1408 images, temporal stereo)')
+    p.add_argument('--layout', default=None,
+                   help="e2e: memory format of the dense modules: 'nchw', 'channels_last' or 'channels_last:<sub-module>,...' "
+                        "(default: $DHD_E2E_LAYOUT, else the measured-best stacks for the half-precision DHD-S step and nchw otherwise)")
     p.add_argument('--no-ema', action='store_true', help='e2e: leave out the per-iteration weight EMA (MEGVIIEMAHook) of the configs')
     p.add_argument('--cpu-samples', type=int, default=4, help='largest batch of the CPU baseline leg (0 = skip)')
     p.add_argument('--deterministic', action='store_true', help='hotpath: order the entries of every voxel by point id (bit-reproducible forward)')
@@ -308,7 +311,7 @@ class EndToEnd:
     SURVEY.md 8d config 2): forward_train -> sum of the four losses -> backward -> grad clip 5 -> AdamW."""
 
     def __init__(self, dev, batch, seed, world, amp, model='dhd-s', ema=True, graph=False, bucket_mb=64, static_graph=False,
-                 ddp_graph=False):
+                 ddp_graph=False, layout=None):
         import dhd_amd
         from dhd_amd.detector import dhd_l_model_cfg, dhd_m_model_cfg, dhd_s_model_cfg
         torch.manual_seed(seed)
@@ -319,8 +322,17 @@ class EndToEnd:
         self.model = dhd_amd.build_detector(cfg).to(dev).train()
         if model == 'dhd-l':
             self.model.img_backbone.init_weights()   # trunc-normal init of the Swin linears / bias tables (swin.py:876-890)
-        # (tried: every dense module in channels_last, with and without PYTORCH_MIOPEN_SUGGEST_NHWC[_BATCHNORM]: 81.7 / 81.9 ms per
-        # fp16 step against 76.1 ms in NCHW -- MIOpen's NCHW path with its own transposes is the faster one here)
+        # Measured per dense stack on MI355X with the committed find-db (experiments/e2e_layout_parts_ab.sh, DHD-S fp16 step, NCHW
+        # 65.85 ms): image encoder in channels_last -5.95 ms, + the three UNets -0.25, + the occupancy head -0.4, + the depth /
+        # height nets +0.1, + the BEV encoder +3.2 -- hence the default below for the half-precision DHD-S step.  float32 and the
+        # other models stay NCHW (the find-db holds no NHWC entries for their problems).
+        default = 'nchw'
+        if model == 'dhd-s' and amp != 'off':
+            default = 'channels_last:img_backbone,img_voxel_encoder0,img_voxel_encoder1,img_voxel_encoder2,occ_head'
+        self.layout = layout or os.environ.get('DHD_E2E_LAYOUT') or default
+        if self.layout.startswith('channels_last'):          # 'channels_last' or 'channels_last:part,part' (detector.use_channels_last)
+            parts = self.layout.partition(':')[2]
+            self.model.use_channels_last(True, parts.split(',') if parts else None)
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         self.n_params = sum(p.numel() for p in self.params)
         self.net = self.model
@@ -399,7 +411,7 @@ class EndToEnd:
 
 def run_e2e(a, rank, world, dev):
     job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp, a.model, not a.no_ema, graph=not a.no_graph, bucket_mb=a.bucket_mb,
-                   static_graph=a.ddp_static_graph, ddp_graph=a.ddp_graph)
+                   static_graph=a.ddp_static_graph, ddp_graph=a.ddp_graph, layout=a.layout)
     for _ in range(a.warmup):
         job.step(False)
     job.capture()
@@ -428,7 +440,8 @@ def run_e2e(a, rank, world, dev):
                                  'forward_train + backward + grad-clip + AdamW' + ('' if a.no_ema else ' + weight EMA (HIP)') + '; random init',
                         samples_per_gpu=a.batch, global_batch=a.batch * world, params=job.n_params,
                         parallelism=f'DDP x{world} (RCCL bucketed all-reduce overlapped with backward)' if world > 1 else 'single GPU',
-                        hip_graph=job.graphed is not None, hip_graph_error=job.graph_error, final_loss=float(loss)))), flush=True)
+                        hip_graph=job.graphed is not None, hip_graph_error=job.graph_error, layout=job.layout,
+                        final_loss=float(loss.detach())))), flush=True)
     ddist.shutdown()
 
 
@@ -920,7 +933,7 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
         job, err = None, None
         try:
             job = EndToEnd(dev, a.batch, 1000 + rank, world, amp, 'dhd-s', True, graph=not a.no_graph, bucket_mb=a.bucket_mb,
-                           static_graph=a.ddp_static_graph, ddp_graph=a.ddp_graph)
+                           static_graph=a.ddp_static_graph, ddp_graph=a.ddp_graph, layout=a.layout)
             n_params = job.n_params
         except Exception as exc:  # noqa: BLE001
             err = f'{type(exc).__name__}: {exc}'[:300]
@@ -939,7 +952,7 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
                 job.graphed = None
         per_step = timed(job, steps, tag)
         rec = dict(samples_per_s=a.batch * world / per_step, ms_per_step=1e3 * per_step, steps=steps, warmup=warmup,
-                   hip_graph=job.graphed is not None)
+                   hip_graph=job.graphed is not None, layout=job.layout)
         if eager is not None:
             rec['ms_per_step_eager'] = 1e3 * eager
         if job.graph_error:

@@ -100,6 +100,8 @@ class BatchNorm2d(nn.BatchNorm2d):
     def _hip_ok(self, x, force=False):
         if not (self.use_hip and self.training and x.is_cuda and x.dim() == 4 and x.dtype in _DTYPES and x.numel() > 0):
             return False
+        if not force and not x.is_contiguous():   # channels_last activations stay with the layout-preserving library path
+            return False
         min_numel, max_channels, big_numel = self.routing()
         if not force and not ((x.numel() >= min_numel and x.shape[1] <= max_channels) or x.numel() >= big_numel):
             return False

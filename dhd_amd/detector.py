@@ -222,6 +222,19 @@ class CustomResNet(nn.Module):
 _PLAIN_UPSAMPLE = bool(__import__('os').environ.get('DHD_PLAIN_UPSAMPLE'))   # A/B switch: autocast's float32 upsample
 
 
+class _ToChannelsLast(torch.autograd.Function):
+    """NCHW -> channels_last copy whose gradient comes back NCHW (a plain `.contiguous(memory_format=...)` hands the producer
+    a channels_last gradient, and torch's backward kernels pick their NHWC variant from the gradient's layout)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        return y.contiguous(memory_format=torch.channels_last)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous()
+
+
 class Upsample(nn.Upsample):
     """nn.Upsample that stays in the autocast dtype.  torch.autocast runs upsample_bilinear2d in float32 (it is on autocast's
     float32 list): a half input comes back as a float32 tensor four / sixteen times its size, the `cat` behind it promotes its
@@ -231,10 +244,18 @@ class Upsample(nn.Upsample):
     produces up to one unit in the last place (bf16: identical; tests/test_detector.py)."""
 
     def forward(self, x):
+        # channels_last input: torch's NHWC backward of the bilinear kernel is ten times slower than the NCHW one on MI355X
+        # (2.3 ms against 0.26 ms per call at the BEV encoder's sizes: experiments/prof_e2e_layout_diff.sh), so the operator runs
+        # on an NCHW copy and its result goes back to the caller's layout (two transposes of ~0.03 ms each way)
+        nhwc = x.is_cuda and x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+        if nhwc:
+            x = x.contiguous()
         if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and torch.is_autocast_enabled() and not _PLAIN_UPSAMPLE:
             with torch.autocast('cuda', enabled=False):
-                return super().forward(x)
-        return super().forward(x)
+                y = super().forward(x)
+        else:
+            y = super().forward(x)
+        return _ToChannelsLast.apply(y) if nhwc else y
 
 
 @NECKS.register_module()
@@ -535,6 +556,35 @@ class DHD(nn.Module):
         # one launch per step for all `num_batches_tracked` counters instead of one per layer (batchnorm.BatchNorm2d.defer_counter)
         from .batchnorm import defer_counters
         defer_counters(self)
+        self._layout = {}
+
+    # sub-modules that exchange tensors directly share a layout group
+    _LAYOUT_GROUPS = dict(img_neck='img_backbone', img_bev_encoder_neck='img_bev_encoder_backbone', img_voxel_neck0='img_voxel_encoder0',
+                          img_voxel_neck1='img_voxel_encoder1', img_voxel_neck2='img_voxel_encoder2')
+    _DENSE_PARTS = ('img_backbone', 'img_view_transformer', 'img_bev_encoder_backbone', 'img_voxel_encoder0', 'img_voxel_encoder1',
+                    'img_voxel_encoder2', 'occ_head')
+
+    def use_channels_last(self, on=True, parts=None):
+        """Run dense convolution stacks in NHWC (`torch.channels_last`): their 4-D weights are converted once and the tensor at
+        the stack's entry is brought to its layout (`_enter`); inside a stack every module keeps the layout it is given.
+        MIOpen's fp16 / bf16 implicit-GEMM solvers on gfx950 are NHWC kernels -- with NCHW tensors every convolution is wrapped
+        in transposes (15 % of the kernel time of a DHD-S fp16 step).  The custom operators (MGHS, the SFA stage, the losses)
+        take and return NCHW as before.  `parts`: names out of `_DENSE_PARTS` (default: all).  Results are those of the NCHW
+        model up to the convolution solvers' rounding."""
+        fmt = torch.channels_last if on else torch.contiguous_format
+        for part in (self._DENSE_PARTS if parts is None else parts):
+            if part not in self._DENSE_PARTS:
+                raise ValueError(f'{part!r} is not one of {self._DENSE_PARTS}')
+            self._layout[part] = fmt
+            for name in [part] + [k for k, v in self._LAYOUT_GROUPS.items() if v == part]:
+                m = getattr(self, name, None)
+                if m is not None:
+                    m.to(memory_format=fmt)
+        return self
+
+    def _enter(self, part, t):
+        """`t` in the layout of dense stack `part` (a copy only where the producer's layout differs)."""
+        return t.contiguous(memory_format=self._layout.get(part, torch.contiguous_format))
 
     @property
     def with_img_neck(self):
@@ -542,7 +592,7 @@ class DHD(nn.Module):
 
     def image_encoder(self, img, stereo=False):
         B, N, C, H, W = img.shape
-        x = self.img_backbone(img.view(B * N, C, H, W))
+        x = self.img_backbone(self._enter('img_backbone', img.view(B * N, C, H, W)))
         stereo_feat = None
         if stereo:
             stereo_feat, x = x[0], x[1:]
@@ -550,6 +600,7 @@ class DHD(nn.Module):
             x = self.img_neck(x)
             if isinstance(x, (list, tuple)):
                 x = x[0]
+        x = self._enter('img_view_transformer', x)
         return x.view(B, N, *x.shape[1:]), stereo_feat
 
     def prepare_inputs(self, inputs):  # noqa: D401
@@ -571,16 +622,16 @@ class DHD(nn.Module):
         return x[0] if isinstance(x, (list, tuple)) else x
 
     def bev_encoder(self, x):
-        return self._first(self.img_bev_encoder_neck(self.img_bev_encoder_backbone(x)))
+        return self._first(self.img_bev_encoder_neck(self.img_bev_encoder_backbone(self._enter('img_bev_encoder_backbone', x))))
 
     def voxel_encoder0(self, x):
-        return self._first(self.img_voxel_neck0(self.img_voxel_encoder0(x)))
+        return self._first(self.img_voxel_neck0(self.img_voxel_encoder0(self._enter('img_voxel_encoder0', x))))
 
     def voxel_encoder1(self, x):
-        return self._first(self.img_voxel_neck1(self.img_voxel_encoder1(x)))
+        return self._first(self.img_voxel_neck1(self.img_voxel_encoder1(self._enter('img_voxel_encoder1', x))))
 
     def voxel_encoder2(self, x):
-        return self._first(self.img_voxel_neck2(self.img_voxel_encoder2(x)))
+        return self._first(self.img_voxel_neck2(self.img_voxel_encoder2(self._enter('img_voxel_encoder2', x))))
 
     def extract_img_feat(self, img_inputs, img_metas=None, **kwargs):
         imgs, s2k, e2g, intrins, post_rots, post_trans, bda = self.prepare_inputs(img_inputs)
@@ -597,7 +648,7 @@ class DHD(nn.Module):
         return x_2d, x_3d, None, depth, height
 
     def forward_occ_train(self, img_feats, voxel_semantics, mask_camera):
-        outs = self.occ_head(self.mix(torch.cat(img_feats, dim=1)))
+        outs = self.occ_head(self._enter('occ_head', self.mix(torch.cat(img_feats, dim=1))))
         return self.occ_head.loss(outs, voxel_semantics, mask_camera)
 
     def forward_train(self, points=None, img_metas=None, img_inputs=None, **kwargs):
@@ -611,7 +662,7 @@ class DHD(nn.Module):
         return self.simple_test_occ([x_2d, x_3d], img_metas)
 
     def simple_test_occ(self, img_feats, img_metas=None):
-        outs = self.occ_head(self.mix(torch.cat(img_feats, dim=1)))
+        outs = self.occ_head(self._enter('occ_head', self.mix(torch.cat(img_feats, dim=1))))
         return self.occ_head.get_occ(outs, img_metas)
 
     def forward(self, return_loss=True, **kwargs):

@@ -112,6 +112,69 @@ def test_dhd_forward_train_and_simple_test_on_gpu(gpu):
     assert len(occ) == B and occ[0].shape == (200, 200, 16) and occ[0].dtype == np.uint8
 
 
+def test_use_channels_last_converts_the_named_stacks_only():
+    """detector.use_channels_last: the 4-D weights of the named dense stacks (and of the necks grouped with them) change layout,
+    the others keep theirs; `_enter` hands a stack its layout and is a no-op where the producer already has it."""
+    import dhd_amd
+    from dhd_amd.detector import dhd_s_model_cfg
+    m = dhd_amd.build_detector(dhd_s_model_cfg())
+    cl = lambda w: w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m.use_channels_last(True, ['img_backbone', 'img_bev_encoder_backbone'])
+    sd = m.state_dict()
+    assert cl(sd['img_backbone.layer1.0.conv2.weight']) and cl(sd['img_neck.fpn_convs.0.conv.weight'])
+    assert cl(sd['img_bev_encoder_backbone.layers.2.1.conv2.weight']) and cl(sd['img_bev_encoder_neck.conv.0.weight'])
+    assert not cl(sd['img_voxel_encoder2.inc.double_conv.0.weight']) and not cl(sd['occ_head.final_conv.conv.weight'])
+    assert all(torch.equal(before[k], v) for k, v in sd.items())          # values untouched
+    x = torch.randn(2, 8, 4, 6)
+    assert cl(m._enter('img_backbone', x)) and m._enter('occ_head', x) is x
+    xc = x.contiguous(memory_format=torch.channels_last)
+    assert m._enter('img_backbone', xc) is xc and m._enter('occ_head', xc).is_contiguous()
+    with pytest.raises(ValueError):
+        m.use_channels_last(True, ['mix'])
+    m.use_channels_last(False)
+    assert not any(cl(v) for v in m.state_dict().values() if v.dim() == 4)
+
+
+@pytest.mark.gpu
+def test_dhd_step_in_channels_last_equals_the_nchw_step(gpu):
+    """The reduced DHD-S of the test above, float32, with every dense stack in channels_last: the same losses and the same
+    gradients as the NCHW model with the same weights, up to the convolution solvers' summation order (MIOpen picks different
+    kernels for the two layouts), and the same occupancy prediction in eval mode."""
+    import copy
+    import dhd_amd
+    from dhd_amd.detector import dhd_s_model_cfg
+    torch.manual_seed(0)
+    vt = dict(syn.dhd_s_config(), type='MGHS', input_size=(64, 176))
+    ref = dhd_amd.build_detector(dhd_s_model_cfg(img_view_transformer=vt)).to(gpu).train()
+    ours = copy.deepcopy(ref).use_channels_last()
+    B, N = 1, 2
+    calib = [T(a, gpu) for a in syn.make_calibration(3, B, N, (64, 176))]
+    imgs = torch.randn(B, N, 3, 64, 176, device=gpu)
+    gt_d = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, 1 + 40 * syn.hash_uniform(2, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    gt_h = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, -1 + 6 * syn.hash_uniform(3, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    sem = torch.randint(0, 18, (B, 200, 200, 16), device=gpu)
+    cam = torch.rand(B, 200, 200, 16, device=gpu) < 0.3
+    kw = dict(return_loss=True, img_inputs=[imgs] + calib, gt_depth=gt_d, gt_height=gt_h, voxel_semantics=sem, mask_camera=cam)
+    la, lb = ref(**kw), ours(**kw)
+    for k in la:
+        assert abs(float(la[k]) - float(lb[k])) <= 2e-3 * abs(float(la[k])) + 1e-5, (k, float(la[k]), float(lb[k]))
+    sum(la.values()).backward()
+    sum(lb.values()).backward()
+    pa, pb = dict(ref.named_parameters()), dict(ours.named_parameters())
+    # the head end of the network sees little of the layout change; the first convolution sees all of it, through ~70 layers with
+    # batch statistics over two images
+    for name, tol in (('occ_head.predicter.0.weight', 1e-3), ('mix.mysk_7.fc.0.weight', 5e-3), ('img_voxel_encoder0.inc.double_conv.0.weight', 1e-2),
+                      ('img_view_transformer.depth_net.weight', 2e-2), ('img_backbone.conv1.weight', 1e-1)):
+        ga, gb = pa[name].grad.double(), pb[name].grad.double()
+        assert torch.isfinite(gb).all() and float((ga - gb).norm() / ga.norm()) < tol, (name, float((ga - gb).norm() / ga.norm()))
+    ref.eval(), ours.eval()
+    with torch.no_grad():
+        oa = ref(return_loss=False, points=None, img_metas=None, img=[imgs] + calib)
+        ob = ours(return_loss=False, points=None, img_metas=None, img=[imgs] + calib)
+    assert (oa[0] != ob[0]).mean() < 1e-3
+
+
 @pytest.mark.gpu
 def test_dhd_stereo_forward_train_and_simple_test_on_gpu(gpu):
     """DHD-M wiring (temporal stereo: key frame + one adjacent frame + one stereo reference frame, D = 88,
