@@ -56,6 +56,63 @@ class _BNTrain(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None
 
 
+BN_RELU, BN_ADD = 1, 2   # include/dhd_amd.h DHD_BN_RELU / DHD_BN_ADD
+
+
+def _is_nhwc(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
+class _BNTrainNHWC(torch.autograd.Function):
+    """Training BatchNorm of a channels_last tensor with the ReLU (and the residual add) that follows it fused in
+    (csrc/batchnorm.hip, second half; include/dhd_amd.h section 9b)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, factor, eps, flags, residual):
+        n, c, h, w = x.shape
+        rows = n * h * w
+        lib = _lib.load()
+        dev = x.device
+        with torch.cuda.device(dev):
+            y = torch.empty_like(x)     # keeps the channels_last strides
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            rstd = torch.empty_like(mean)
+            affine = torch.empty(2 * c, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.dhd_bn_nhwc_workspace_bytes(rows, c), dtype=torch.uint8, device=dev)
+            _lib.check(lib.dhd_bn_nhwc_train_forward(_lib.ptr(x), _lib.ptr(residual), _DTYPES[x.dtype], rows, c, flags, _lib.ptr(weight),
+                                                     _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var), factor, eps, _lib.ptr(y),
+                                                     _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(affine), _lib.ptr(ws), _lib.stream_ptr(dev)),
+                       'dhd_bn_nhwc_train_forward')
+        ctx.save_for_backward(x, weight, mean, rstd, affine, y if flags & BN_ADD else None)
+        ctx.has_bias, ctx.flags = bias is not None, flags
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, mean, rstd, affine, y = ctx.saved_tensors
+        n, c, h, w = x.shape
+        rows = n * h * w
+        lib = _lib.load()
+        dev = x.device
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        want_res = bool(ctx.flags & BN_ADD) and ctx.needs_input_grad[8]
+        with torch.cuda.device(dev):
+            gx = torch.empty_like(x)
+            gres = torch.empty_like(x) if want_res else None
+            dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+            dbeta = torch.empty_like(dgamma)
+            ws = torch.empty(lib.dhd_bn_nhwc_workspace_bytes(rows, c), dtype=torch.uint8, device=dev)
+            _lib.check(lib.dhd_bn_nhwc_train_backward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gy), _DTYPES[x.dtype], rows, c, ctx.flags,
+                                                      _lib.ptr(weight), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(affine), _lib.ptr(gx),
+                                                      _lib.ptr(gres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.stream_ptr(dev)),
+                       'dhd_bn_nhwc_train_backward')
+        gw = dgamma.to(weight.dtype) if weight is not None and ctx.needs_input_grad[1] else None
+        gb = dbeta if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, None, None, None, None, gres
+
+
 class BatchNorm2d(nn.BatchNorm2d):
     """Drop-in for nn.BatchNorm2d; `use_hip = False` switches the operator off.
 
@@ -112,15 +169,33 @@ class BatchNorm2d(nn.BatchNorm2d):
         n, c = x.shape[:2]
         return bool(_lib.load().dhd_bn_supported(_DTYPES[x.dtype], n, c, x[0, 0].numel()))
 
-    def forward(self, x):
+    use_nhwc = not os.environ.get('DHD_BN_NO_NHWC')   # A/B switch: channels_last tensors go to the library's kernels
+
+    def _nhwc_ok(self, x):
+        if not (self.use_hip and self.use_nhwc and self.training and x.is_cuda and x.dtype in _DTYPES and x.numel() > 0 and _is_nhwc(x)):
+            return False
+        if self.weight is not None and (self.weight.dtype != torch.float32 or (self.bias is not None and self.bias.dtype != torch.float32)):
+            return False
+        if self.track_running_stats and self.running_mean.dtype != torch.float32:
+            return False
+        n, c, h, w = x.shape
+        return bool(_lib.load().dhd_bn_nhwc_supported(_DTYPES[x.dtype], n * h * w, c))
+
+    def forward(self, x, relu=False, residual=None):
+        """`relu` / `residual`: the caller's `relu(bn(x))` or `relu(bn(x) + residual)` (resnet.py:282-300, mmcv's ConvModule) in
+        one call; on channels_last GPU tensors in training they are fused into the normalisation's kernels, everywhere else they
+        are applied with torch operators after it."""
         defer = (self.defer_counter and self.training and self.track_running_stats and self.momentum is not None
                  and self.num_batches_tracked is not None)
-        if not self._hip_ok(x):
+        nhwc = self._nhwc_ok(x)
+        if not nhwc and not self._hip_ok(x):
             if defer:   # nn.BatchNorm2d.forward in training mode with running statistics, minus the counter launch
                 self._check_input_dim(x)
                 self._pending += 1
-                return nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
-            return super().forward(x)
+                y = nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
+            else:
+                y = super().forward(x)
+            return self._tail(y, relu, residual)
         self._check_input_dim(x)
         factor = 0.0 if self.momentum is None else self.momentum
         rm = rv = None
@@ -132,7 +207,18 @@ class BatchNorm2d(nn.BatchNorm2d):
                 self.num_batches_tracked.add_(1)
                 if self.momentum is None:
                     factor = 1.0 / float(self.num_batches_tracked)
-        return _BNTrain.apply(x.contiguous(), self.weight, self.bias, rm, rv, float(factor), float(self.eps))
+        if nhwc:
+            fuse_add = residual is not None and residual.shape == x.shape and residual.dtype == x.dtype and _is_nhwc(residual)
+            flags = BN_ADD if fuse_add else (BN_RELU if relu and residual is None else 0)
+            y = _BNTrainNHWC.apply(x, self.weight, self.bias, rm, rv, float(factor), float(self.eps), flags, residual if fuse_add else None)
+            return y if flags or not (relu or residual is not None) else self._tail(y, relu, residual)
+        return self._tail(_BNTrain.apply(x.contiguous(), self.weight, self.bias, rm, rv, float(factor), float(self.eps)), relu, residual)
+
+    @staticmethod
+    def _tail(y, relu, residual):
+        if residual is not None:
+            y = y + residual
+        return torch.relu_(y) if (relu or residual is not None) else y
 
 
 def defer_counters(model, on=True):

@@ -48,10 +48,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + identity)
+        # relu(bn(.)) and relu(bn(.) + identity) as one operator each (batchnorm.BatchNorm2d.forward)
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), residual=identity)
 
 
 @BACKBONES.register_module()
@@ -109,7 +109,7 @@ class ResNet(nn.Module):
         self._freeze_stages()   # as mmdet's ResNet.__init__: frozen parameters never reach an optimizer built before .train()
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         outs = []
         for i, name in enumerate(self.res_layers):
             layer = getattr(self, name)
@@ -147,7 +147,7 @@ class ResNet(nn.Module):
 
     def forward_first_stage(self, x):
         """Stem + first residual stage only: the stereo reference feature of BEVStereo4D (bevstereo4d.py:29-40)."""
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         return getattr(self, self.res_layers[0])(x)
 
 
@@ -163,7 +163,7 @@ class ConvModule(nn.Module):
     def forward(self, x):
         x = self.conv(x)
         if self.bn is not None:
-            x = self.bn(x)
+            return self.bn(x, relu=self.act is not None)
         return x if self.act is None else self.act(x)
 
 
@@ -295,7 +295,8 @@ class _DoubleConv(nn.Module):
                                          nn.Conv2d(mid, cout, 3, padding=1, bias=False), BatchNorm2d(cout), nn.ReLU(inplace=True))
 
     def forward(self, x):
-        return self.double_conv(x)
+        c1, b1, _, c2, b2, _ = self.double_conv      # conv, BN, ReLU twice; each BN takes its ReLU along
+        return b2(c2(b1(c1(x), relu=True)), relu=True)
 
 
 class _Down(nn.Module):

@@ -24,5 +24,8 @@ print('total A %.2f  B %.2f' % (sum(a.values()), sum(b.values())))
 keys = sorted(set(a) | set(b), key=lambda k: -abs(b[k] - a[k]))
 for k in keys[:40]:
     print(f'{b[k]-a[k]:+8.3f}  A {a[k]:7.3f} ({na[k]:5d})  B {b[k]:7.3f} ({nb[k]:5d})  {k}')
+print('--- largest kernels of B')
+for k in sorted(b, key=lambda k: -b[k])[:45]:
+    print(f'{b[k]:7.3f} ms ({nb[k] // 8:4d} launches per step)  {k}')
 PY
 cat $R/gpurun_out/e2e_layout_diff.txt

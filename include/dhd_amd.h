@@ -582,6 +582,27 @@ int dhd_bn_train_backward(const void* x, const void* grad_y, int dtype, int n, i
                           const float* gamma, const float* save_mean, const float* save_rstd,
                           void* grad_x, float* dgamma, float* dbeta, void* workspace, void* stream);
 
+/* 9b. The same for channels_last activations: x, y, residual and the gradients are row-major matrices (rows = n*hw, c) --
+ *     what torch.channels_last tensors are in memory -- with c a multiple of 4 (float32) or 8 elements.  `flags` fuses the
+ *     element-wise operators that follow the normalisation in the dense callers (resnet.py's Bottleneck, mmcv's ConvModule):
+ *       DHD_BN_RELU  y = max(0, bn(x));   DHD_BN_ADD  y = max(0, bn(x) + residual)   (ADD implies the ReLU).
+ *     Backward takes the gradient with respect to that y: its ReLU mask is recomputed from x and save_affine (= the forward's
+ *     per-channel scale | shift, [2*c]; RELU) or read from the saved output y (ADD), and with ADD grad_residual (may be NULL)
+ *     receives the masked gradient.  Without flags y / residual / grad_residual may be NULL in backward.
+ *     Workspace: dhd_bn_nhwc_workspace_bytes. */
+#define DHD_BN_RELU 1
+#define DHD_BN_ADD 2
+int dhd_bn_nhwc_supported(int dtype, long rows, int c);
+size_t dhd_bn_nhwc_workspace_bytes(long rows, int c);
+int dhd_bn_nhwc_train_forward(const void* x, const void* residual, int dtype, long rows, int c, int flags,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float factor, float eps, void* y, float* save_mean, float* save_rstd,
+                              float* save_affine, void* workspace, void* stream);
+int dhd_bn_nhwc_train_backward(const void* x, const void* y, const void* grad_y, int dtype, long rows, int c, int flags,
+                               const float* gamma, const float* save_mean, const float* save_rstd,
+                               const float* save_affine, void* grad_x, void* grad_residual, float* dgamma,
+                               float* dbeta, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1890,6 +1890,59 @@ def test_batchnorm2d_training_vs_torch(gpu, dtype, tol, shape):
         assert torch.equal(ours(x), torch.nn.functional.batch_norm(x, ours.running_mean, ours.running_var, ours.weight, ours.bias, False, 0.0, ours.eps))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize('mode', ['plain', 'relu', 'add'])
+@pytest.mark.parametrize('shape', [(6, 64, 32, 88), (3, 8, 5, 7), (2, 2048, 4, 6), (2, 4096, 3, 3), (2, 24, 6, 10), (1, 136, 40, 40)])
+def test_batchnorm2d_channels_last_fused_vs_torch(gpu, dtype, tol, mode, shape):
+    """The channels_last kernels (include/dhd_amd.h 9b) with the ReLU / residual + ReLU that follows the normalisation fused in,
+    against torch's BatchNorm2d + add + relu on float32 copies of the same (rounded) inputs: output, running statistics, and the
+    gradients of x, the residual, weight and bias.  Shapes: 8 vectors per row (32 row lanes), one vector (odd row count), 256 and
+    512 vectors (two column groups), 3 vectors (row lanes do not fill the workgroup), 17 vectors."""
+    from dhd_amd.batchnorm import BatchNorm2d
+    torch.manual_seed(sum(shape))
+    n, c, h, w = shape
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    ours = BatchNorm2d(c).to(gpu).train()
+    ref = torch.nn.BatchNorm2d(c).to(gpu).train()
+    with torch.no_grad():
+        ours.weight.copy_(torch.rand(c) + 0.5); ours.bias.copy_(torch.randn(c) * 0.5)
+        ours.running_mean.copy_(torch.randn(c)); ours.running_var.copy_(torch.rand(c) + 0.5)
+    ref.load_state_dict(ours.state_dict())
+    for step in range(2):
+        x = cl((torch.randn(shape, device=gpu) * 1.7 + 0.4).to(dtype)).requires_grad_()
+        res = cl(torch.randn(shape, device=gpu).to(dtype)).requires_grad_() if mode == 'add' else None
+        g = cl(torch.randn(shape, device=gpu).to(dtype))
+        assert ours._nhwc_ok(x) == (c % (4 if dtype == torch.float32 else 8) == 0)
+        y = ours(x, relu=mode == 'relu', residual=res)
+        assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+        y.backward(g)
+        xr = x.detach().float().requires_grad_()
+        rr = res.detach().float().requires_grad_() if res is not None else None
+        pre = ref(xr) if rr is None else ref(xr) + rr
+        scale = max(1.0, float(pre.abs().max()))
+        if mode == 'plain':
+            yr = pre
+        else:
+            # an element whose pre-activation is within rounding of zero may land on either side; the reference takes the
+            # operator's own decision there (as autograd would from the stored half output) and checks it everywhere else
+            mask = y.detach().float() > 0
+            sure = pre.detach().abs() > 2 * tol * scale
+            assert (mask == (pre.detach() > 0))[sure].all()
+            yr = pre * mask
+        yr.backward(g.float())
+        assert (y.float() - yr).abs().max() <= tol * scale
+        assert (x.grad.float() - xr.grad).abs().max() <= tol * max(1.0, float(xr.grad.abs().max())) * 2
+        if res is not None:
+            assert (res.grad.float() - rr.grad).abs().max() <= tol * max(1.0, float(rr.grad.abs().max()))
+        for a, b in ((ours.weight.grad, ref.weight.grad), (ours.bias.grad, ref.bias.grad)):
+            assert (a - b).abs().max() <= tol * max(1.0, float(b.abs().max())) * (1 if dtype == torch.float32 else 4)
+        assert torch.allclose(ours.running_mean, ref.running_mean, atol=1e-5, rtol=1e-5)
+        assert torch.allclose(ours.running_var, ref.running_var, atol=1e-5, rtol=1e-4)
+        assert int(ours.num_batches_tracked) == step + 1
+        ours.zero_grad(); ref.zero_grad()
+
+
 # ---------------------------------------------------------------------------------------------
 # SFA stage under nn.SyncBatchNorm (DHD-L.py:308-311 SyncbnControlHook): the phased operator, two ranks sharing cuda:0 over gloo
 # ---------------------------------------------------------------------------------------------
