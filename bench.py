@@ -322,13 +322,11 @@ class EndToEnd:
         self.model = dhd_amd.build_detector(cfg).to(dev).train()
         if model == 'dhd-l':
             self.model.img_backbone.init_weights()   # trunc-normal init of the Swin linears / bias tables (swin.py:876-890)
-        # Measured per dense stack on MI355X with the committed find-db (experiments/e2e_layout_parts_ab.sh, DHD-S fp16 step, NCHW
-        # 65.85 ms): image encoder in channels_last -5.95 ms, + the three UNets -0.25, + the occupancy head -0.4, + the depth /
-        # height nets +0.1, + the BEV encoder +3.2 -- hence the default below for the half-precision DHD-S step.  float32 and the
-        # other models stay NCHW (the find-db holds no NHWC entries for their problems).
-        default = 'nchw'
-        if model == 'dhd-s' and amp != 'off':
-            default = 'channels_last:img_backbone,img_voxel_encoder0,img_voxel_encoder1,img_voxel_encoder2,occ_head'
+        # Measured per dense stack on MI355X with the committed find-db, DHD-S fp16 step (docs/LAB_NOTEBOOK.md R5.5): NCHW 65.9 ms;
+        # image encoder in channels_last 59.9; + UNets + head 59.5; + the library's NHWC BatchNorm(+ReLU) 57.1; + its bilinear
+        # upsample kernels 56.5; + the BEV encoder (which lost 3.2 ms in channels_last on torch's NHWC upsample backward) 55.1.
+        # float32 and the other models stay NCHW (the find-db holds no NHWC entries for their problems).
+        default = 'channels_last' if (model == 'dhd-s' and amp != 'off') else 'nchw'
         self.layout = layout or os.environ.get('DHD_E2E_LAYOUT') or default
         if self.layout.startswith('channels_last'):          # 'channels_last' or 'channels_last:part,part' (detector.use_channels_last)
             parts = self.layout.partition(':')[2]

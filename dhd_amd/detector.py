@@ -219,43 +219,77 @@ class CustomResNet(nn.Module):
         return feats
 
 
-_PLAIN_UPSAMPLE = bool(__import__('os').environ.get('DHD_PLAIN_UPSAMPLE'))   # A/B switch: autocast's float32 upsample
+_PLAIN_UPSAMPLE = bool(__import__('os').environ.get('DHD_PLAIN_UPSAMPLE'))   # A/B switch: leave nn.Upsample to torch
 
 
-class _ToChannelsLast(torch.autograd.Function):
-    """NCHW -> channels_last copy whose gradient comes back NCHW (a plain `.contiguous(memory_format=...)` hands the producer
-    a channels_last gradient, and torch's backward kernels pick their NHWC variant from the gradient's layout)."""
-
-    @staticmethod
-    def forward(ctx, y):
-        return y.contiguous(memory_format=torch.channels_last)
+class _UpsampleBilinear(torch.autograd.Function):
+    """csrc/upsample.hip: bilinear, align_corners=True, NCHW or channels_last, in the tensor's own dtype."""
 
     @staticmethod
-    def backward(ctx, g):
-        return g.contiguous()
+    def _geom(x, size):
+        from . import _lib
+        nhwc = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+        n, c, h, w = x.shape
+        return (_lib_dtype(x.dtype), int(nhwc), n, c, h, w, int(size[0]), int(size[1]))
+
+    @staticmethod
+    def forward(ctx, x, size):
+        from . import _lib
+        geom = _UpsampleBilinear._geom(x, size)
+        if not geom[1]:
+            x = x.contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            y = torch.empty((geom[2], geom[3], geom[6], geom[7]), dtype=x.dtype, device=x.device,
+                            memory_format=torch.channels_last if geom[1] else torch.contiguous_format)
+            _lib.check(lib.dhd_upsample_bilinear_forward(_lib.ptr(x), *geom, _lib.ptr(y), _lib.stream_ptr(x.device)), 'dhd_upsample_bilinear_forward')
+        ctx.geom = geom
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        geom = ctx.geom
+        gy = gy.contiguous(memory_format=torch.channels_last if geom[1] else torch.contiguous_format)
+        lib = _lib.load()
+        with torch.cuda.device(gy.device):
+            gx = torch.empty((geom[2], geom[3], geom[4], geom[5]), dtype=gy.dtype, device=gy.device,
+                             memory_format=torch.channels_last if geom[1] else torch.contiguous_format)
+            _lib.check(lib.dhd_upsample_bilinear_backward(_lib.ptr(gy), *geom, _lib.ptr(gx), _lib.stream_ptr(gy.device)), 'dhd_upsample_bilinear_backward')
+        return gx, None
+
+
+def _lib_dtype(dt):
+    return {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}.get(dt, -1)
 
 
 class Upsample(nn.Upsample):
-    """nn.Upsample that stays in the autocast dtype.  torch.autocast runs upsample_bilinear2d in float32 (it is on autocast's
-    float32 list): a half input comes back as a float32 tensor four / sixteen times its size, the `cat` behind it promotes its
-    other operand, and the convolution that follows casts everything back to half -- 3 % of the DHD-S fp16 step in
-    `upsample_bilinear2d_out_frame<float>` plus the casts (profiles/r4/e2e_dhds_fp16_steady_state.txt).  The half kernel
-    interpolates in float32 registers and rounds once on the way out, which is what the consumer's cast of the float32 result
-    produces up to one unit in the last place (bf16: identical; tests/test_detector.py)."""
+    """nn.Upsample whose bilinear / align_corners=True case (the only one the DHD configs use: lss_fpn.py:27,43, unet.py:86) runs
+    on the library's kernels (csrc/upsample.hip) on GPU tensors, in the tensor's own layout (NCHW or channels_last) and dtype.
+    torch.autocast would run upsample_bilinear2d in float32 (it is on autocast's float32 list): a half input comes back as a
+    float32 tensor four / sixteen times its size, the `cat` behind it promotes its other operand, and the convolution that
+    follows casts everything back to half; torch's own kernels take 0.6-1.0 ms per call at the BEV encoder's sizes (NCHW forward)
+    and 2.3 ms (channels_last backward).  The kernels interpolate in float32 registers and round once on the way out -- what the
+    consumer's cast of the float32 result produces up to one unit in the last place (tests/test_detector.py).  DHD_PLAIN_UPSAMPLE=1
+    leaves everything to torch (A/B switch)."""
 
     def forward(self, x):
-        # channels_last input: torch's NHWC backward of the bilinear kernel is ten times slower than the NCHW one on MI355X
-        # (2.3 ms against 0.26 ms per call at the BEV encoder's sizes: experiments/prof_e2e_layout_diff.sh), so the operator runs
-        # on an NCHW copy and its result goes back to the caller's layout (two transposes of ~0.03 ms each way)
-        nhwc = x.is_cuda and x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
-        if nhwc:
-            x = x.contiguous()
-        if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and torch.is_autocast_enabled() and not _PLAIN_UPSAMPLE:
-            with torch.autocast('cuda', enabled=False):
-                y = super().forward(x)
+        if _PLAIN_UPSAMPLE or not (x.is_cuda and x.dim() == 4 and self.mode == 'bilinear' and self.align_corners):
+            return super().forward(x)
+        from . import _lib
+        h, w = x.shape[2:]
+        if self.size is not None:
+            size = (self.size, self.size) if isinstance(self.size, int) else tuple(self.size)
         else:
-            y = super().forward(x)
-        return _ToChannelsLast.apply(y) if nhwc else y
+            sf = self.scale_factor if isinstance(self.scale_factor, (tuple, list)) else (self.scale_factor, self.scale_factor)
+            size = (int(h * sf[0]), int(w * sf[1]))        # floor(in * scale), as F.interpolate
+        geom = _UpsampleBilinear._geom(x, size)
+        if geom[0] < 0 or not _lib.load().dhd_upsample_bilinear_supported(*geom):
+            if x.dtype in (torch.float16, torch.bfloat16) and torch.is_autocast_enabled():
+                with torch.autocast('cuda', enabled=False):
+                    return super().forward(x)
+            return super().forward(x)
+        return _UpsampleBilinear.apply(x, size)
 
 
 @NECKS.register_module()

@@ -603,6 +603,19 @@ int dhd_bn_nhwc_train_backward(const void* x, const void* y, const void* grad_y,
                                const float* save_affine, void* grad_x, void* grad_residual, float* dgamma,
                                float* dbeta, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * 10. Bilinear up-sampling with align_corners = True (nn.Upsample of necks/lss_fpn.py:27,43 and
+ *     backbones/unet.py:86), forward and backward, for the dense callers.  layout 0: (n, c, h, w) NCHW,
+ *     1: (n, h, w, c) channels_last with c a multiple of 4 (float32) / 8 elements; dtype as in section 9;
+ *     hout >= hin, wout >= win, factors up to 8.  Index arithmetic as torch's UpSample.cuh (float32);
+ *     backward is a gather: one writer per element, float32 accumulation, deterministic.
+ * ------------------------------------------------------------------------------------ */
+int dhd_upsample_bilinear_supported(int dtype, int layout, int n, int c, int hin, int win, int hout, int wout);
+int dhd_upsample_bilinear_forward(const void* x, int dtype, int layout, int n, int c, int hin, int win,
+                                  int hout, int wout, void* y, void* stream);
+int dhd_upsample_bilinear_backward(const void* grad_y, int dtype, int layout, int n, int c, int hin, int win,
+                                   int hout, int wout, void* grad_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -288,8 +288,8 @@ def test_hip_nodes_under_autocast(gpu, dtype):
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_upsample_stays_in_the_autocast_dtype_and_feeds_identical_convolutions(gpu, dtype):
-    """detector.Upsample: under autocast a half input is interpolated by the half kernel (float32 arithmetic, one rounding)
-    instead of autocast's float32 upsample.  What the convolution behind it receives differs from the half cast of autocast's
+    """detector.Upsample: under autocast a half input is interpolated by the library's kernel in half storage (float32 arithmetic,
+    one rounding) instead of autocast's float32 upsample.  What the convolution behind it receives differs from the half cast of autocast's
     float32 tensor by at most one unit in the last place of the half type (the two kernel instantiations order their float32
     operations differently; bf16: measured identical), so FPN_LSS gives the same output and gradients up to that rounding."""
     import copy
@@ -303,7 +303,7 @@ def test_upsample_stays_in_the_autocast_dtype_and_feeds_identical_convolutions(g
         b = torch.nn.Upsample(scale_factor=4, mode='bilinear', align_corners=True)(x.to(dtype))
     assert a.dtype == dtype and b.dtype == torch.float32
     assert ((a.float() - b).abs() <= ulp * b.abs().clamp_min(2.0 ** -14)).all()
-    assert up(x).dtype == torch.float32 and torch.equal(up(x), torch.nn.functional.interpolate(x, scale_factor=4, mode='bilinear', align_corners=True))
+    assert up(x).dtype == torch.float32 and torch.allclose(up(x), torch.nn.functional.interpolate(x, scale_factor=4, mode='bilinear', align_corners=True), rtol=1e-6, atol=1e-6)
     neck = FPN_LSS(in_channels=16 + 24, out_channels=8, scale_factor=4, input_feature_index=(0, 1), extra_upsample=2).to(gpu).train()
     ref = copy.deepcopy(neck)
     ref.up = torch.nn.Upsample(scale_factor=4, mode='bilinear', align_corners=True)

@@ -1944,6 +1944,49 @@ def test_batchnorm2d_channels_last_fused_vs_torch(gpu, dtype, tol, mode, shape):
 
 
 # ---------------------------------------------------------------------------------------------
+# bilinear up-sampling, align_corners=True (csrc/upsample.hip) vs torch's float64 interpolate
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,eps', [(torch.float32, 2.0 ** -23), (torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+@pytest.mark.parametrize('shape,size', [((2, 16, 25, 25), (100, 100)), ((2, 8, 9, 13), (18, 26)), ((1, 8, 7, 5), (15, 16)), ((3, 24, 1, 6), (4, 6)),
+                                        ((2, 8, 6, 6), (6, 6)), ((1, 40, 50, 50), (100, 100)), ((1, 8, 3, 4), (24, 32))])
+def test_bilinear_upsample_forward_backward_vs_float64(gpu, dtype, eps, layout, shape, size):
+    """Forward: every output within one rounding of the float64 interpolation of the same (rounded) input.  Backward: the gather
+    equals the float64 transpose of that interpolation (autograd through torch's float64 kernel) -- float32 accumulation, one
+    rounding: a few units of the type's epsilon relative to the largest gradient -- and two runs give identical bits (no atomics).
+    Shapes: x4 (FPN_LSS), x2 (UNet, FPN_LSS.up2), a non-integer ratio, one input row (scale 0), identity, x8."""
+    from dhd_amd.detector import Upsample
+    torch.manual_seed(sum(shape) + sum(size))
+    x = torch.randn(shape, device=gpu).to(dtype)
+    g = torch.randn(shape[:2] + size, device=gpu).to(dtype)
+    if layout == 'channels_last':
+        x, g = x.contiguous(memory_format=torch.channels_last), g.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_()
+    up = Upsample(size=size, mode='bilinear', align_corners=True)
+    y = up(x)
+    assert y.dtype == dtype and tuple(y.shape) == shape[:2] + size
+    assert y.is_contiguous(memory_format=torch.channels_last if layout == 'channels_last' else torch.contiguous_format)
+    y.backward(g)
+    xr = x.detach().double().requires_grad_()
+    yr = torch.nn.functional.interpolate(xr, size=size, mode='bilinear', align_corners=True)
+    yr.backward(g.double())
+    # the source index is computed in float32 as torch's kernels do: lambda carries ~6e-8 * size of error against float64
+    assert ((y.double() - yr).abs() <= (0.5 * eps + 2e-5) * yr.abs().clamp_min(1.0) + 1e-30).all()
+    gscale = float(xr.grad.abs().max())
+    assert float((x.grad.double() - xr.grad).abs().max()) <= (eps + 4e-5) * gscale
+    assert x.grad.is_contiguous(memory_format=torch.channels_last if layout == 'channels_last' else torch.contiguous_format)
+    g1 = x.grad.clone()
+    x.grad = None
+    up(x).backward(g)
+    assert torch.equal(g1, x.grad)
+    if dtype == torch.float32 and layout == 'nchw':      # and against torch's own float32 kernel: the same index arithmetic
+        yt = torch.nn.functional.interpolate(x.detach(), size=size, mode='bilinear', align_corners=True)
+        assert torch.allclose(y, yt, rtol=1e-6, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
 # SFA stage under nn.SyncBatchNorm (DHD-L.py:308-311 SyncbnControlHook): the phased operator, two ranks sharing cuda:0 over gloo
 # ---------------------------------------------------------------------------------------------
 
