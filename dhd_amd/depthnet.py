@@ -160,7 +160,10 @@ class ASPP(nn.Module):
     def forward(self, x):
         branches = [self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x)]
         pooled = self.global_avg_pool(x)
-        branches.append(F.interpolate(pooled, size=x.shape[2:], mode='bilinear', align_corners=True))
+        # F.interpolate(pooled, size, 'bilinear', align_corners=True) of a 1 x 1 map (mmdet3d depthnet ASPP.forward) is that value
+        # everywhere (scale 0: cell 0, lambda 0) -- a broadcast view instead of a float32 up-sampling kernel under autocast
+        branches.append(pooled.expand(-1, -1, *x.shape[2:]) if pooled.shape[2:] == (1, 1) else
+                        F.interpolate(pooled, size=x.shape[2:], mode='bilinear', align_corners=True))
         x = self.relu(self.bn1(self.conv1(torch.cat(branches, dim=1))))
         return self.dropout(x)
 

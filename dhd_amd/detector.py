@@ -618,8 +618,10 @@ class DHD(nn.Module):
         return self
 
     def _enter(self, part, t):
-        """`t` in the layout of dense stack `part` (a copy only where the producer's layout differs)."""
-        return t.contiguous(memory_format=self._layout.get(part, torch.contiguous_format))
+        """`t` in the layout of dense stack `part` (NCHW for everything that is not a stack, e.g. 'mix'): a copy only where the
+        producer's layout differs, made by the library's tiled transpose, whose gradient returns in the producer's layout."""
+        from .layout import to_layout
+        return to_layout(t, self._layout.get(part, torch.contiguous_format))
 
     @property
     def with_img_neck(self):
@@ -683,7 +685,7 @@ class DHD(nn.Module):
         return x_2d, x_3d, None, depth, height
 
     def forward_occ_train(self, img_feats, voxel_semantics, mask_camera):
-        outs = self.occ_head(self._enter('occ_head', self.mix(torch.cat(img_feats, dim=1))))
+        outs = self.occ_head(self._enter('occ_head', self.mix(self._enter('mix', torch.cat(img_feats, dim=1)))))
         return self.occ_head.loss(outs, voxel_semantics, mask_camera)
 
     def forward_train(self, points=None, img_metas=None, img_inputs=None, **kwargs):
@@ -697,7 +699,7 @@ class DHD(nn.Module):
         return self.simple_test_occ([x_2d, x_3d], img_metas)
 
     def simple_test_occ(self, img_feats, img_metas=None):
-        outs = self.occ_head(self._enter('occ_head', self.mix(torch.cat(img_feats, dim=1))))
+        outs = self.occ_head(self._enter('occ_head', self.mix(self._enter('mix', torch.cat(img_feats, dim=1)))))
         return self.occ_head.get_occ(outs, img_metas)
 
     def forward(self, return_loss=True, **kwargs):

@@ -616,6 +616,13 @@ int dhd_upsample_bilinear_forward(const void* x, int dtype, int layout, int n, i
 int dhd_upsample_bilinear_backward(const void* grad_y, int dtype, int layout, int n, int c, int hin, int win,
                                    int hout, int wout, void* grad_x, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * 11. Layout conversion at the boundary between the NCHW operators above and dense stacks that run in
+ *     channels_last: batched transpose in[b][rows][cols] -> out[b][cols][rows] of 2- or 4-byte elements
+ *     (NCHW -> NHWC: rows = c, cols = h*w; NHWC -> NCHW: rows = h*w, cols = c).  in and out must not overlap.
+ * ------------------------------------------------------------------------------------ */
+int dhd_transpose_batched(const void* in, void* out, int elem_bytes, long batch, int rows, int cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

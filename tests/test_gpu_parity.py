@@ -1986,6 +1986,34 @@ def test_bilinear_upsample_forward_backward_vs_float64(gpu, dtype, eps, layout, 
         assert torch.allclose(y, yt, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16, torch.int32])
+@pytest.mark.parametrize('shape', [(2, 64, 20, 28), (3, 7, 5, 9), (1, 130, 65, 3), (2, 1, 8, 8), (4, 256, 1, 1), (2, 512, 100, 100)])
+def test_layout_conversion_is_a_pure_copy_in_both_directions(gpu, dtype, shape):
+    """dhd_amd.layout.to_layout (csrc/layout.hip): the same values as torch's `.contiguous(memory_format=...)` bit for bit, in the
+    requested format, NCHW -> channels_last -> NCHW; the gradient comes back in the producer's layout; partial tiles, one channel,
+    one pixel (both formats at once: returned as is)."""
+    from dhd_amd.layout import to_layout
+    torch.manual_seed(sum(shape))
+    x = (torch.randn(shape, device=gpu) * 100).to(dtype)
+    a = to_layout(x, torch.channels_last)
+    assert a.is_contiguous(memory_format=torch.channels_last) and torch.equal(a, x)
+    assert a.contiguous(memory_format=torch.channels_last).data_ptr() == a.data_ptr()
+    b = to_layout(a, torch.contiguous_format)
+    assert b.is_contiguous() and torch.equal(b, x)
+    if shape[1] == 1 or shape[2:] == (1, 1):
+        assert a is x and b is x
+    if dtype.is_floating_point:
+        for src, dst in ((torch.contiguous_format, torch.channels_last), (torch.channels_last, torch.contiguous_format)):
+            t = x.detach().clone(memory_format=torch.contiguous_format).contiguous(memory_format=src).detach().requires_grad_()
+            y = to_layout(t, dst)
+            g = torch.randn_like(x).contiguous(memory_format=dst)
+            (y * g).sum().backward()
+            assert torch.equal(t.grad, g)
+            if not (shape[1] == 1 or shape[2:] == (1, 1)):
+                assert t.grad.is_contiguous(memory_format=src)
+
+
 # ---------------------------------------------------------------------------------------------
 # SFA stage under nn.SyncBatchNorm (DHD-L.py:308-311 SyncbnControlHook): the phased operator, two ranks sharing cuda:0 over gloo
 # ---------------------------------------------------------------------------------------------
