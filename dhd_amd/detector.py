@@ -54,6 +54,11 @@ class Bottleneck(nn.Module):
         return self.bn3(self.conv3(out), residual=identity)
 
 
+# A/B switch: the configs' with_cp=True trades a second forward of the image backbone for activation memory (32 GB cards); on 288 GB it
+# only costs time.  The default keeps the configs' behaviour.
+_NO_CHECKPOINT = bool(__import__('os').environ.get('DHD_NO_CHECKPOINT'))
+
+
 @BACKBONES.register_module()
 class ResNet(nn.Module):
     """ResNet-50/101 trunk; returns the stages listed in out_indices."""
@@ -113,7 +118,7 @@ class ResNet(nn.Module):
         outs = []
         for i, name in enumerate(self.res_layers):
             layer = getattr(self, name)
-            if self.with_cp and x.requires_grad:
+            if self.with_cp and x.requires_grad and not _NO_CHECKPOINT:
                 for blk in layer:
                     x = checkpoint(blk, x, use_reentrant=False)
             else:
