@@ -1,7 +1,7 @@
 """One-off job (gpurun): MIOpen's exhaustive FIND over the convolution problems of the DHD-S training step, so that the user find-db
 it leaves can be committed (dhd_amd/miopen_db/) and later runs pick the measured-fastest solver in immediate mode instead of the
 heuristic's choice (this image ships no gfx950 find-db at all: /opt/rocm/share/miopen/db has none).  VERDICT r4 item 2b.
-usage: miopen_find_job.py <db dir> [fp16|fp32|both] [batch] [layout]      (layout as bench.py --layout; the db dir is seeded with the committed db)"""
+usage: miopen_find_job.py <db dir> [fp16|bf16|fp32|both] [batch] [layout] [model]      (layout as bench.py --layout; the db dir is seeded with the committed db)"""
 import os, sys, time
 db = os.path.abspath(sys.argv[1])
 os.makedirs(db, exist_ok=True)
@@ -14,10 +14,11 @@ import bench
 which = sys.argv[2] if len(sys.argv) > 2 else 'both'
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 layout = sys.argv[4] if len(sys.argv) > 4 else 'nchw'
+model = sys.argv[5] if len(sys.argv) > 5 else 'dhd-s'
 dev = torch.device('cuda:0')
-for amp in (('fp16', 'off') if which == 'both' else (('fp16',) if which == 'fp16' else ('off',))):
+for amp in (('fp16', 'off') if which == 'both' else (('off',) if which == 'fp32' else (which,))):
     t0 = time.time()
-    job = bench.EndToEnd(dev, batch, 1000, 1, amp, 'dhd-s', True, graph=False, layout=layout)
+    job = bench.EndToEnd(dev, batch, 1000, 1, amp, model, True, graph=False, layout=layout)
     for i in range(2):
         job.step(False)
         torch.cuda.synchronize()

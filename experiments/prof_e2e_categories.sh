@@ -12,14 +12,14 @@ rows = list(csv.DictReader(open(f)))
 t_end = max(int(r['End_Timestamp']) for r in rows)
 win = float(os.environ.get('WIN', '0.35')) * 1e9
 cats = [('convolution / GEMM (MFMA)', r'igemm|Cijk_|Winograd|SP3AsmConv|miopenSp3AsmConv|gemm|xdlops|Conv.*Xdl|naive_conv|wrw|DeviceGroupedConv|kernel_grouped_conv'),
-        ('layout transposes around NHWC solvers', r'batched_transpose|transpose_'),
-        ('batch norm (MIOpen + dhd bn kernels)', r'BatchNorm|bn_affine|bn_train|bn_bwd|bn_stat'),
+        ('layout transposes around NHWC solvers (MIOpen) + NCHW <-> channels_last at the operators (transpose_batched)', r'batched_transpose|transpose_'),
+        ('batch norm (MIOpen + dhd bn kernels)', r'BatchNorm|bn_affine|bn_train|bn_bwd|bn_stat|bn_plane|bn_cl_|bn_forward|bn_backward'),
         ('casts half <-> float', r'float16_copy|float16tofloat32|bfloat16_copy|copy_kernel'),
-        ('dhd_amd HIP kernels (MGHS, SFA stage, losses, EMA)', r'mghs_|pw_gemm|pw_wgrad|blend|plane_mean|pair_sums|stage_gx|fc_forward|fc_backward|wgrad_reduce|occ_loss|label_|bin_bce|ema_update|deform_|bev_pool|lift|scan|sparse_bin'),
+        ('dhd_amd HIP kernels (MGHS, SFA stage, losses, EMA)', r'mghs_|pw_gemm|pw_wgrad|blend|plane_mean|pair_sums|stage_gx|fc_forward|fc_backward|wgrad_reduce|occ_loss|label_|bin_bce|ema_update|deform_|bev_pool|lift|scan|sparse_bin|up_fwd_|up_bwd_'),
         ('optimizer / grad clip (multi-tensor)', r'multi_tensor|FusedOptimizer|Lamb|adam'),
+        ('pooling / upsample / pad (torch)', r'pool|upsample|pad'),
         ('float32 element-wise / reductions', r'<float|float,|c10::Half, float'),
-        ('half element-wise / reductions', r'c10::Half|__half|BFloat16'),
-        ('pooling / upsample / pad', r'pool|upsample|pad')]
+        ('half element-wise / reductions', r'c10::Half|__half|BFloat16')]
 acc = collections.OrderedDict((c, [0, 0.0]) for c, _ in cats)
 acc['other'] = [0, 0.0]
 tot = 0.0
