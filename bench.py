@@ -325,8 +325,8 @@ class EndToEnd:
         # Measured per dense stack on MI355X with the committed find-db, DHD-S fp16 step (docs/LAB_NOTEBOOK.md R5.5): NCHW 65.9 ms;
         # image encoder in channels_last 59.9; + UNets + head 59.5; + the library's NHWC BatchNorm(+ReLU) 57.1; + its bilinear
         # upsample kernels 56.5; + the BEV encoder (which lost 3.2 ms in channels_last on torch's NHWC upsample backward) 55.1.
-        # float32 and the other models stay NCHW (the find-db holds no NHWC entries for their problems).
-        default = 'channels_last' if (model == 'dhd-s' and amp != 'off') else 'nchw'
+        # float32 (with its own NHWC find-db entries): 143.7 -> 127.9 ms.  The other models stay NCHW (the find-db holds DHD-S problems only).
+        default = 'channels_last' if model == 'dhd-s' else 'nchw'
         self.layout = layout or os.environ.get('DHD_E2E_LAYOUT') or default
         if self.layout.startswith('channels_last'):          # 'channels_last' or 'channels_last:part,part' (detector.use_channels_last)
             parts = self.layout.partition(':')[2]
