@@ -325,9 +325,10 @@ class EndToEnd:
         # Measured per dense stack on MI355X with the committed find-db, DHD-S fp16 step (docs/LAB_NOTEBOOK.md R5.5): NCHW 65.9 ms;
         # image encoder in channels_last 59.9; + UNets + head 59.5; + the library's NHWC BatchNorm(+ReLU) 57.1; + its bilinear
         # upsample kernels 56.5; + the BEV encoder (which lost 3.2 ms in channels_last on torch's NHWC upsample backward) 55.1.
-        # float32 (with its own NHWC find-db entries): 143.7 -> 127.9 ms.  DHD-L stays NCHW (no find-db entries for its problems).
+        # float32 (with its own NHWC find-db entries): 143.7 -> 127.9 ms.
         # DHD-M fp16 B = 3 with find-db entries for its NHWC problems (experiments/e2e_dhdm_layout_ab.sh): 140.8 -> 122.4 ms.
-        default = 'channels_last' if (model == 'dhd-s' or (model == 'dhd-m' and amp == 'fp16')) else 'nchw'
+        # DHD-L bf16 B = 2 (Swin-B: the convolutions are the smaller part): heuristics 379.1 -> find-db NCHW 362.1 -> channels_last 356.1 ms.
+        default = 'channels_last' if (model == 'dhd-s' or (model, amp) in (('dhd-m', 'fp16'), ('dhd-l', 'bf16'))) else 'nchw'
         self.layout = layout or os.environ.get('DHD_E2E_LAYOUT') or default
         if self.layout.startswith('channels_last'):          # 'channels_last' or 'channels_last:part,part' (detector.use_channels_last)
             parts = self.layout.partition(':')[2]
