@@ -338,6 +338,54 @@ def test_batchnorm2d_subclass_is_transparent_off_the_gpu():
     assert isinstance(conv[0], torch.nn.SyncBatchNorm)
 
 
+def test_batchnorm_relu_and_residual_arguments_off_the_gpu():
+    """BatchNorm2d.forward(x, relu=..., residual=...): off the GPU (and in eval mode) the ReLU / residual add + ReLU are applied with
+    torch operators after the parent's normalisation -- the same values and gradients as the reference's module code
+    `relu(bn(x))` / `relu(bn(x) + identity)` (resnet.py Bottleneck.forward); the callers that use it keep their state-dict keys."""
+    import copy
+    from dhd_amd.batchnorm import BatchNorm2d
+    from dhd_amd.detector import Bottleneck
+    torch.manual_seed(1)
+    for layout in (torch.contiguous_format, torch.channels_last):
+        a = BatchNorm2d(8).train()
+        b = copy.deepcopy(a)
+        x = torch.randn(3, 8, 5, 7).contiguous(memory_format=layout).requires_grad_()
+        r = torch.randn(3, 8, 5, 7).requires_grad_()
+        xr, rr = x.detach().clone().requires_grad_(), r.detach().clone().requires_grad_()
+        ya, yb = a(x, relu=True), torch.relu(torch.nn.BatchNorm2d.forward(b, xr))
+        za, zb = a(x, residual=r), torch.relu(torch.nn.BatchNorm2d.forward(b, xr) + rr)
+        assert torch.equal(ya, yb) and torch.equal(za, zb)
+        (ya.sum() + (za * za).sum()).backward()
+        (yb.sum() + (zb * zb).sum()).backward()
+        assert torch.allclose(x.grad, xr.grad, atol=1e-6) and torch.allclose(r.grad, rr.grad, atol=1e-6)
+        assert torch.equal(a.running_mean, b.running_mean) and int(a.num_batches_tracked) == int(b.num_batches_tracked) == 2
+        a.eval(), b.eval()
+        assert torch.equal(a(x, residual=r), torch.relu(b(xr) + rr))
+    blk = Bottleneck(16, 4)
+    assert [k for k, _ in blk.named_parameters()] == ['conv1.weight', 'bn1.weight', 'bn1.bias', 'conv2.weight', 'bn2.weight', 'bn2.bias',
+                                                       'conv3.weight', 'bn3.weight', 'bn3.bias']
+    y = blk(torch.randn(2, 16, 6, 6))
+    assert y.shape == (2, 16, 6, 6) and float(y.detach().min()) >= 0.0
+
+
+def test_to_layout_off_the_gpu_and_its_gradient_layout():
+    """dhd_amd.layout.to_layout on CPU tensors (torch's copy): values unchanged, the requested format, identity when the tensor
+    already has it (or has both: one channel / one pixel), and the gradient handed back in the PRODUCER's layout."""
+    from dhd_amd.layout import to_layout, _format_of
+    cl, nchw = torch.channels_last, torch.contiguous_format
+    x = torch.randn(2, 6, 4, 5)
+    y = to_layout(x, cl)
+    assert _format_of(y) == cl and torch.equal(x, y) and to_layout(y, cl) is y and to_layout(x, nchw) is x
+    assert _format_of(torch.randn(2, 1, 4, 5)) == 'both' and to_layout(torch.randn(2, 6, 1, 1), cl).is_contiguous()
+    assert _format_of(x[:, ::2]) is None and _format_of(torch.randn(3, 4)) is None
+    assert to_layout(x[:, ::2], cl).is_contiguous(memory_format=cl)
+    for src, dst in ((nchw, cl), (cl, nchw)):
+        t = torch.randn(2, 6, 4, 5).contiguous(memory_format=src).requires_grad_()
+        g = torch.randn(2, 6, 4, 5).contiguous(memory_format=dst)
+        (to_layout(t, dst) * g).sum().backward()
+        assert torch.equal(t.grad, g) and _format_of(t.grad) == src
+
+
 def test_batchnorm_deferred_counters_match_the_per_layer_updates():
     """batchnorm.defer_counters / flush_counters (the detector's one-launch-per-step update of every `num_batches_tracked`): outputs,
     running statistics and the counters after a flush equal those of plain nn.BatchNorm2d behaviour -- also for a layer that is
