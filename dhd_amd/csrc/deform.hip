@@ -174,71 +174,17 @@ int dhd_deform_col2im(const float* dcol, const float* x, const float* offset, fl
 //     out = softmax_d(-cost)
 // The reference runs C/4 grid_sample calls over (BN, 4, D*H, W) tensors plus sub/abs/sum passes (29 % of a
 // DHD-M training step on this GPU).  Here: features in NHWC, one wave per pixel: the current feature lives in
-// registers (lane = 4 channels), each hypothesis costs four 1-KB tap loads, a DPP wave reduction, and the
-// softmax over the D hypotheses is done in the same wave.  No gradient (the reference wraps it in no_grad).
+// registers (lane = 4 channels), each hypothesis costs up to four 1-KB tap loads (a register cache keeps the taps of the
+// previous hypothesis: see the kernel), a DPP wave reduction, and the softmax over the D hypotheses is done in the same wave.  No gradient (the reference wraps it in no_grad).
 // ------------------------------------------------------------------------------------------------
 namespace {
 
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 constexpr int kCvMaxD = 256;
 
-__global__ __launch_bounds__(kBlock) void stereo_cost_volume_kernel(const float* __restrict__ prev, const float* __restrict__ curr,
-                                                                    const float* __restrict__ grid, int c, int h, int w, int nd,
-                                                                    float bias, int flag_channel, float* __restrict__ out, int n_pix) {
-  const int lane = threadIdx.x & 63;
-  const int pix = blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6);  // (bn, y, x)
-  if (pix >= n_pix) return;
-  const int hw = h * w;
-  const int bn = pix / hw, yx = pix % hw;
-  const int c4 = c >> 2;                       // float4 groups per pixel
-  const float* pb = prev + (size_t)bn * hw * c;
-  // this lane's channels: groups lane, lane + 64, ...
-  f32x4_t cur[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int g = lane + 64 * q;
-    cur[q] = g < c4 ? reinterpret_cast<const f32x4_t*>(curr + (size_t)pix * c)[g] : f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-  const int flag_group = flag_channel >> 2, flag_comp = flag_channel & 3;
-  float mine[kCvMaxD / DHD_WAVE];  // cost of hypothesis d lives in lane d % 64, register d / 64
-#pragma unroll
-  for (int q = 0; q < kCvMaxD / DHD_WAVE; ++q) mine[q] = 3.0e38f;
-  const float* gp = grid + ((size_t)bn * nd * hw + yx) * 2;
-  for (int d0 = 0; d0 < nd; d0 += DHD_WAVE) {
-    // lane l fetches the sampling position of hypothesis d0 + l
-    float gx = 0.f, gy = 0.f;
-    if (d0 + lane < nd) {
-      const float2 g2 = *reinterpret_cast<const float2*>(gp + (size_t)(d0 + lane) * hw * 2);
-      gx = g2.x; gy = g2.y;
-    }
-    const int nb = min(DHD_WAVE, nd - d0);
-    for (int i = 0; i < nb; ++i) {
-      const float px = (__shfl(gx, i, DHD_WAVE) + 1.0f) * 0.5f * (float)(w - 1);   // align_corners=True
-      const float py = (__shfl(gy, i, DHD_WAVE) + 1.0f) * 0.5f * (float)(h - 1);
-      const Tap tp = make_tap(py, px, h, w);
-      float acc = 0.f, flag = 1.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int g = lane + 64 * q;
-        if (g >= c4) break;
-        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-        if (tp.v00) s += tp.w00 * reinterpret_cast<const f32x4_t*>(pb + (size_t)tp.i00 * c)[g];
-        if (tp.v01) s += tp.w01 * reinterpret_cast<const f32x4_t*>(pb + (size_t)tp.i01 * c)[g];
-        if (tp.v10) s += tp.w10 * reinterpret_cast<const f32x4_t*>(pb + (size_t)tp.i10 * c)[g];
-        if (tp.v11) s += tp.w11 * reinterpret_cast<const f32x4_t*>(pb + (size_t)tp.i11 * c)[g];
-        const f32x4_t df = cur[q] - s;
-        acc += (fabsf(df.x) + fabsf(df.y)) + (fabsf(df.z) + fabsf(df.w));
-        if (g == flag_group) flag = s[flag_comp];
-      }
-      float tot = wave_sum_bcast(acc);
-      if (bias != 0.f) {
-        const float fv = __shfl(flag, flag_group & 63, DHD_WAVE);
-        if (fv == 0.f) tot += bias;
-      }
-      if (lane == i) mine[d0 >> 6] = tot;
-    }
-  }
-  // softmax over the hypotheses of -cost: lanes/registers without a hypothesis hold +3e38 -> exp(-inf) = 0
+// softmax over the hypotheses of -cost (hypothesis d in lane d % 64, register d / 64); registers without a hypothesis hold +3e38
+__device__ __forceinline__ void cv_softmax_store(const float (&mine)[kCvMaxD / DHD_WAVE], float* __restrict__ out, int bn, int nd, int hw,
+                                                 int yx, int lane) {
   float mn = mine[0];
 #pragma unroll
   for (int q = 1; q < kCvMaxD / DHD_WAVE; ++q) mn = fminf(mn, mine[q]);
@@ -259,6 +205,205 @@ __global__ __launch_bounds__(kBlock) void stereo_cost_volume_kernel(const float*
   }
 }
 
+
+// Round 5.  The first version computed every hypothesis' sampling cell in all 64 lanes (a wave-uniform value) and reduced the
+// cost over the wave once per hypothesis: ~100 VALU instructions per hypothesis, and with 128 channels half of the lanes idle --
+// 7.5 ms at the DHD-L stereo size even when every tap hits the same position (experiments/cost_volume_bench.py), 9.6 ms in the
+// model.  Now: (1) lane l computes the cell (four flat indices, -1 = outside, and four weights) of hypothesis d0 + l, 64
+// hypotheses at once; the hypothesis loop only broadcasts them; (2) the taps of the previous hypothesis stay in registers keyed
+// by their index (consecutive hypotheses walk along the epipolar line in sub-pixel steps for all but the nearest bins);
+// (3) PAIR mode for c <= 128: the two halves of the wave take two hypotheses per step.  The arithmetic of a hypothesis and its
+// order (tap order, the DPP reduction tree) are those of the first version.  DHD-L stereo size, c = 128: 7.5 -> 3.5 ms with every
+// tap in one place, 9.1 -> 4.4 ms for a half-pixel walk; in the DHD-L step 9.6 -> 4.3 ms per call, DHD-M (c = 256) 3.25 -> 2.7.
+struct CellRegs {
+  int idx[4];
+  float wt[4];
+};
+
+__device__ __forceinline__ CellRegs lane_cell(const float* __restrict__ gp, int d, int nd, int hw, int h, int w) {
+  CellRegs r;
+  float gx = 0.f, gy = 0.f;
+  const bool have = d < nd;
+  if (have) {
+    const float2 g2 = *reinterpret_cast<const float2*>(gp + (size_t)d * hw * 2);
+    gx = g2.x; gy = g2.y;
+  }
+  const float px = (gx + 1.0f) * 0.5f * (float)(w - 1);   // align_corners=True
+  const float py = (gy + 1.0f) * 0.5f * (float)(h - 1);
+  const Tap tp = make_tap(py, px, h, w);
+  r.idx[0] = have && tp.v00 ? tp.i00 : -1;
+  r.idx[1] = have && tp.v01 ? tp.i01 : -1;
+  r.idx[2] = have && tp.v10 ? tp.i10 : -1;
+  r.idx[3] = have && tp.v11 ? tp.i11 : -1;
+  r.wt[0] = tp.w00; r.wt[1] = tp.w01; r.wt[2] = tp.w10; r.wt[3] = tp.w11;
+  return r;
+}
+
+__device__ __forceinline__ float pick(const f32x4_t& v, int comp) {
+  return comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
+}
+
+// one hypothesis per step, all lanes on its channels (c > 128): Q 16-byte channel groups per lane
+template <int Q>
+__global__ __launch_bounds__(kBlock) void stereo_cost_volume_kernel(const float* __restrict__ prev, const float* __restrict__ curr,
+                                                                    const float* __restrict__ grid, int c, int h, int w, int nd,
+                                                                    float bias, int flag_channel, float* __restrict__ out, int n_pix) {
+  const int lane = threadIdx.x & 63;
+  const int pix = blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6);  // (bn, y, x)
+  if (pix >= n_pix) return;
+  const int hw = h * w;
+  const int bn = pix / hw, yx = pix % hw;
+  const int c4 = c >> 2;                       // float4 groups per pixel
+  const float* pb = prev + (size_t)bn * hw * c;
+  f32x4_t cur[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int g = lane + 64 * q;
+    cur[q] = g < c4 ? reinterpret_cast<const f32x4_t*>(curr + (size_t)pix * c)[g] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const int flag_group = flag_channel >> 2, flag_comp = flag_channel & 3;
+  float mine[kCvMaxD / DHD_WAVE];  // cost of hypothesis d lives in lane d % 64, register d / 64
+#pragma unroll
+  for (int q = 0; q < kCvMaxD / DHD_WAVE; ++q) mine[q] = 3.0e38f;
+  const float* gp = grid + ((size_t)bn * nd * hw + yx) * 2;
+  f32x4_t cache[4][Q];
+  int cidx[4] = {-1, -1, -1, -1};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) cache[k][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int d0 = 0; d0 < nd; d0 += DHD_WAVE) {
+    const CellRegs cell = lane_cell(gp, d0 + lane, nd, hw, h, w);
+    const int nb = min(DHD_WAVE, nd - d0);
+    for (int i = 0; i < nb; ++i) {
+      int nidx[4];
+      float wt[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        nidx[k] = __builtin_amdgcn_readlane(cell.idx[k], i);
+        wt[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cell.wt[k]), i));
+      }
+      if (nidx[0] != cidx[0] || nidx[1] != cidx[1] || nidx[2] != cidx[2] || nidx[3] != cidx[3]) {
+        f32x4_t nv[4][Q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int want = nidx[k];
+          if (want < 0) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) nv[k][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          } else if (want == cidx[0]) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) nv[k][q] = cache[0][q];
+          } else if (want == cidx[1]) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) nv[k][q] = cache[1][q];
+          } else if (want == cidx[2]) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) nv[k][q] = cache[2][q];
+          } else if (want == cidx[3]) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) nv[k][q] = cache[3][q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+              const int g = lane + 64 * q;
+              nv[k][q] = g < c4 ? reinterpret_cast<const f32x4_t*>(pb + (size_t)want * c)[g] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          cidx[k] = nidx[k];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) cache[k][q] = nv[k][q];
+        }
+      }
+      float acc = 0.f, flag = 1.f;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int g = lane + 64 * q;
+        if (g >= c4) break;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (cidx[k] >= 0) s += wt[k] * cache[k][q];
+        const f32x4_t df = cur[q] - s;
+        acc += (fabsf(df.x) + fabsf(df.y)) + (fabsf(df.z) + fabsf(df.w));
+        if (g == flag_group) flag = pick(s, flag_comp);
+      }
+      float tot = wave_sum_bcast(acc);
+      if (bias != 0.f) {
+        const float fv = __shfl(flag, flag_group & 63, DHD_WAVE);
+        if (fv == 0.f) tot += bias;
+      }
+      if (lane == i) mine[d0 >> 6] = tot;
+    }
+  }
+  cv_softmax_store(mine, out, bn, nd, hw, yx, lane);
+}
+
+// PAIR mode (c <= 128: at most 32 channel groups): lanes 0-31 take hypothesis 2 j, lanes 32-63 hypothesis 2 j + 1 of a step
+__global__ __launch_bounds__(kBlock) void stereo_cost_volume_pair_kernel(const float* __restrict__ prev, const float* __restrict__ curr,
+                                                                         const float* __restrict__ grid, int c, int h, int w, int nd,
+                                                                         float bias, int flag_channel, float* __restrict__ out,
+                                                                         int n_pix) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, g = lane & 31;
+  const int pix = blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6);
+  if (pix >= n_pix) return;
+  const int hw = h * w;
+  const int bn = pix / hw, yx = pix % hw;
+  const int c4 = c >> 2;
+  const bool live = g < c4;
+  const float* pb = prev + (size_t)bn * hw * c + 4 * g;
+  const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4_t cur = live ? reinterpret_cast<const f32x4_t*>(curr + (size_t)pix * c)[g] : zero;
+  const int flag_group = flag_channel >> 2, flag_comp = flag_channel & 3;
+  float mine[kCvMaxD / DHD_WAVE];
+#pragma unroll
+  for (int q = 0; q < kCvMaxD / DHD_WAVE; ++q) mine[q] = 3.0e38f;
+  const float* gp = grid + ((size_t)bn * nd * hw + yx) * 2;
+  f32x4_t cache[4] = {zero, zero, zero, zero};
+  int cidx[4] = {-1, -1, -1, -1};
+  for (int d0 = 0; d0 < nd; d0 += DHD_WAVE) {
+    const CellRegs cell = lane_cell(gp, d0 + lane, nd, hw, h, w);
+    const int nb = min(DHD_WAVE, nd - d0);
+    for (int i = 0; i < nb; i += 2) {
+      const int src = i + half;                 // the lane that holds this half's hypothesis (beyond nb: every index -1)
+      f32x4_t s = zero;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int want = __shfl(cell.idx[k], src, DHD_WAVE);
+        const float wk = __shfl(cell.wt[k], src, DHD_WAVE);
+        if (want != cidx[k]) {                   // per lane: the halves walk their own lines
+          cache[k] = (want >= 0 && live) ? *reinterpret_cast<const f32x4_t*>(pb + (size_t)want * c) : zero;
+          cidx[k] = want;
+        }
+        if (want >= 0) s += wk * cache[k];
+      }
+      const f32x4_t df = cur - s;
+      float acc = live ? (fabsf(df.x) + fabsf(df.y)) + (fabsf(df.z) + fabsf(df.w)) : 0.f;
+      // the first five steps of wave_sum_bcast: lane 31 = sum of lanes 0-31, lane 63 = sum of lanes 32-63
+      acc = dpp_add<0xB1, 0xf>(acc);
+      acc = dpp_add<0x4E, 0xf>(acc);
+      acc = dpp_add<0x114, 0xf>(acc);
+      acc = dpp_add<0x118, 0xf>(acc);
+      acc = dpp_add<0x142, 0xa>(acc);
+      float ta = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 31));
+      float tb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));
+      if (bias != 0.f) {
+        const float flag = pick(s, flag_comp);
+        const float fa = __shfl(flag, flag_group & 31, DHD_WAVE);
+        const float fb = __shfl(flag, 32 + (flag_group & 31), DHD_WAVE);
+        if (fa == 0.f) ta += bias;
+        if (fb == 0.f) tb += bias;
+      }
+      if (lane == i) mine[d0 >> 6] = ta;
+      if (lane == i + 1 && i + 1 < nb) mine[d0 >> 6] = tb;
+    }
+  }
+  cv_softmax_store(mine, out, bn, nd, hw, yx, lane);
+}
+
 }  // namespace
 
 extern "C" int dhd_stereo_cost_volume(const float* prev_nhwc, const float* curr_nhwc, const float* grid, int bn, int c, int h, int w,
@@ -267,8 +412,16 @@ extern "C" int dhd_stereo_cost_volume(const float* prev_nhwc, const float* curr_
   if ((c & 3) != 0 || c > 1024 || n_depth > kCvMaxD || flag_channel < 0 || flag_channel >= c) return DHD_EUNSUPPORTED;
   const long n_pix = (long)bn * h * w;
   if (n_pix >= (1L << 31) / n_depth) return DHD_EUNSUPPORTED;
-  hipLaunchKernelGGL(stereo_cost_volume_kernel, dim3(dhd_cdiv(n_pix, kBlock / DHD_WAVE)), dim3(kBlock), 0, dhd_stream(stream), prev_nhwc,
-                     curr_nhwc, grid, c, h, w, n_depth, bias, flag_channel, out, (int)n_pix);
+  const dim3 blocks(dhd_cdiv(n_pix, kBlock / DHD_WAVE)), threads(kBlock);
+  hipStream_t st = dhd_stream(stream);
+  const int q = ((c >> 2) + DHD_WAVE - 1) / DHD_WAVE;   // 16-byte channel groups per lane
+#define DHD_CV(K) hipLaunchKernelGGL(K, blocks, threads, 0, st, prev_nhwc, curr_nhwc, grid, c, h, w, n_depth, bias, flag_channel, out, (int)n_pix)
+  if ((c >> 2) <= 32) DHD_CV(stereo_cost_volume_pair_kernel);
+  else if (q <= 1) DHD_CV(stereo_cost_volume_kernel<1>);
+  else if (q == 2) DHD_CV(stereo_cost_volume_kernel<2>);
+  else if (q == 3) DHD_CV(stereo_cost_volume_kernel<3>);
+  else DHD_CV(stereo_cost_volume_kernel<4>);
+#undef DHD_CV
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }

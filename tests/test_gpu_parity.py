@@ -1741,15 +1741,28 @@ def test_dcn_hip_sampling_vs_grid_sample_formulation(gpu, c, groups, h, w, dil, 
 
 # --------------------------------------------------------------------------- stereo cost volume (DHD-M / DHD-L DepthNet)
 
-@pytest.mark.parametrize('bn,c,h,w,d,bias', [(2, 16, 6, 10, 8, 5.0), (3, 256, 16, 44, 88, 5.0), (1, 64, 9, 13, 70, 0.0)])
-def test_stereo_cost_volume_vs_grid_sample_formulation(gpu, bn, c, h, w, d, bias):
+@pytest.mark.parametrize('bn,c,h,w,d,bias', [(2, 16, 6, 10, 8, 5.0), (3, 256, 16, 44, 88, 5.0), (1, 64, 9, 13, 70, 0.0),
+                                             (2, 128, 9, 13, 71, 0.7), (1, 132, 6, 9, 65, 0.3), (1, 520, 5, 6, 9, 0.5)])
+@pytest.mark.parametrize('walk', [False, True])
+def test_stereo_cost_volume_vs_grid_sample_formulation(gpu, bn, c, h, w, d, bias, walk):
     """dhd_stereo_cost_volume against the reference's formulation (C/4 grid_sample calls + |diff| sums + bias where the
-    last group's first channel sampled 0 + softmax over depth, depthnet.py:307-361), incl. samples outside the image."""
+    last group's first channel sampled 0 + softmax over depth, depthnet.py:307-361), incl. samples outside the image.
+    Random sampling positions (every tap a fresh load) and `walk`: hypothesis k sits 0.37 k pixels along a line from the pixel
+    itself, leaving the image for the later ones (the kernel keeps the previous hypothesis' taps in registers and reuses them
+    by index).  Channel counts: the pair mode (c <= 128: two hypotheses per step) and 1 / 3 channel groups per lane."""
     from dhd_amd.depthnet import DepthNet
     torch.manual_seed(bn + c)
     dn = DepthNet(32, 32, 16, d, use_dcn=False, aspp_mid_channels=16, stereo=True, bias=bias).to(gpu)
     prev, curr = torch.randn(bn, c, h, w, device=gpu), torch.randn(bn, c, h, w, device=gpu)
-    grid = torch.rand(bn, d * h, w, 2, device=gpu) * 2.6 - 1.3       # ~20 % of the samples fall outside
+    if walk:
+        ys, xs = torch.meshgrid(torch.linspace(-1, 1, h, device=gpu), torch.linspace(-1, 1, w, device=gpu), indexing='ij')
+        k = torch.arange(d, device=gpu, dtype=torch.float32).view(1, d, 1, 1)
+        sign = torch.tensor([1.0, -1.0, 0.5], device=gpu)[:bn].view(bn, 1, 1, 1) if bn <= 3 else 1.0
+        gx = xs.view(1, 1, h, w) + sign * k * 0.37 * 2 / (w - 1)
+        gy = ys.view(1, 1, h, w) - k * 0.21 * 2 / (h - 1)
+        grid = torch.stack([gx.expand(bn, d, h, w), gy.expand(bn, d, h, w)], -1).reshape(bn, d * h, w, 2).contiguous()
+    else:
+        grid = torch.rand(bn, d * h, w, 2, device=gpu) * 2.6 - 1.3   # ~20 % of the samples fall outside
     grid[0, :w] = -2.0                                               # the "behind the camera" marker of gen_grid
     got = dn._hip_cost_volume(prev, curr, grid, d, (c // 4 - 1) * 4)
     cost, warped = 0, None
