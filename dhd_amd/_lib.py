@@ -151,6 +151,7 @@ _PROTOTYPES = {
     'dhd_bn_train_forward': ([_P, _I, _I, _I, _I, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P], _I),
     'dhd_bn_train_backward': ([_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     'dhd_transpose_batched': ([_P, _P, _I, C.c_long, _I, _I, _P], _I),
+    'dhd_window_rows': ([_P, _P] + [_I] * 9 + [_P], _I),
     'dhd_upsample_bilinear_supported': ([_I] * 8, _I),
     'dhd_upsample_bilinear_forward': ([_P] + [_I] * 8 + [_P, _P], _I),
     'dhd_upsample_bilinear_backward': ([_P] + [_I] * 8 + [_P, _P], _I),

@@ -142,6 +142,39 @@ def shift_window_mask(H_pad, W_pad, window, shift, device):
     return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
 
 
+_WIN_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+_PLAIN_WINDOWS = bool(__import__('os').environ.get('DHD_PLAIN_WINDOWS'))   # A/B switch: F.pad + torch.roll + permute copies
+
+
+class _WindowRows(torch.autograd.Function):
+    """csrc/window.hip: pad + cyclic shift + window partition (reverse=False), or its inverse (reverse=True), as one row gather;
+    the gradient of either is the other one applied to the incoming gradient.  `out_dtype` lets the partition emit the autocast
+    dtype the qkv projection would cast its input to anyway (its gradient comes back in the input's dtype)."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, ws, sh, reverse, out_dtype):
+        from . import _lib
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        nh, nw = -(-H // ws), -(-W // ws)
+        shape = (B, H, W, C) if reverse else (B, nh * nw, ws * ws, C)
+        with torch.cuda.device(x.device):
+            out = torch.empty(shape, dtype=out_dtype, device=x.device)
+            _lib.check(_lib.load().dhd_window_rows(_lib.ptr(x), _lib.ptr(out), _WIN_DTYPES[x.dtype], _WIN_DTYPES[out_dtype], B, H, W, C, ws, sh,
+                                                   int(reverse), _lib.stream_ptr(x.device)), 'dhd_window_rows')
+        ctx.args = (H, W, ws, sh, reverse, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W, ws, sh, reverse, in_dtype = ctx.args
+        return _WindowRows.apply(g, H, W, ws, sh, not reverse, in_dtype), None, None, None, None, None, None
+
+
+def _windows_on_gpu(x):
+    return (not _PLAIN_WINDOWS) and x.is_cuda and x.dtype in _WIN_DTYPES and x.shape[-1] % 8 == 0
+
+
 class ShiftWindowMSA(nn.Module):
     """swin.py:353-513."""
 
@@ -159,6 +192,23 @@ class ShiftWindowMSA(nn.Module):
         ws, sh = self.window_size, self.shift_size
         x = query.view(B, H, W, C)
         pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+        if _windows_on_gpu(x):
+            # the same data movement as below in two launches instead of six copies (csrc/window.hip); under autocast the
+            # windows leave in the dtype the qkv projection casts its input to, and come back in the projection's dtype
+            mask = None
+            if sh > 0:
+                key = (H + pad_b, W + pad_r, ws, sh, x.device)
+                if masks is None:
+                    mask = shift_window_mask(H + pad_b, W + pad_r, ws, sh, x.device)
+                else:
+                    if key not in masks:
+                        masks[key] = shift_window_mask(H + pad_b, W + pad_r, ws, sh, x.device)
+                    mask = masks[key]
+            odt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() and x.dtype == torch.float32 else x.dtype
+            win = _WindowRows.apply(x, H, W, ws, sh, False, odt)
+            win = self.w_msa(win, mask)
+            x = _WindowRows.apply(win, H, W, ws, sh, True, win.dtype)
+            return self.drop(x.view(B, H * W, C))
         if pad_r or pad_b:
             x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
         Hp, Wp = H + pad_b, W + pad_r

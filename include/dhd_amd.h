@@ -623,6 +623,16 @@ int dhd_upsample_bilinear_backward(const void* grad_y, int dtype, int layout, in
  * ------------------------------------------------------------------------------------ */
 int dhd_transpose_batched(const void* in, void* out, int elem_bytes, long batch, int rows, int cols, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * 12. Shifted-window partition / reverse of the Swin backbone (DHD-L; backbones/swin.py:448-513: F.pad + torch.roll +
+ *     permute-reshape, and their inverses) as one row gather each way.  Token map (b, h, w, c) <-> windows
+ *     (b, nh*nw, window*window, c) with nh = ceil(h / window), nw = ceil(w / window); reverse = 0: partition (padding rows
+ *     are zeros), 1: reverse (padding rows dropped).  c a multiple of 8; in / out dtypes as in section 9 and may differ
+ *     (float32 LayerNorm output -> autocast dtype; half gradients -> float32).  Each direction is the other's transpose.
+ * ------------------------------------------------------------------------------------ */
+int dhd_window_rows(const void* in, void* out, int in_dtype, int out_dtype, int b, int h, int w, int c, int window,
+                    int shift, int reverse, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

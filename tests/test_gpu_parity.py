@@ -2027,6 +2027,57 @@ def test_layout_conversion_is_a_pure_copy_in_both_directions(gpu, dtype, shape):
                 assert t.grad.is_contiguous(memory_format=src)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,H,W,C,ws,sh', [(2, 14, 21, 32, 7, 3), (1, 16, 23, 64, 7, 0), (3, 7, 7, 8, 7, 3), (2, 32, 88, 128, 7, 3), (1, 5, 9, 16, 4, 2)])
+def test_swin_window_rows_equal_pad_roll_partition(gpu, dtype, B, H, W, C, ws, sh):
+    """csrc/window.hip against the reference's sequence (swin.py:448-513): F.pad -> torch.roll(-shift) -> window partition, and
+    window reverse -> torch.roll(+shift) -> crop; values bit for bit, gradients too (each direction is the other's transpose);
+    with a float32 input and a bfloat16 output the values are the cast of the same rows."""
+    import torch.nn.functional as F
+    from dhd_amd.swin import _WindowRows
+    torch.manual_seed(H * W + C)
+    x = torch.randn(B, H, W, C, device=gpu).to(dtype).requires_grad_()
+    pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+    Hp, Wp = H + pad_b, W + pad_r
+    nh, nw = Hp // ws, Wp // ws
+
+    def ref_partition(t):
+        t = F.pad(t, (0, 0, 0, pad_r, 0, pad_b))
+        if sh:
+            t = torch.roll(t, shifts=(-sh, -sh), dims=(1, 2))
+        return t.view(B, nh, ws, nw, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, nh * nw, ws * ws, C)
+
+    def ref_reverse(win):
+        t = win.view(B, nh, nw, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+        if sh:
+            t = torch.roll(t, shifts=(sh, sh), dims=(1, 2))
+        return t[:, :H, :W].contiguous()
+
+    win = _WindowRows.apply(x, H, W, ws, sh, False, dtype)
+    xr = x.detach().clone().requires_grad_()
+    win_r = ref_partition(xr)
+    assert torch.equal(win, win_r)
+    gw = torch.randn_like(win)
+    win.backward(gw)
+    win_r.backward(gw)
+    assert torch.equal(x.grad, xr.grad)
+    w2 = torch.randn(B, nh * nw, ws * ws, C, device=gpu).to(dtype).requires_grad_()
+    w2r = w2.detach().clone().requires_grad_()
+    y, yr = _WindowRows.apply(w2, H, W, ws, sh, True, dtype), ref_reverse(w2r)
+    assert torch.equal(y, yr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yr.backward(gy)
+    assert torch.equal(w2.grad, w2r.grad)          # the padding rows get zeros
+    if dtype == torch.float32:                      # the autocast form: float32 rows out in bfloat16, the gradient back in float32
+        x2 = x.detach().clone().requires_grad_()
+        wb = _WindowRows.apply(x2, H, W, ws, sh, False, torch.bfloat16)
+        assert wb.dtype == torch.bfloat16 and torch.equal(wb, win_r.detach().bfloat16())
+        wb.backward(gw.bfloat16())
+        assert x2.grad.dtype == torch.float32 and torch.equal(x2.grad, ref_reverse(gw.bfloat16().float()))
+
+
 # ---------------------------------------------------------------------------------------------
 # SFA stage under nn.SyncBatchNorm (DHD-L.py:308-311 SyncbnControlHook): the phased operator, two ranks sharing cuda:0 over gloo
 # ---------------------------------------------------------------------------------------------
