@@ -221,6 +221,16 @@ class BatchNorm2d(nn.BatchNorm2d):
         return torch.relu_(y) if (relu or residual is not None) else y
 
 
+def bn_act(bn, x, relu=False, residual=None):
+    """`relu(bn(x))` / `relu(bn(x) + residual)` / `bn(x)` for ANY normalisation module: this file's BatchNorm2d takes the
+    element-wise tail along (fused on channels_last GPU tensors), every other module -- nn.SyncBatchNorm after
+    `convert_sync_batchnorm` (SyncbnControlHook, DHD-L.py:308-311), a plain nn.BatchNorm2d, GroupNorm -- is called as it is and
+    the tail applied with torch operators."""
+    if isinstance(bn, BatchNorm2d):
+        return bn(x, relu=relu, residual=residual)
+    return BatchNorm2d._tail(bn(x), relu, residual)
+
+
 def defer_counters(model, on=True):
     """Switch the per-layer `num_batches_tracked` launches of every dhd_amd BatchNorm2d under `model` to host-side counting
     (see BatchNorm2d.defer_counter); the owner of the step then calls flush_counters(model) once per step."""

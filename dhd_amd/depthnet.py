@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
-from .batchnorm import BatchNorm2d
+from .batchnorm import BatchNorm2d, bn_act
 
 
 class BasicBlock(nn.Module):
@@ -33,8 +33,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(out), residual=identity)
+        out = bn_act(self.bn1, self.conv1(x), relu=True)
+        return bn_act(self.bn2, self.conv2(out), residual=identity)
 
 
 class _DeformIm2col(torch.autograd.Function):

@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
-from .batchnorm import BatchNorm2d
+from .batchnorm import BatchNorm2d, bn_act
 from .depthnet import BasicBlock
 from .registry import BACKBONES, DETECTORS, HEADS, NECKS, build_backbone, build_head, build_neck
 
@@ -49,9 +49,9 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
         # relu(bn(.)) and relu(bn(.) + identity) as one operator each (batchnorm.BatchNorm2d.forward)
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), residual=identity)
+        out = bn_act(self.bn1, self.conv1(x), relu=True)
+        out = bn_act(self.bn2, self.conv2(out), relu=True)
+        return bn_act(self.bn3, self.conv3(out), residual=identity)
 
 
 # A/B switch: the configs' with_cp=True trades a second forward of the image backbone for activation memory (32 GB cards); on 288 GB it
@@ -114,7 +114,7 @@ class ResNet(nn.Module):
         self._freeze_stages()   # as mmdet's ResNet.__init__: frozen parameters never reach an optimizer built before .train()
 
     def forward(self, x):
-        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
+        x = self.maxpool(bn_act(self.bn1, self.conv1(x), relu=True))
         outs = []
         for i, name in enumerate(self.res_layers):
             layer = getattr(self, name)
@@ -152,7 +152,7 @@ class ResNet(nn.Module):
 
     def forward_first_stage(self, x):
         """Stem + first residual stage only: the stereo reference feature of BEVStereo4D (bevstereo4d.py:29-40)."""
-        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
+        x = self.maxpool(bn_act(self.bn1, self.conv1(x), relu=True))
         return getattr(self, self.res_layers[0])(x)
 
 
@@ -168,7 +168,7 @@ class ConvModule(nn.Module):
     def forward(self, x):
         x = self.conv(x)
         if self.bn is not None:
-            return self.bn(x, relu=self.act is not None)
+            return bn_act(self.bn, x, relu=self.act is not None)
         return x if self.act is None else self.act(x)
 
 
@@ -335,7 +335,7 @@ class _DoubleConv(nn.Module):
 
     def forward(self, x):
         c1, b1, _, c2, b2, _ = self.double_conv      # conv, BN, ReLU twice; each BN takes its ReLU along
-        return b2(c2(b1(c1(x), relu=True)), relu=True)
+        return bn_act(b2, c2(bn_act(b1, c1(x), relu=True)), relu=True)
 
 
 class _Down(nn.Module):

@@ -368,6 +368,29 @@ def test_batchnorm_relu_and_residual_arguments_off_the_gpu():
     assert y.shape == (2, 16, 6, 6) and float(y.detach().min()) >= 0.0
 
 
+def test_callers_of_the_fused_batchnorm_survive_sync_batchnorm_conversion():
+    """SyncbnControlHook (core/hook/syncbncontrol.py:18-32, on from epoch 0 in DHD-L.py) replaces every BatchNorm2d by
+    nn.SyncBatchNorm, whose forward takes no relu / residual arguments: the callers go through batchnorm.bn_act, which applies the
+    tail with torch operators for any module that is not this repo's BatchNorm2d.  Same values as before the conversion (eval
+    mode: SyncBatchNorm runs on CPU tensors only there)."""
+    import copy
+    from dhd_amd.batchnorm import bn_act
+    from dhd_amd.depthnet import BasicBlock
+    from dhd_amd.detector import Bottleneck, ConvModule, _DoubleConv
+    torch.manual_seed(2)
+    x = torch.randn(2, 16, 6, 6)
+    for m in (Bottleneck(16, 4), BasicBlock(16, 16), ConvModule(16, 8, 3, padding=1, norm=True, act=True), _DoubleConv(16, 8)):
+        for bn in (b for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d)):
+            bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 1.5)
+        m.eval()
+        ref = m(x)
+        conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(m)).eval()
+        assert any(isinstance(b, torch.nn.SyncBatchNorm) for b in conv.modules())
+        assert torch.allclose(conv(x), ref, atol=1e-6)
+    gn = torch.nn.GroupNorm(2, 16)
+    assert torch.equal(bn_act(gn, x, relu=True), torch.relu(gn(x))) and torch.equal(bn_act(gn, x, residual=x), torch.relu(gn(x) + x))
+
+
 def test_to_layout_off_the_gpu_and_its_gradient_layout():
     """dhd_amd.layout.to_layout on CPU tensors (torch's copy): values unchanged, the requested format, identity when the tensor
     already has it (or has both: one channel / one pixel), and the gradient handed back in the PRODUCER's layout."""
