@@ -301,7 +301,9 @@ constexpr size_t kStreamLds = (size_t)kTableFloats * 4 + (size_t)kSegMaxVox * 2 
 // the price is that the slot map of a segment is built once per part.  Where segments are sparse that is cheap and 16
 // channels per workgroup are best; where they are dense (D = 88: twice the points, or the 32 x 88 feature maps of
 // DHD-L) the table holds 32 channels per pass anyway and halves are best.  The host picks by points per segment
-// (stream_split).  mghs_stream_bwd gains nothing from 2 parts (134 us) and loses with 4 (147 us): it stays whole.
+// (stream_split).  mghs_stream_bwd at DHD-S B = 4 gains nothing from 2 parts and loses with 4 (backward 131.5 / 132.2 / 147 us) and
+// stays whole there; at the dense geometries two parts pay (round 5, A/B of three builds on one box, MGHS-only step: DHD-L
+// B = 2 0.4693 -> 0.459 ms, DHD-M B = 3 0.3398 -> 0.3325), so it takes 2 where the writer takes 2.
 // Element types of the dense tensors (dhd_tensor_view.dtype): a lane always moves 16 bytes = kVox<T> voxels of one channel run.
 // Half types: float32 sums from the table, rounded to nearest even on the way out (what `.half()` / `.bfloat16()` of the
 // float32 tensor would give); gradients are widened exactly.
@@ -957,7 +959,8 @@ static int backward_impl(const dhd_mghs_desc* desc, const float* depth, const fl
   if ((rc = make_views<InPtrs, const float>(L, out_grad, views, &in))) return rc;
   hipStream_t st = dhd_stream(stream);
   if (L.compact) {
-    if ((rc = launch_stream_bwd(L, in, 1, st))) return rc;
+    // two channel parts per segment where segments are dense (the D = 88 geometries), whole segments otherwise: see stream_split
+    if ((rc = launch_stream_bwd(L, in, stream_split(L) == 2 ? 2 : 1, st))) return rc;
     hipLaunchKernelGGL(mghs_pixel_bwd, dim3(dhd_cdiv((long)L.B * L.N * L.hw, 8 * (kBlock / DHD_WAVE)) * 8), dim3(kBlock), 0, st, L,
                        depth, feat_nhwc, depth_grad, feat_grad_nhwc);
     DHD_LAUNCH_CHECK();
