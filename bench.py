@@ -925,8 +925,11 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
         return ddist.max_over_ranks(mine, dev) / n
 
     n_params = None
-    for amp in ('off', 'fp16'):
-        tag = 'fp32' if amp == 'off' else 'fp16'
+    # third leg, single GPU only, NOT the configs' behaviour and therefore never the headline of this sub-record: the fp16 step without
+    # the image backbone's activation checkpointing (DHD-S.py: with_cp=True buys memory on 32 GB cards; on 288 GB it only costs the
+    # second backbone forward) -- reported beside the faithful fp16 leg as an A/B
+    legs = [('off', 'fp32', True), ('fp16', 'fp16', True)] + ([('fp16', 'fp16_no_activation_checkpointing', False)] if world == 1 else [])
+    for amp, tag, with_cp in legs:
         # A rank that fails (out of memory, a bad kernel ...) must not leave the others waiting in a collective, and rank 0
         # must be able to report a failure it did not see: the construction and the warm-up -- where such errors show -- run
         # under try, then ALL ranks exchange their error texts and abandon the leg together if any of them failed.
@@ -934,6 +937,8 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
         try:
             job = EndToEnd(dev, a.batch, 1000 + rank, world, amp, 'dhd-s', True, graph=not a.no_graph, bucket_mb=a.bucket_mb,
                            static_graph=a.ddp_static_graph, ddp_graph=a.ddp_graph, layout=a.layout)
+            if not with_cp:
+                job.model.img_backbone.with_cp = False
             n_params = job.n_params
         except Exception as exc:  # noqa: BLE001
             err = f'{type(exc).__name__}: {exc}'[:300]
@@ -953,6 +958,8 @@ def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
         per_step = timed(job, steps, tag)
         rec = dict(samples_per_s=a.batch * world / per_step, ms_per_step=1e3 * per_step, steps=steps, warmup=warmup,
                    hip_graph=job.graphed is not None, layout=job.layout)
+        if not with_cp:
+            rec['note'] = 'img_backbone.with_cp = False (the configs set True): an A/B beside the fp16 leg, not the configs\' step'
         if eager is not None:
             rec['ms_per_step_eager'] = 1e3 * eager
         if job.graph_error:
