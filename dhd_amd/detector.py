@@ -681,17 +681,26 @@ class DHD(nn.Module):
         vt = self.img_view_transformer
         mlp_input = vt.get_mlp_input(s2k, e2g, intrins, post_rots, post_trans, bda)
         x_2d, depth, height, low, mid, high = vt([x, s2k, e2g, intrins, post_rots, post_trans, bda, mlp_input])
+        x_2d, x_3d = self.encode_maps(x_2d, low, mid, high)
+        return x_2d, x_3d, depth, height
+
+    def encode_maps(self, x_2d, low, mid, high):
+        """The four BEV maps of the view transform -> (x_2d, x_3d): `bev_encoder` on the collapsed map, one UNet per height band,
+        the three band features concatenated (DHD_model.py:107-113)."""
         x_2d = self.bev_encoder(x_2d)
         x_3d = torch.cat((self.voxel_encoder0(low), self.voxel_encoder1(mid), self.voxel_encoder2(high)), dim=1)
-        return x_2d, x_3d, depth, height
+        return x_2d, x_3d
+
+    def occ_logits(self, img_feats):
+        """[x_2d, x_3d] -> voxel logits (B, Dx, Dy, Dz, n_cls): cat -> mix -> occ_head (DHD_model.py:196-198, :224-226)."""
+        return self.occ_head(self._enter('occ_head', self.mix(self._enter('mix', torch.cat(img_feats, dim=1)))))
 
     def extract_feat(self, points, img_inputs, img_metas=None, **kwargs):
         x_2d, x_3d, depth, height = self.extract_img_feat(img_inputs, img_metas, **kwargs)
         return x_2d, x_3d, None, depth, height
 
     def forward_occ_train(self, img_feats, voxel_semantics, mask_camera):
-        outs = self.occ_head(self._enter('occ_head', self.mix(self._enter('mix', torch.cat(img_feats, dim=1)))))
-        return self.occ_head.loss(outs, voxel_semantics, mask_camera)
+        return self.occ_head.loss(self.occ_logits(img_feats), voxel_semantics, mask_camera)
 
     def forward_train(self, points=None, img_metas=None, img_inputs=None, **kwargs):
         x_2d, x_3d, _, depth, height = self.extract_feat(points, img_inputs=img_inputs, img_metas=img_metas, **kwargs)
@@ -704,8 +713,7 @@ class DHD(nn.Module):
         return self.simple_test_occ([x_2d, x_3d], img_metas)
 
     def simple_test_occ(self, img_feats, img_metas=None):
-        outs = self.occ_head(self._enter('occ_head', self.mix(self._enter('mix', torch.cat(img_feats, dim=1)))))
-        return self.occ_head.get_occ(outs, img_metas)
+        return self.occ_head.get_occ(self.occ_logits(img_feats), img_metas)
 
     def forward(self, return_loss=True, **kwargs):
         if not return_loss:
