@@ -35,18 +35,30 @@ sys.path.insert(0, ROOT)
 # MIOpen's user find-db (dhd_amd/miopen_db/: built once by experiments/miopen_find_job.py -- an exhaustive FIND over the convolution
 # problems of the DHD-S step on an MI355X; this image ships no gfx950 find-db, so without it every convolution runs the solver a
 # heuristic picks).  Must be in the environment before MIOpen initialises; DHD_NO_MIOPEN_DB=1 leaves MIOpen on its defaults (A/B).
-# A scratch copy is used so that MIOpen's own write-backs never touch the tracked files.
+# A FRESH scratch copy per run (tempfile.mkdtemp: private, unpredictable name) is used so that MIOpen's own write-backs never touch the
+# tracked files and no run reads what an earlier run -- or an earlier version of the tracked db -- left behind; ranks and child
+# processes inherit the path through the environment.  The db's content hash goes into the JSON line (`miopen_db`).
+MIOPEN_DB = dict(source=None, sha256_16=None)
 if 'MIOPEN_USER_DB_PATH' not in os.environ and not os.environ.get('DHD_NO_MIOPEN_DB'):
     _src = os.path.join(ROOT, 'dhd_amd', 'miopen_db')
     if os.path.isdir(_src) and any(f.endswith('.ufdb.txt') for f in os.listdir(_src)):
+        import atexit
+        import hashlib
         import shutil
         import tempfile
-        _dst = os.path.join(tempfile.gettempdir(), 'dhd_amd_miopen_db_%d' % os.getuid())
-        os.makedirs(_dst, exist_ok=True)
-        for _f in os.listdir(_src):
-            if _f.endswith('.txt') and not os.path.exists(os.path.join(_dst, _f)):
+        _dst = tempfile.mkdtemp(prefix='dhd_amd_miopen_db_')
+        _h = hashlib.sha256()
+        for _f in sorted(os.listdir(_src)):
+            if _f.endswith('.txt'):
                 shutil.copy(os.path.join(_src, _f), _dst)
+                _h.update(_f.encode() + b'\0' + open(os.path.join(_src, _f), 'rb').read())
         os.environ['MIOPEN_USER_DB_PATH'] = _dst
+        os.environ['DHD_MIOPEN_DB_SHA'] = _h.hexdigest()[:16]
+        atexit.register(lambda d=_dst, pid=os.getpid(): os.getpid() == pid and shutil.rmtree(d, ignore_errors=True))
+if os.environ.get('DHD_MIOPEN_DB_SHA'):
+    MIOPEN_DB = dict(source='dhd_amd/miopen_db (scratch copy)', sha256_16=os.environ['DHD_MIOPEN_DB_SHA'])
+elif 'MIOPEN_USER_DB_PATH' in os.environ:
+    MIOPEN_DB = dict(source='MIOPEN_USER_DB_PATH from the environment', sha256_16=None)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -199,9 +211,16 @@ def parse():
                         'DHD-L / fresh-process children, no half-precision or fused-operator launches (they share kernel names with the '
                         'hot path at other sizes and would be averaged into its per-launch traffic)')
     p.add_argument('--child', action='store_true', help='(internal) a --fresh-procs child: print the timing statistics only')
-    p.add_argument('--ddp-graph', action='store_true',
-                   help='e2e under DDP: capture the whole step, RCCL all-reduces included, into a HIP graph (N = 1 always does; with N > 1 '
-                        'it is opt-in because it cannot be validated on the one-GPU development box: falls back to eager on a capture error)')
+    p.add_argument('--ddp-graph', dest='ddp_graph', action='store_true', default=None,
+                   help='e2e under DDP: capture the whole step, RCCL all-reduces included, into a HIP graph.  Default (neither flag): TRY it '
+                        'when the backend is RCCL ("nccl"), after every eager number of the record has been measured, under a watchdog '
+                        '(--ddp-graph-timeout); on a capture error / timeout the record keeps the eager step and says why')
+    p.add_argument('--no-ddp-graph', dest='ddp_graph', action='store_false', help='e2e under DDP: do not attempt the graph capture')
+    p.add_argument('--ddp-graph-timeout', type=float, default=240.0,
+                   help='seconds the DDP graph attempt (capture + replays, all legs) may take before the line is printed without it')
+    p.add_argument('--stub-model', action='store_true',
+                   help='(test only) --workload e2e on a few-kilobyte stand-in detector that runs on CPU tensors: exercises the launcher, the '
+                        'process group, DDP and the record plumbing without a GPU (tests/test_distributed.py); the line is marked "stub"')
     a = p.parse_args()
     if a.pmc_pass:
         a.no_dhdl, a.fresh_procs, a.repeats, a.no_e2e, a.cpu_samples = True, 0, 1, True, 0
@@ -306,15 +325,35 @@ class HotPath:
         return outs, dg, fg_nchw
 
 
+class _StubDetector(torch.nn.Module):
+    """(test only, --stub-model) the detector's call interface -- forward(return_loss=True, img_inputs=[imgs, ...], **labels) ->
+    dict of losses -- on a few-kilobyte network, so that the self-launch, the process group, DDP and the record plumbing of the e2e
+    workload can run in a CPU-only container.  Never part of a reported number: every line it produces carries "stub": true."""
+
+    def __init__(self):
+        super().__init__()
+        nn = torch.nn
+        self.body = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 16, 1))
+        self.head = nn.Linear(16, 18)
+
+    def forward(self, return_loss=True, img_inputs=None, voxel_semantics=None, **_):
+        imgs = img_inputs[0]
+        x = self.body(imgs.flatten(0, 1)).mean((2, 3)).view(imgs.shape[0], imgs.shape[1], -1).mean(1)
+        return dict(loss_occ=torch.nn.functional.cross_entropy(self.head(x).float(), voxel_semantics), loss_height=(x.float() ** 2).mean())
+
+
 class EndToEnd:
     """DHD-S exactly as projects/configs/DHD/DHD-S.py:42-155 (random init, synthetic 6-camera batch,
     SURVEY.md 8d config 2): forward_train -> sum of the four losses -> backward -> grad clip 5 -> AdamW."""
 
     def __init__(self, dev, batch, seed, world, amp, model='dhd-s', ema=True, graph=False, bucket_mb=64, static_graph=False,
-                 ddp_graph=False, layout=None):
+                 ddp_graph=False, layout=None, stub=False):
         import dhd_amd
         from dhd_amd.detector import dhd_l_model_cfg, dhd_m_model_cfg, dhd_s_model_cfg
         torch.manual_seed(seed)
+        self.dev_type = dev.type
+        if stub:
+            return self._init_stub(dev, batch, seed, world, amp, graph, bucket_mb, static_graph, ddp_graph)
         # dhd-m: DHD-M.py (DHD_stereo: key frame + 1 adjacent + 1 stereo reference frame, D = 88, SFA with C = 512)
         # dhd-l: DHD-L.py (the same wiring on a Swin-B backbone, 512 x 1408 images, 32 x 88 feature maps with 512 channels)
         frames = 1 if model == 'dhd-s' else 3
@@ -372,6 +411,31 @@ class EndToEnd:
             self.graph_error = (f'not attempted: --ddp-graph needs RCCL (backend "nccl"); "{torch.distributed.get_backend()}" stages its '
                                 'collectives through the host and cannot be captured into a HIP graph')
 
+    def _init_stub(self, dev, batch, seed, world, amp, graph, bucket_mb, static_graph, ddp_graph):
+        """--stub-model (test only): the same step protocol (zero_grad, autocast, losses dict -> backward -> clip -> AdamW, DDP when
+        world > 1) on a stand-in module of a few thousand parameters that accepts CPU tensors."""
+        self.model = _StubDetector().to(dev).train()
+        self.layout = 'stub'
+        self.params = list(self.model.parameters())
+        self.n_params = sum(p.numel() for p in self.params)
+        self.net = self.model
+        if world > 1:
+            self.net = torch.nn.parallel.DistributedDataParallel(self.model, device_ids=[dev.index] if dev.type == 'cuda' else None,
+                                                                 bucket_cap_mb=bucket_mb, gradient_as_bucket_view=True,
+                                                                 static_graph=bool(static_graph))
+        cuda = dev.type == 'cuda'
+        self.opt = torch.optim.AdamW(self.params, lr=2e-4, weight_decay=1e-2, fused=cuda, capturable=bool(graph) and cuda)
+        self.ema = None
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        self.kw = dict(img_inputs=[torch.randn(batch, 6, 3, 16, 16, generator=g).to(dev)],
+                       voxel_semantics=torch.randint(0, 18, (batch,), generator=g).to(dev))
+        self.amp = {'off': None, 'bf16': torch.bfloat16, 'fp16': torch.float16}[amp]
+        self.scaler = torch.amp.GradScaler(dev.type) if amp == 'fp16' else None
+        self.B, self.graphed, self.graph_error = batch, None, None
+        self.want_graph = bool(graph) and cuda and (world == 1 or bool(ddp_graph))
+        if bool(graph) and not cuda:
+            self.graph_error = 'not attempted: CPU tensors (--stub-model)'
+
     def capture(self):
         """After the eager warm-up: the whole step as one HIP graph (dhd_amd/graph.py); falls back to eager on failure."""
         if not self.want_graph:
@@ -382,7 +446,10 @@ class EndToEnd:
         except Exception as e:  # noqa: BLE001 -- report and keep measuring eagerly
             self.graph_error = f'{type(e).__name__}: {e}'[:300]
             self.graphed = None
-            torch.cuda.synchronize()
+            try:
+                torch.cuda.synchronize()
+            except Exception as e2:  # noqa: BLE001 -- a capture that poisoned the context: the caller keeps its eager numbers
+                self.graph_error += f' | then synchronize: {type(e2).__name__}: {e2}'[:200]
 
     def step(self, record):
         if self.graphed is not None:
@@ -391,7 +458,7 @@ class EndToEnd:
 
     def _eager_step(self):
         self.opt.zero_grad(set_to_none=True)
-        with torch.autocast('cuda', dtype=self.amp, enabled=self.amp is not None):
+        with torch.autocast(self.dev_type, dtype=self.amp, enabled=self.amp is not None):
             losses = self.net(return_loss=True, **self.kw)
             loss = sum(losses.values())
         if self.scaler is not None:
@@ -409,39 +476,252 @@ class EndToEnd:
         return loss
 
 
+def fence():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    ddist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+class Watchdog:
+    """A host timer around a step that may hang on the device (the first graph replay of RCCL collectives on hardware this code
+    was never run on): when it expires, `on_expire()` runs (rank 0 prints the line from what has been measured) and the process
+    leaves with os._exit(0) -- no destructors, no collective."""
+
+    def __init__(self, seconds, on_expire):
+        import threading
+        self.seconds, self.on_expire = seconds, on_expire
+        self._timer = threading.Timer(seconds, self._fire)
+        self._timer.daemon = True
+
+    def _fire(self):
+        try:
+            self.on_expire(f'watchdog: the DDP graph attempt exceeded {self.seconds:.0f} s; the record holds the eager measurements')
+        finally:
+            sys.stdout.flush()
+            os._exit(0)
+
+    def __enter__(self):
+        self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._timer.cancel()
+        return False
+
+
+def resolve_ddp_graph(a, world):
+    """--ddp-graph / --no-ddp-graph / neither (= try when the backend is RCCL)."""
+    if world == 1 or a.no_graph:
+        return False
+    return (a.dist_backend == 'nccl') if a.ddp_graph is None else bool(a.ddp_graph)
+
+
+def e2e_measure(a, rank, world, dev, legs, model, warmup, steps, emit_partial=None, stub=False, want_util=False):
+    """The whole-detector step, per leg (amp, tag, with_cp).  N = 1: eager + HIP-graph step.  N > 1, in this order:
+      1. the SAME binary's single-GPU step on every rank at once (no DDP wrapper, no collective): eager and graphed -- the
+         like-for-like denominators of a scaling efficiency;
+      2. the DDP step eagerly (bucketed all-reduce overlapped with backward), each rank's own time next to the MAX, and the
+         same under no_sync() -> exposed (non-overlapped) all-reduce time;
+      3. LAST, when asked for or by default over RCCL (resolve_ddp_graph): the DDP step captured into a HIP graph, under a
+         watchdog -- everything above is already in the record if the capture fails, poisons the context or hangs.
+    Returns (out, scaling): `out[tag]` as before; `scaling` = the N > 1 summary that goes to the top level of the line."""
+    out, scaling, pending = {}, {}, []
+    per_rank = {}
+    backend = a.dist_backend if world > 1 else None
+    try_ddp_graph = resolve_ddp_graph(a, world)
+
+    def timed(job, n, tag=None):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            job.step(True)
+        fence()
+        mine = time.perf_counter() - t0
+        if tag is not None and world > 1:   # every rank's own time next to the MAX that defines the step
+            per_rank[tag] = [round(1e3 * v / n, 3) for v in ddist.gather_values(mine)]
+        return ddist.max_over_ranks(mine, dev) / n
+
+    def make(amp, w, with_cp, ddp_graph=False):
+        job = EndToEnd(dev, a.batch, 1000 + rank, w, amp, model, not a.no_ema, graph=not a.no_graph, bucket_mb=a.bucket_mb,
+                       static_graph=a.ddp_static_graph, ddp_graph=ddp_graph, layout=a.layout, stub=stub)
+        if not with_cp and not stub:
+            job.model.img_backbone.with_cp = False
+        return job
+
+    def guarded(fn):
+        """fn() on every rank; (result, [errors over all ranks]).  A rank that fails (out of memory, a bad kernel ...) must not
+        leave the others waiting in a collective, and rank 0 must be able to report a failure it did not see."""
+        res, err = None, None
+        try:
+            res = fn()
+        except Exception as exc:  # noqa: BLE001
+            err = f'{type(exc).__name__}: {exc}'[:300]
+        return res, ddist.gather_errors(err)
+
+    n_params = None
+    for amp, tag, with_cp in legs:
+        rec = dict(steps=steps, warmup=warmup)
+        if world > 1:
+            # 1. single-GPU step of the same binary, all ranks at once
+            single, errs = guarded(lambda: make(amp, 1, with_cp))
+            if errs:
+                out[tag] = dict(error=errs)
+                continue
+            for _ in range(warmup):
+                single.step(False)
+            sg = dict(ms_per_step_eager=1e3 * timed(single, max(2, steps // 2)))
+            single.capture()
+            if single.graphed is not None:
+                sg['ms_per_step_graph'] = 1e3 * timed(single, steps)
+            if single.graph_error:
+                sg['hip_graph_error'] = single.graph_error
+            sg['note'] = 'no DDP wrapper, no collective; every rank runs it at the same time, MAX over ranks'
+            rec['single_gpu_same_binary'] = sg
+            del single
+            if torch.cuda.is_available():
+                torch.cuda.empty_cache()
+        job, errs = guarded(lambda: make(amp, world, with_cp, ddp_graph=try_ddp_graph))
+        if errs:
+            out[tag] = dict(rec, error=errs)
+            continue
+        n_params = job.n_params
+        rec['layout'] = job.layout
+        for _ in range(warmup):
+            job.step(False)
+        if world == 1:
+            eager = timed(job, 2) if job.want_graph else None
+            job.capture()
+            per_step = timed(job, steps, tag)
+            rec.update(samples_per_s=a.batch / per_step, ms_per_step=1e3 * per_step, hip_graph=job.graphed is not None)
+            if eager is not None:
+                rec['ms_per_step_eager'] = 1e3 * eager
+            if job.graph_error:
+                rec['hip_graph_error'] = job.graph_error
+        else:
+            # 2. DDP, eager
+            per_step = timed(job, steps, tag)
+            rec.update(samples_per_s=a.batch * world / per_step, ms_per_step=1e3 * per_step, ms_per_step_eager=1e3 * per_step,
+                       hip_graph=False, ms_per_step_by_rank=per_rank.get(tag), ddp_graph_requested=a.ddp_graph,
+                       ddp_graph_attempt=bool(try_ddp_graph and job.want_graph))
+            with job.net.no_sync():
+                job.step(False)
+                rec['ms_per_step_no_allreduce'] = 1e3 * timed(job, steps)
+            rec['exposed_allreduce_ms'] = max(0.0, rec['ms_per_step_eager'] - rec['ms_per_step_no_allreduce'])
+            rec.update(allreduce_bytes=4 * job.n_params, bucket_mb=a.bucket_mb, static_graph=bool(a.ddp_static_graph))
+            if job.graph_error:     # e.g. "not attempted: --ddp-graph needs RCCL"
+                rec['hip_graph_error'] = job.graph_error
+            if rec['ddp_graph_attempt']:
+                pending.append((tag, job))
+        if not with_cp:
+            rec['note'] = 'img_backbone.with_cp = False (the configs set True): an A/B beside the fp16 leg, not the configs\' step'
+        if want_util and tag == 'fp16' and world == 1 and not stub:
+            try:
+                util = e2e_module_utilisation(job)
+                util['whole_step_tflops'] = round(util['sum_gflop'] / rec['ms_per_step'], 1)          # GFLOP / ms = TFLOP/s
+                util['whole_step_frac_of_mfma_peak'] = round(util['sum_gflop'] / rec['ms_per_step'] / MFMA_PEAK_TFLOPS, 4)
+                rec['mfma_utilisation'] = util
+            except Exception as exc:  # noqa: BLE001
+                rec['mfma_utilisation'] = dict(error=f'{type(exc).__name__}: {exc}'[:300])
+        out[tag] = rec
+        if not any(job is j for _, j in pending):
+            del job
+            if torch.cuda.is_available():
+                torch.cuda.empty_cache()
+
+    def summary():
+        legs_out = {}
+        for tag, rec in out.items():
+            if not isinstance(rec, dict) or 'ms_per_step_eager' not in rec or world == 1:
+                continue
+            sg = rec.get('single_gpu_same_binary', {})
+            per = lambda ms, n: None if ms is None else a.batch * n / (ms * 1e-3)
+            legs_out[tag] = dict(
+                ddp_ms_per_step_eager=rec['ms_per_step_eager'], ddp_ms_per_step_graph=rec.get('ms_per_step_graph'),
+                ddp_samples_per_s_eager=per(rec['ms_per_step_eager'], world), ddp_samples_per_s_graph=per(rec.get('ms_per_step_graph'), world),
+                ddp_graph_error=rec.get('hip_graph_error'),
+                single_gpu_ms_per_step_eager=sg.get('ms_per_step_eager'), single_gpu_ms_per_step_graph=sg.get('ms_per_step_graph'),
+                single_gpu_samples_per_s_eager=per(sg.get('ms_per_step_eager'), 1), single_gpu_samples_per_s_graph=per(sg.get('ms_per_step_graph'), 1),
+                ms_per_step_no_allreduce=rec.get('ms_per_step_no_allreduce'), exposed_allreduce_ms=rec.get('exposed_allreduce_ms'),
+                ms_per_step_by_rank=rec.get('ms_per_step_by_rank'))
+        if not legs_out:
+            return None
+        return dict(n_gpus=world, samples_per_gpu=a.batch, backend=('RCCL ("nccl")' if backend == 'nccl' else f'{backend} (test only)'),
+                    bucket_mb=a.bucket_mb, allreduce_bytes=None if n_params is None else 4 * n_params, static_graph=bool(a.ddp_static_graph),
+                    legs=legs_out,
+                    note='north_star\'s scaling number: the whole-detector step under DDP at this N, eager and (if the capture worked) as one '
+                         'HIP graph, beside the single-GPU step of the same binary measured in the same process -- compare eager with eager and '
+                         'graph with graph.  The top-level `value` of this line is the collective-free hot path and says nothing about the fabric.')
+
+    # 3. the DDP graph attempt, last, under the watchdog
+    if pending:
+        if emit_partial is not None:
+            wd = Watchdog(a.ddp_graph_timeout, lambda why: emit_partial(out, dict(summary() or {}, ddp_graph_abandoned=why)))
+        else:
+            wd = Watchdog(a.ddp_graph_timeout, lambda why: None)
+        fence()
+        with wd:
+            for tag, job in pending:
+                rec = out[tag]
+                job.capture()
+                failed = ddist.gather_errors(job.graph_error)   # a capture that failed on one rank only: every rank stays eager
+                if failed:
+                    job.graphed = None
+                    rec['hip_graph_error'] = failed
+                    continue
+                try:
+                    g = timed(job, steps)
+                    rec.update(ms_per_step_graph=1e3 * g, hip_graph=True, ms_per_step=1e3 * g, samples_per_s=a.batch * world / g)
+                except Exception as exc:  # noqa: BLE001
+                    rec['hip_graph_error'] = f'replay: {type(exc).__name__}: {exc}'[:300]
+                    break
+        pending.clear()
+    return out, summary(), n_params
+
+
+E2E_WORKLOAD = {'dhd-m': 'DHD-M (DHD_stereo: key + adjacent + stereo reference frame, D=88) whole detector: ResNet-50 + FPN',
+                'dhd-l': 'DHD-L (configs[3]: DHD_stereo on 512x1408 images, D=88, 32x88 feature maps) whole detector: Swin-B + FPN_LSS',
+                'dhd-s': 'DHD-S (configs[1]/[2]) whole detector: ResNet-50 + FPN'}
+
+
+def parallelism_text(a, world):
+    if world == 1:
+        return 'single GPU'
+    return (f'DDP x{world} ({"RCCL" if a.dist_backend == "nccl" else "gloo (test only)"} bucketed all-reduce, {a.bucket_mb} MB buckets, '
+            'overlapped with backward)')
+
+
 def run_e2e(a, rank, world, dev):
-    job = EndToEnd(dev, a.batch, 1000 + rank, world, a.amp, a.model, not a.no_ema, graph=not a.no_graph, bucket_mb=a.bucket_mb,
-                   static_graph=a.ddp_static_graph, ddp_graph=a.ddp_graph, layout=a.layout)
-    for _ in range(a.warmup):
-        job.step(False)
-    job.capture()
+    """--workload e2e: the whole-detector step as the line's own metric (one leg: --amp)."""
+    tag = {'off': 'fp32', 'bf16': 'bf16', 'fp16': 'fp16'}[a.amp]
+    printed = []
 
-    def fence():
-        torch.cuda.synchronize()
-        ddist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = job.step(True)
-    fence()
-    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
-    if rank == 0:
+    def emit(out, scaling):
+        if rank != 0 or printed:
+            return
+        printed.append(True)
+        rec = out.get(tag, {})
+        ok = 'ms_per_step' in rec
         print(json.dumps(dict(
-            metric=f'samples/sec (6-cam fwd+bwd) {a.model.upper()} end-to-end', value=a.batch * world * a.steps / elapsed, unit='samples/s',
-            n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True,
+            metric=f'samples/sec (6-cam fwd+bwd) {a.model.upper()} end-to-end', value=rec['samples_per_s'] if ok else None, unit='samples/s',
+            n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=rec.get('ms_per_step'), higher_is_better=True,
             scaling='weak', vs_baseline=None, dtype={'off': 'f32', 'bf16': 'bf16', 'fp16': 'f16'}[a.amp], data='synthetic',
-            config=dict(workload={'dhd-m': 'DHD-M (DHD_stereo: key + adjacent + stereo reference frame, D=88) whole detector: ResNet-50 + FPN',
-                                  'dhd-l': 'DHD-L (configs[3]: DHD_stereo on 512x1408 images, D=88, 32x88 feature maps) whole detector: '
-                                           'Swin-B + FPN_LSS',
-                                  'dhd-s': 'DHD-S (configs[1]/[2]) whole detector: ResNet-50 + FPN'}[a.model] +
-                                 ', MGHS (HIP), BEV encoder, 3 UNets, SFA (HIP stage), predictor + losses (HIP); '
-                                 'forward_train + backward + grad-clip + AdamW' + ('' if a.no_ema else ' + weight EMA (HIP)') + '; random init',
-                        samples_per_gpu=a.batch, global_batch=a.batch * world, params=job.n_params,
-                        parallelism=f'DDP x{world} (RCCL bucketed all-reduce overlapped with backward)' if world > 1 else 'single GPU',
-                        hip_graph=job.graphed is not None, hip_graph_error=job.graph_error, layout=job.layout,
-                        final_loss=float(loss.detach())))), flush=True)
+            **(dict(stub=True) if a.stub_model else {}),
+            config=dict(workload=('STUB detector (test only, --stub-model): plumbing, not a measurement' if a.stub_model else
+                                  E2E_WORKLOAD[a.model] + ', MGHS (HIP), BEV encoder, 3 UNets, SFA (HIP stage), predictor + losses (HIP); '
+                                  'forward_train + backward + grad-clip + AdamW' + ('' if a.no_ema else ' + weight EMA (HIP)') + '; random init'),
+                        samples_per_gpu=a.batch, global_batch=a.batch * world, params=rec.get('n_params'),
+                        parallelism=parallelism_text(a, world), hip_graph=rec.get('hip_graph'), hip_graph_error=rec.get('hip_graph_error'),
+                        layout=rec.get('layout')),
+            e2e={tag: rec}, e2e_scaling=scaling, distributed=dist_report, miopen_db=MIOPEN_DB)), flush=True)
+
+    dist_report = ddist.rank_report()
+    out, scaling, n_params = e2e_measure(a, rank, world, dev, [(a.amp, tag, True)], a.model, a.warmup, a.steps, emit_partial=emit,
+                                         stub=a.stub_model)
+    if tag in out and isinstance(out[tag], dict):
+        out[tag]['n_params'] = n_params
+    emit(out, scaling)
     ddist.shutdown()
 
 
@@ -899,101 +1179,24 @@ def e2e_module_utilisation(job, reps=4):
                      'shares (layout transposes, casts, fp32 kernels) of the same step: profiles/r5/e2e_dhds_fp16_kernel_categories.txt')
 
 
-def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5):
+def e2e_subrecord(a, rank, world, dev, warmup=3, steps=5, emit_partial=None):
     """north_star's target number, observed by the driver inside the default line: the whole DHD-S detector
     (forward_train + backward + grad clip + AdamW + weight EMA) in fp32 and under fp16 autocast, B samples per GPU,
-    `warmup` warm-ups + `steps` timed steps.  N > 1: DDP over RCCL (64 MB buckets, overlapped with backward); the
-    exposed (non-overlapped) all-reduce time is measured as step(DDP) - step(DDP.no_sync())."""
-    out = {}
-
-    def fence():
-        torch.cuda.synchronize()
-        ddist.barrier()
-        torch.cuda.synchronize()
-
-    per_rank = {}
-
-    def timed(job, n, tag=None):
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            job.step(True)
-        fence()
-        mine = time.perf_counter() - t0
-        if tag is not None and world > 1:   # every rank's own time next to the MAX that defines the step
-            per_rank[tag] = [round(1e3 * v / n, 3) for v in ddist.gather_values(mine)]
-        return ddist.max_over_ranks(mine, dev) / n
-
-    n_params = None
+    `warmup` warm-ups + `steps` timed steps (e2e_measure).  N > 1: DDP over RCCL (64 MB buckets, overlapped with backward); the
+    exposed (non-overlapped) all-reduce time is measured as step(DDP) - step(DDP.no_sync()); returns (record, e2e_scaling)."""
     # third leg, single GPU only, NOT the configs' behaviour and therefore never the headline of this sub-record: the fp16 step without
     # the image backbone's activation checkpointing (DHD-S.py: with_cp=True buys memory on 32 GB cards; on 288 GB it only costs the
     # second backbone forward) -- reported beside the faithful fp16 leg as an A/B
     legs = [('off', 'fp32', True), ('fp16', 'fp16', True)] + ([('fp16', 'fp16_no_activation_checkpointing', False)] if world == 1 else [])
-    for amp, tag, with_cp in legs:
-        # A rank that fails (out of memory, a bad kernel ...) must not leave the others waiting in a collective, and rank 0
-        # must be able to report a failure it did not see: the construction and the warm-up -- where such errors show -- run
-        # under try, then ALL ranks exchange their error texts and abandon the leg together if any of them failed.
-        job, err = None, None
-        try:
-            job = EndToEnd(dev, a.batch, 1000 + rank, world, amp, 'dhd-s', True, graph=not a.no_graph, bucket_mb=a.bucket_mb,
-                           static_graph=a.ddp_static_graph, ddp_graph=a.ddp_graph, layout=a.layout)
-            if not with_cp:
-                job.model.img_backbone.with_cp = False
-            n_params = job.n_params
-        except Exception as exc:  # noqa: BLE001
-            err = f'{type(exc).__name__}: {exc}'[:300]
-        errs = ddist.gather_errors(err)
-        if errs:
-            out[tag] = dict(error=errs)
-            del job
-            torch.cuda.empty_cache()
-            continue
-        for _ in range(warmup):
-            job.step(False)
-        eager = timed(job, 2) if job.want_graph else None
-        job.capture()
-        if world > 1 and job.want_graph:   # a capture that failed on one rank only: every rank goes back to eager
-            if ddist.gather_errors(job.graph_error):
-                job.graphed = None
-        per_step = timed(job, steps, tag)
-        rec = dict(samples_per_s=a.batch * world / per_step, ms_per_step=1e3 * per_step, steps=steps, warmup=warmup,
-                   hip_graph=job.graphed is not None, layout=job.layout)
-        if not with_cp:
-            rec['note'] = 'img_backbone.with_cp = False (the configs set True): an A/B beside the fp16 leg, not the configs\' step'
-        if eager is not None:
-            rec['ms_per_step_eager'] = 1e3 * eager
-        if job.graph_error:
-            rec['hip_graph_error'] = job.graph_error
-        if world > 1:
-            rec['ms_per_step_by_rank'] = per_rank.get(tag)
-            rec['ddp_graph_requested'] = bool(a.ddp_graph)
-            graphed, job.graphed = job.graphed, None     # the no_sync() comparison runs eagerly
-            with job.net.no_sync():
-                job.step(False)
-                rec['ms_per_step_no_allreduce'] = 1e3 * timed(job, steps)
-            job.graphed = graphed
-            base = rec.get('ms_per_step_eager', rec['ms_per_step']) if graphed is not None else rec['ms_per_step']
-            rec['exposed_allreduce_ms'] = max(0.0, base - rec['ms_per_step_no_allreduce'])
-            rec['allreduce_bytes'] = 4 * job.n_params
-            rec['bucket_mb'] = a.bucket_mb
-            rec['static_graph'] = bool(a.ddp_static_graph)
-        if tag == 'fp16' and world == 1:
-            try:
-                util = e2e_module_utilisation(job)
-                util['whole_step_tflops'] = round(util['sum_gflop'] / rec['ms_per_step'], 1)          # GFLOP / ms = TFLOP/s
-                util['whole_step_frac_of_mfma_peak'] = round(util['sum_gflop'] / rec['ms_per_step'] / MFMA_PEAK_TFLOPS, 4)
-                rec['mfma_utilisation'] = util
-            except Exception as exc:  # noqa: BLE001
-                rec['mfma_utilisation'] = dict(error=f'{type(exc).__name__}: {exc}'[:300])
-        out[tag] = rec
-        del job
-        torch.cuda.empty_cache()
-    out['config'] = dict(workload='DHD-S (configs[1]/[2]) whole detector: ResNet-50 + FPN, MGHS (HIP), BEV encoder, 3 UNets, SFA (HIP stage), '
-                                  'predictor + losses (HIP); forward_train + backward + grad-clip + AdamW + weight EMA (HIP); random init',
-                         samples_per_gpu=a.batch, global_batch=a.batch * world, params=n_params,
-                         parallelism=f'DDP x{world} ({"RCCL" if a.dist_backend == "nccl" else "gloo, test only"} bucketed all-reduce, {a.bucket_mb} MB buckets, '
-                                     f'overlapped with backward)' if world > 1 else 'single GPU')
-    return out
+    cfg = lambda n_params: dict(workload='DHD-S (configs[1]/[2]) whole detector: ResNet-50 + FPN, MGHS (HIP), BEV encoder, 3 UNets, SFA (HIP stage), '
+                                         'predictor + losses (HIP); forward_train + backward + grad-clip + AdamW + weight EMA (HIP); random init',
+                                samples_per_gpu=a.batch, global_batch=a.batch * world, params=n_params, parallelism=parallelism_text(a, world))
+    partial = None
+    if emit_partial is not None:
+        partial = lambda out, scaling: emit_partial(dict(out, config=cfg(None)), scaling)
+    out, scaling, n_params = e2e_measure(a, rank, world, dev, legs, 'dhd-s', warmup, steps, emit_partial=partial, want_util=True)
+    out['config'] = cfg(n_params)
+    return out, scaling
 
 
 def run_occ_loss(a, rank, world, dev):
@@ -1112,13 +1315,14 @@ def run_ema(a, rank, world, dev):
 
 def main():
     a = parse()
-    if not torch.cuda.is_available():
+    stub_cpu = a.stub_model and a.workload == 'e2e' and not torch.cuda.is_available()
+    if not torch.cuda.is_available() and not stub_cpu:
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
         # no launcher environment: start one rank per GPU ourselves (the reference's tools/dist_train.sh:11-20 does the same
         # with torch.distributed.launch), then this process becomes the launcher
         have = torch.cuda.device_count()
-        if have < a.gpus and a.dist_backend != 'gloo':   # gloo (test only): ranks may share a GPU
+        if have < a.gpus and a.dist_backend != 'gloo':   # gloo (test only): ranks may share a GPU (or have none: --stub-model)
             raise SystemExit(f'--gpus {a.gpus} requested but only {have} GPU(s) are visible')
         import socket
         with socket.socket() as sock:
@@ -1129,10 +1333,13 @@ def main():
     rank, local, world = ddist.env_world()
     if world != a.gpus:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or without a launcher)')
-    if a.dist_backend == 'gloo':
-        local = local % torch.cuda.device_count()   # ranks may share a device (RCCL refuses that, gloo does not)
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    if stub_cpu:
+        dev = torch.device('cpu')
+    else:
+        if a.dist_backend == 'gloo':
+            local = local % torch.cuda.device_count()   # ranks may share a device (RCCL refuses that, gloo does not)
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     # RCCL ("nccl"); the hot path uses it only for the barrier / MAX around the timed region, the e2e sub-record for DDP
     ddist.init_from_env(backend=a.dist_backend, device=dev if a.dist_backend == 'nccl' else None)
     _lib.load()
@@ -1146,11 +1353,6 @@ def main():
 
     for _ in range(a.warmup):
         hp.step(False)
-
-    def fence():
-        torch.cuda.synchronize()
-        ddist.barrier()
-        torch.cuda.synchronize()
 
     # R repeats of the timed loop of exactly K steps; each repeat has its own fences and its own event samples
     def timed_loop(record=True):
@@ -1211,7 +1413,9 @@ def main():
             config=dict(workload=('DHD-S (configs[1])' if a.geometry == 'dhd-s' else a.geometry.upper() + ' geometry (configs[3-4])') + ' hot path: MGHS 4-grid lift-splat fwd+bwd incl. geometry/grouping'
                                  + ('' if a.no_sfa else ' + SFA attention stage fwd+bwd') +
                                  f'; geometry {a.geometry}: 6 cams -> {hp.dims[2]}x{hp.dims[3]}, D={hp.dims[1]}, C=64, grids 200x200x{{1,4,4,8}}; dense backbone/encoder convs not in the step',
-                        samples_per_gpu=a.batch, global_batch=a.batch * world, parallelism=f'sample-sharded x{world}, no data-path collective',
+                        samples_per_gpu=a.batch, global_batch=a.batch * world, parallelism=f'sample-sharded x{world}, no data-path collective' +
+                        ('' if world == 1 else ': `value` is the collective-free hot path (N independent replicas of the per-GPU work); the DDP / RCCL '
+                         'step north_star asks for at this N is the top-level `e2e_scaling` record'),
                         deterministic_forward=bool(a.deterministic),
                         sfa_gemm=None if a.no_sfa else (a.sfa_gemm or 'bf16x3') +
                         ' (float32 operands cut into bf16 parts for the bf16 MFMA, float32 accumulate; bf16x3 = 2 parts / 3 products per a*b, '
@@ -1228,6 +1432,7 @@ def main():
                           event_samples=n_event_samples))
         # the protocol: R in-process repeats of the K-step loop; the headline is the MEDIAN loop
         line['distributed'] = dist_report
+        line['miopen_db'] = MIOPEN_DB
         line.update(repeats=len(reps), ms_per_step_min=per_step[0], ms_per_step_max=per_step[-1], ms_per_step_first=1e3 * reps[0][0] / a.steps,
                     ms_per_step_all=[round(v, 5) for v in (1e3 * el / a.steps for el, _ in reps)], parts=part_stats)
         line['prepare'] = dict(lift_us, note='dhd_mghs_lift = height argmax -> band + context re-layout + geometry + grouping (4 launches, '
@@ -1298,12 +1503,24 @@ def main():
     if a.geometry == 'dhd-s' and not a.no_sfa and not a.no_e2e:
         del hp
         torch.cuda.empty_cache()
+        printed = []
+
+        def emit_partial(e2e, scaling):   # the watchdog's way out (a hung DDP graph replay): the line from what has been measured
+            if rank == 0 and not printed:
+                printed.append(True)
+                line['e2e'], line['event_samples_dropped'] = e2e, dict(EVENT_DROPS)
+                if scaling is not None:
+                    line['e2e_scaling'] = scaling
+                print(json.dumps(line), flush=True)
+        scaling = None
         try:
-            e2e = e2e_subrecord(a, rank, world, dev)
+            e2e, scaling = e2e_subrecord(a, rank, world, dev, emit_partial=emit_partial)
         except Exception as exc:  # noqa: BLE001 -- the hot-path line must still be printed
             e2e = dict(error=f'{type(exc).__name__}: {exc}'[:400])
         if rank == 0:
             line['e2e'] = e2e
+            if scaling is not None:
+                line['e2e_scaling'] = scaling
             print(f'[bench] e2e leg {time.perf_counter() - t_stage:.1f} s', file=sys.stderr, flush=True)
     if rank == 0:
         line['event_samples_dropped'] = dict(EVENT_DROPS)   # event intervals event_mean() left out as host stalls (> 3 x median)

@@ -136,6 +136,20 @@ class BatchNorm2d(nn.BatchNorm2d):
     defer_counter = False
     _pending = 0
 
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        # `_pending` is host state: whoever reads the counter through state_dict() (checkpoints, EMA copies, load_state_dict of a
+        # deepcopy) must see it flushed, also when the owner of the step did not call flush_counters (a sub-module trained on its
+        # own, forward_train called directly, a checkpointed recompute that counted after the step's flush) -- ADVICE r5
+        self.register_state_dict_pre_hook(BatchNorm2d._flush_own)
+
+    @staticmethod
+    def _flush_own(module, prefix, keep_vars):
+        t = module.num_batches_tracked
+        if module._pending and t is not None and not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            module.num_batches_tracked.add_(module._pending)
+            module._pending = 0
+
     @classmethod
     def routing(cls):
         """(min_numel, max_channels, big_numel); DHD_BN_ROUTING is read at first use, a malformed value falls back
@@ -159,6 +173,8 @@ class BatchNorm2d(nn.BatchNorm2d):
             return False
         if not force and not x.is_contiguous():   # channels_last activations stay with the layout-preserving library path
             return False
+        if x.data_ptr() % 16:                     # the kernels move 16-byte vectors: a view at an odd storage offset goes to torch
+            return False
         min_numel, max_channels, big_numel = self.routing()
         if not force and not ((x.numel() >= min_numel and x.shape[1] <= max_channels) or x.numel() >= big_numel):
             return False
@@ -172,7 +188,8 @@ class BatchNorm2d(nn.BatchNorm2d):
     use_nhwc = not os.environ.get('DHD_BN_NO_NHWC')   # A/B switch: channels_last tensors go to the library's kernels
 
     def _nhwc_ok(self, x):
-        if not (self.use_hip and self.use_nhwc and self.training and x.is_cuda and x.dtype in _DTYPES and x.numel() > 0 and _is_nhwc(x)):
+        if not (self.use_hip and self.use_nhwc and self.training and x.is_cuda and x.dtype in _DTYPES and x.numel() > 0 and _is_nhwc(x)
+                and x.data_ptr() % 16 == 0):      # 16-byte vector loads / stores
             return False
         if self.weight is not None and (self.weight.dtype != torch.float32 or (self.bias is not None and self.bias.dtype != torch.float32)):
             return False
@@ -208,7 +225,8 @@ class BatchNorm2d(nn.BatchNorm2d):
                 if self.momentum is None:
                     factor = 1.0 / float(self.num_batches_tracked)
         if nhwc:
-            fuse_add = residual is not None and residual.shape == x.shape and residual.dtype == x.dtype and _is_nhwc(residual)
+            fuse_add = (residual is not None and residual.shape == x.shape and residual.dtype == x.dtype and _is_nhwc(residual)
+                        and residual.data_ptr() % 16 == 0)
             flags = BN_ADD if fuse_add else (BN_RELU if relu and residual is None else 0)
             y = _BNTrainNHWC.apply(x, self.weight, self.bias, rm, rv, float(factor), float(self.eps), flags, residual if fuse_add else None)
             return y if flags or not (relu or residual is not None) else self._tail(y, relu, residual)

@@ -85,7 +85,7 @@ class QuickCumsumCuda(torch.autograd.Function):
                 torch.cuda.current_stream(depth.device).cuda_stream)
         if rc:
             _lib.check(rc, 'dhd_bev_pool_v2_backward')
-        return depth_grad, feat_grad, None, None, None, None, None, None
+        return depth_grad, feat_grad, None, None, None, None, None, None, None
 
 
 _regroup_cache = {}   # device index -> (stamp, tensors kept alive, result): the last regrouping per device
@@ -132,11 +132,10 @@ class _FusedPool(torch.autograd.Function):
     """bev_pool_v2 + `permute(0, 4, 1, 2, 3).contiguous()` (bev_pool.py:86-106) as one node: the (B, C, Dz, Dy, Dx) tensor is
     written once, zeros included, and its gradient is read once in that layout (dhd_bev_pool_v2_fused_forward / _backward)."""
 
-    cache = True   # set per call by bev_pool_v2(..., cache=...)
-
     @staticmethod
     @traced('dhd.bev_pool_v2.fused.forward')
-    def forward(ctx, depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts, interval_lengths):
+    def forward(ctx, depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts, interval_lengths, cache=True):
+        # `cache` is a per-call argument (not class state): a checkpointed recompute or another thread sees its own caller's choice
         lib = _lib.load()
         if not depth.is_cuda:
             raise _lib.DhdError('bev_pool_v2 runs only on the GPU (no CPU path, as in the reference)')
@@ -158,7 +157,7 @@ class _FusedPool(torch.autograd.Function):
         with _on(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             stamp = tuple((t.data_ptr(), t._version, t.numel()) for t in srcs) + (b, dz, dy, dx, stream)   # filled on this stream
-            hit = _state_cache.get(dev.index) if _FusedPool.cache else None
+            hit = _state_cache.get(dev.index) if cache else None
             valid = hit is not None and hit[0] == stamp
             out = torch.empty((b, c, dz, dy, dx), dtype=f32, device=dev)
             state = hit[2] if valid else torch.empty(sizes[0], dtype=torch.uint8, device=dev)
@@ -169,7 +168,7 @@ class _FusedPool(torch.autograd.Function):
                 state.data_ptr(), sizes[0], 1 if valid else 0, scratch.data_ptr(), scratch.numel(), stream)
         if rc:
             _lib.check(rc, 'dhd_bev_pool_v2_fused_forward')
-        if not valid and _FusedPool.cache:
+        if not valid and cache:
             _state_cache[dev.index] = (stamp, srcs, state)   # srcs kept alive: their addresses cannot be recycled for other lists
         ctx.save_for_backward(ranks_bev, depth, feat, ranks_feat, ranks_depth, state)
         ctx.dims = (b, dz, dy, dx, c, n_iv, sizes)
@@ -197,7 +196,7 @@ class _FusedPool(torch.autograd.Function):
                 b, dz, dy, dx, state.data_ptr(), sizes[0], scratch.data_ptr(), scratch.numel(), stream)
         if rc:
             _lib.check(rc, 'dhd_bev_pool_v2_fused_backward')
-        return depth_grad, feat_grad, None, None, None, None, None, None
+        return depth_grad, feat_grad, None, None, None, None, None, None, None
 
 
 _fused_size_cache = {}
@@ -256,12 +255,8 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
         bev feature (B, C, Dz, Dy, Dx)
     """
     if fused and fused_supported(bev_feat_shape, interval_lengths.numel()):
-        _FusedPool.cache = bool(cache)
-        try:
-            return _FusedPool.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
-                                    interval_lengths)
-        finally:
-            _FusedPool.cache = True
+        return _FusedPool.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
+                                interval_lengths, bool(cache))
     x = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
                               interval_starts, interval_lengths)
     return x.permute(0, 4, 1, 2, 3).contiguous()

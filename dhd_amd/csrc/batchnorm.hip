@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kBnBlock) void bn_cl_apply_fwd(const T* __restrict_
     for (int k = 0; k < N; ++k) {
       float t = fmaf(k0[k], a[k], k1[k]);
       if (ADD) t += b[k];
-      out[k] = RELU ? fmaxf(t, 0.f) : t;
+      out[k] = RELU ? (t < 0.f ? 0.f : t) : t;   // not fmaxf: a NaN must come out as NaN, as torch.relu gives (fmaxf(NaN, 0) = 0)
     }
     Vec<T>::store(y + ch0 + o, out);
   };

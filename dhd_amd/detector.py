@@ -289,7 +289,7 @@ class Upsample(nn.Upsample):
             sf = self.scale_factor if isinstance(self.scale_factor, (tuple, list)) else (self.scale_factor, self.scale_factor)
             size = (int(h * sf[0]), int(w * sf[1]))        # floor(in * scale), as F.interpolate
         geom = _UpsampleBilinear._geom(x, size)
-        if geom[0] < 0 or not _lib.load().dhd_upsample_bilinear_supported(*geom):
+        if geom[0] < 0 or x.data_ptr() % 16 or not _lib.load().dhd_upsample_bilinear_supported(*geom):   # (16-byte vector loads)
             if x.dtype in (torch.float16, torch.bfloat16) and torch.is_autocast_enabled():
                 with torch.autocast('cuda', enabled=False):
                     return super().forward(x)
@@ -715,13 +715,20 @@ class DHD(nn.Module):
     def simple_test_occ(self, img_feats, img_metas=None):
         return self.occ_head.get_occ(self.occ_logits(img_feats), img_metas)
 
+    def flush_bn_counters(self):
+        """Add the BatchNorm calls counted on the host since the last flush to the `num_batches_tracked` buffers (one launch).
+        `forward(return_loss=True)` does it once per step; a caller that drives `forward_train` or a sub-module itself calls this
+        after its step.  Reading a `state_dict()` flushes too (batchnorm.BatchNorm2d._flush_own), so checkpoints and EMA copies
+        always see the reference's counts; `_pending` itself is host state that a HIP-graph replay does not advance (graph.py)."""
+        from .batchnorm import flush_counters
+        flush_counters(self)
+
     def forward(self, return_loss=True, **kwargs):
         if not return_loss:
             return self.simple_test(**kwargs)
         losses = self.forward_train(**kwargs)
         if self.training:
-            from .batchnorm import flush_counters
-            flush_counters(self)
+            self.flush_bn_counters()
         return losses
 
 

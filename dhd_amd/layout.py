@@ -27,7 +27,8 @@ def _convert(t, fmt):
     src = _format_of(t)
     if src == 'both' or src == fmt:
         return t
-    if _TORCH_ONLY or src is None or not t.is_cuda or t.element_size() not in (2, 4) or t.numel() == 0:
+    if _TORCH_ONLY or src is None or not t.is_cuda or t.element_size() not in (2, 4) or t.numel() == 0 or t.data_ptr() % 16:
+        # (the kernel moves 16-byte vectors / 4-byte pairs: a dense view at an odd storage offset takes torch's strided copy)
         return t.contiguous(memory_format=fmt)
     n, c, h, w = t.shape
     out = torch.empty((n, c, h, w), dtype=t.dtype, device=t.device, memory_format=fmt)

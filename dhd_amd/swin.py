@@ -172,7 +172,7 @@ class _WindowRows(torch.autograd.Function):
 
 
 def _windows_on_gpu(x):
-    return (not _PLAIN_WINDOWS) and x.is_cuda and x.dtype in _WIN_DTYPES and x.shape[-1] % 8 == 0
+    return (not _PLAIN_WINDOWS) and x.is_cuda and x.dtype in _WIN_DTYPES and x.shape[-1] % 8 == 0 and x.data_ptr() % 16 == 0
 
 
 class ShiftWindowMSA(nn.Module):

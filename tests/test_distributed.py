@@ -117,3 +117,52 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_two_ranks_gloo_stub_e2e_scaling_record():
+    """`bench.py --gpus 2 --dist-backend gloo --workload e2e --stub-model` end to end WITHOUT a GPU: the self-launch through
+    torch.distributed.run, the gloo process group, DDP, the one-JSON-line contract and the `e2e_scaling` record (single-GPU step
+    of the same binary next to the DDP step, exposed all-reduce time, per-rank times, the reason no graph was attempted).  The
+    stand-in detector (bench._StubDetector) makes the numbers meaningless -- the line says "stub" -- the plumbing is the same
+    code the first RCCL run of the real detector goes through."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--workload', 'e2e',
+                          '--stub-model', '--steps', '3', '--warmup', '1', '--batch', '2'], capture_output=True, text=True, timeout=600,
+                         cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['stub'] is True and d['n_gpus'] == 2 and d['steps'] == 3 and d['unit'] == 'samples/s' and d['scaling'] == 'weak'
+    assert abs(d['value'] - 2 * 2 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    assert 'DDP x2' in d['config']['parallelism'] and d['config']['global_batch'] == 4
+    sc = d['e2e_scaling']
+    assert sc['n_gpus'] == 2 and sc['samples_per_gpu'] == 2 and sc['bucket_mb'] == 64 and 'gloo' in sc['backend']
+    leg = sc['legs']['fp32']
+    for k in ('ddp_ms_per_step_eager', 'single_gpu_ms_per_step_eager', 'ms_per_step_no_allreduce', 'exposed_allreduce_ms',
+              'ddp_samples_per_s_eager', 'single_gpu_samples_per_s_eager'):
+        assert leg[k] is not None and leg[k] >= 0, k
+    assert leg['ddp_ms_per_step_graph'] is None and 'not attempted' in leg['ddp_graph_error']
+    assert len(leg['ms_per_step_by_rank']) == 2
+    assert abs(leg['ddp_samples_per_s_eager'] - 4 / (leg['ddp_ms_per_step_eager'] * 1e-3)) < 1e-6 * leg['ddp_samples_per_s_eager']
+    dist = d['distributed']
+    assert dist['backend'] == 'gloo' and dist['world_size'] == 2 and [r['rank'] for r in dist['ranks']] == [0, 1]
+
+
+def test_bench_watchdog_prints_the_partial_line_and_leaves():
+    """bench.Watchdog, the guard around the first DDP graph replay over RCCL: when the guarded block outlives its deadline the
+    callback runs once (rank 0 prints the line from the eager measurements) and the process exits 0 without unwinding."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.Watchdog(0.5, lambda why: print('PARTIAL', why, flush=True)):\n"
+            "    time.sleep(30)\n"
+            "print('NOT REACHED')\n") % root
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and 'PARTIAL watchdog' in out.stdout and 'NOT REACHED' not in out.stdout
+    code = code.replace('time.sleep(30)', 'pass').replace("'NOT REACHED'", "'DONE'")
+    out = subprocess.run([sys.executable, '-c', code + "time.sleep(1.0)\n"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and 'PARTIAL' not in out.stdout and 'DONE' in out.stdout

@@ -1956,6 +1956,33 @@ def test_batchnorm2d_channels_last_fused_vs_torch(gpu, dtype, tol, mode, shape):
         ours.zero_grad(); ref.zero_grad()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+@pytest.mark.parametrize('mode', ['relu', 'add'])
+def test_batchnorm2d_fused_relu_propagates_nan_like_torch(gpu, mode, layout):
+    """A non-finite input makes the channel's batch statistics NaN; torch.relu (and so the reference's BN -> ReLU) hands the NaN
+    on, so an overflow under fp16 autocast surfaces as a NaN loss.  The fused epilogue must do the same (fmaxf(NaN, 0)
+    = 0 would turn the channel into zeros)."""
+    from dhd_amd.batchnorm import BatchNorm2d
+    torch.manual_seed(3)
+    shape = (2, 16, 6, 10)
+    fmt = torch.channels_last if layout == 'channels_last' else torch.contiguous_format
+    ours = BatchNorm2d(16).to(gpu).train()
+    ref = torch.nn.BatchNorm2d(16).to(gpu).train()
+    x = torch.randn(shape, device=gpu)
+    x[1, 5, 2, 3] = float('nan')
+    x[0, 9, 0, 0] = float('inf')
+    x = x.contiguous(memory_format=fmt)
+    res = torch.randn(shape, device=gpu).contiguous(memory_format=fmt) if mode == 'add' else None
+    y = ours(x, relu=mode == 'relu', residual=res)
+    pre = ref(x) if res is None else ref(x) + res
+    yr = torch.relu(pre)
+    assert torch.equal(torch.isnan(y), torch.isnan(yr))
+    assert torch.isnan(y[:, 5]).all() and torch.isnan(y[:, 9]).all() and not torch.isnan(y[:, 0]).any()
+    ok = ~torch.isnan(yr)
+    assert (y[ok] - yr[ok]).abs().max() < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------
 # bilinear up-sampling, align_corners=True (csrc/upsample.hip) vs torch's float64 interpolate
 # ---------------------------------------------------------------------------------------------

@@ -438,6 +438,18 @@ def test_batchnorm_deferred_counters_match_the_per_layer_updates():
     defer_counters(cum)
     cum(torch.randn(2, 4, 3, 3))
     assert int(cum.num_batches_tracked) == 1 and cum._pending == 0
+    # a reader of the state (checkpoint, EMA copy, deepcopy + state_dict) between the forward and the owner's flush sees the
+    # reference's counts: state_dict() flushes the layer's own pending calls, and nothing is counted twice afterwards
+    net.train(); ref.train()
+    net(x); ref(x)
+    assert net[1]._pending == 1
+    sd = net.state_dict()
+    assert int(sd['1.num_batches_tracked']) == int(ref[1].num_batches_tracked) and net[1]._pending == 0
+    clone = copy.deepcopy(net)
+    net(x); ref(x)
+    assert int(copy.deepcopy(net).state_dict()['4.num_batches_tracked']) == int(ref[4].num_batches_tracked)
+    flush_counters(net)
+    assert int(net[4].num_batches_tracked) == int(ref[4].num_batches_tracked) == int(clone[4].num_batches_tracked) + 1
 
 
 def _g13_case(name, device='cpu'):
