@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DHD_AMD_LIB', os.path.join(_HERE, 'csrc', 'libdhd_amd.so'))
 
 DHD_MAX_GRIDS = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _ERRORS = {-1: 'DHD_EINVAL (bad argument)', -2: 'DHD_ENOSPACE (workspace too small)',
            -3: 'DHD_EUNSUPPORTED (size outside supported range)'}
@@ -144,6 +144,12 @@ _PROTOTYPES = {
     'dhd_deform_im2col': ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     'dhd_stereo_cost_volume': ([_P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P], _I),
     'dhd_deform_col2im': ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    'dhd_deform_im2col_t': ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    'dhd_deform_col2im_workspace_bytes': ([_I, _I, _I, _I], C.c_size_t),
+    'dhd_deform_col2im_gather_supported': ([_I, _I, _I, _I], _I),
+    'dhd_deform_col2im_t': ([_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, C.c_size_t, _P], _I),
+    'dhd_mghs_softmax_forward': ([_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    'dhd_mghs_softmax_backward': ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _I, _I, _P], _I),
     'dhd_ema_update': ([_P, _P, _P, _I, C.c_float, C.c_float, _P], _I),
     'dhd_ema_update_dev': ([_P, _P, _P, _I, _P, _P], _I),
     'dhd_bn_supported': ([_I, _I, _I, _I], _I),

@@ -7,14 +7,27 @@
 // with K = k*k taps t = ky*k + kx, zero outside the image (corners outside contribute 0).
 //
 //   deform_im2col      thread = (b, t, p) x a chunk of channels: corner indices / weights once, then a channel loop
-//   deform_col2im      block = (b, chunk of channel planes): scatter into LDS planes (the feature maps here are
-//                      16x44 .. 32x88), then plain stores -- no global float atomics
+//   deform_col2im      (ABI <= 4 entry point, no workspace) block = (b, chunk of channel planes): scatter into LDS planes
+//                      with LDS float atomics, then plain stores.  713 us at the DHD-S HeightNet size (24 x 256 x 16x44): bound
+//                      by the LDS atomic rate, 155 M read-modify-writes whose neighbouring lanes hit the same cells
+//   deform_tap_sort +  (ABI 5, dhd_deform_col2im_t) the GATHER form: one block per image groups the <= 4 k k hw bilinear
+//   deform_col2im_gather  corner entries (source (t, p), weight) by the cell they land in (LDS counting sort: the taps are
+//                      shared by all channels -- one deformable group); then a block per (image, chunk of channels) stages its
+//                      dcol rows in LDS with coalesced 16-byte loads and every cell sums its own entry list from LDS --
+//                      plain LDS reads, one writer per cell, no atomics
 //   deform_col2offset  thread = (b, t, p): channel loop of the coordinate gradients
+// The column matrix may be float32, float16 or bfloat16 (`col_dtype`): under autocast the GEMM behind it runs in half, so
+// im2col emits half and the two backward kernels read the half gradient (155 MB -> 78 MB per pass at the DHD-S size, and
+// no cast kernels in between); x, the offsets and every gradient that leaves are float32, arithmetic is float32.
 #include "common.h"
 
 namespace {
 
 constexpr int kBlock = 256;
+
+typedef __bf16 bf16_t;
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }   // round to nearest even
 
 struct Tap {
   int i00, i01, i10, i11;   // flat indices into the H*W plane (valid ones only are used)
@@ -51,8 +64,9 @@ __device__ __forceinline__ Tap tap_of(const float* __restrict__ off_b, int t, in
   return make_tap(py, px, h, w);
 }
 
+template <typename TC>
 __global__ __launch_bounds__(kBlock) void deform_im2col(const float* __restrict__ x, const float* __restrict__ off,
-                                                        float* __restrict__ col, int c, int h, int w, int k, int pad, int dil,
+                                                        TC* __restrict__ col, int c, int h, int w, int k, int pad, int dil,
                                                         int c_chunk) {
   const int hw = h * w, kk = k * k;
   const int i = blockIdx.x * kBlock + threadIdx.x;  // (t, p)
@@ -61,14 +75,116 @@ __global__ __launch_bounds__(kBlock) void deform_im2col(const float* __restrict_
   const Tap tp = tap_of(off + (size_t)b * 2 * kk * hw, t, p, h, w, k, pad, dil);
   const int c0 = blockIdx.y * c_chunk, c1 = min(c, c0 + c_chunk);
   const float* xb = x + ((size_t)b * c + c0) * hw;
-  float* cb = col + (((size_t)b * c + c0) * kk + t) * hw + p;
+  TC* cb = col + (((size_t)b * c + c0) * kk + t) * hw + p;
   for (int ch = c0; ch < c1; ++ch, xb += hw, cb += (size_t)kk * hw) {
     float v = 0.f;
     if (tp.v00) v = fmaf(tp.w00, xb[tp.i00], v);
     if (tp.v01) v = fmaf(tp.w01, xb[tp.i01], v);
     if (tp.v10) v = fmaf(tp.w10, xb[tp.i10], v);
     if (tp.v11) v = fmaf(tp.w11, xb[tp.i11], v);
-    *cb = v;
+    *cb = from_f32<TC>(v);
+  }
+}
+
+// ---- gather form of col2im ---------------------------------------------------------------------------------------
+// Workspace per image: cell_start[hw + 1] (int32), then up to 4 k k hw entries {source = t hw + p, weight bits}.
+constexpr int kSortBlock = 1024;
+
+__global__ __launch_bounds__(kSortBlock) void deform_tap_sort(const float* __restrict__ off, int* __restrict__ cell_start,
+                                                              uint2* __restrict__ entries, int h, int w, int k, int pad, int dil) {
+  extern __shared__ int sm[];           // cnt[hw] | cur[hw] | part[kSortBlock]
+  const int hw = h * w, kk = k * k, b = blockIdx.x, tid = threadIdx.x;
+  int* cnt = sm;
+  int* cur = sm + hw;
+  int* part = sm + 2 * hw;
+  for (int i = tid; i < hw; i += kSortBlock) cnt[i] = 0;
+  __syncthreads();
+  const float* off_b = off + (size_t)b * 2 * kk * hw;
+  for (int i = tid; i < kk * hw; i += kSortBlock) {
+    const Tap tp = tap_of(off_b, i / hw, i % hw, h, w, k, pad, dil);
+    if (tp.v00) atomicAdd(cnt + tp.i00, 1);
+    if (tp.v01) atomicAdd(cnt + tp.i01, 1);
+    if (tp.v10) atomicAdd(cnt + tp.i10, 1);
+    if (tp.v11) atomicAdd(cnt + tp.i11, 1);
+  }
+  __syncthreads();
+  // exclusive scan of cnt: a contiguous chunk of cells per thread, then a scan of the chunk sums by one thread per wave + wave 0
+  const int chunk = (hw + kSortBlock - 1) / kSortBlock, lo = min(hw, tid * chunk), hi = min(hw, lo + chunk);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += cnt[i];
+  part[tid] = sum;
+  __syncthreads();
+  if (tid < DHD_WAVE) {                 // 16 partials per lane, wave-inclusive scan, back to exclusive prefixes
+    int local[kSortBlock / DHD_WAVE], run = 0;
+#pragma unroll
+    for (int q = 0; q < kSortBlock / DHD_WAVE; ++q) { local[q] = run; run += part[tid * (kSortBlock / DHD_WAVE) + q]; }
+    int incl = run;
+    for (int m = 1; m < DHD_WAVE; m <<= 1) {
+      const int o = __shfl_up(incl, m, DHD_WAVE);
+      if (tid >= m) incl += o;
+    }
+    const int base = incl - run;
+#pragma unroll
+    for (int q = 0; q < kSortBlock / DHD_WAVE; ++q) part[tid * (kSortBlock / DHD_WAVE) + q] = base + local[q];
+  }
+  __syncthreads();
+  int* start_b = cell_start + (size_t)b * (hw + 1);
+  int run = part[tid];
+  for (int i = lo; i < hi; ++i) {
+    cur[i] = run;
+    start_b[i] = run;
+    run += cnt[i];
+  }
+  if (hi == hw && lo < hw) start_b[hw] = run;
+  if (hw == 0 && tid == 0) start_b[0] = 0;
+  __syncthreads();
+  uint2* ent_b = entries + (size_t)b * 4 * kk * hw;
+  for (int i = tid; i < kk * hw; i += kSortBlock) {
+    const Tap tp = tap_of(off_b, i / hw, i % hw, h, w, k, pad, dil);
+    if (tp.v00) ent_b[atomicAdd(cur + tp.i00, 1)] = make_uint2((unsigned)i, __float_as_uint(tp.w00));
+    if (tp.v01) ent_b[atomicAdd(cur + tp.i01, 1)] = make_uint2((unsigned)i, __float_as_uint(tp.w01));
+    if (tp.v10) ent_b[atomicAdd(cur + tp.i10, 1)] = make_uint2((unsigned)i, __float_as_uint(tp.w10));
+    if (tp.v11) ent_b[atomicAdd(cur + tp.i11, 1)] = make_uint2((unsigned)i, __float_as_uint(tp.w11));
+  }
+}
+
+// dx[b, c0 .. c0+NC) for one image and NC channels whose dcol rows (NC x kk x hw, contiguous) sit in LDS
+template <typename TC, int NC>
+__global__ __launch_bounds__(kBlock) void deform_col2im_gather(const TC* __restrict__ dcol, const int* __restrict__ cell_start,
+                                                               const uint2* __restrict__ entries, float* __restrict__ dx, int c,
+                                                               int hw, int kk, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+  TC* tile = reinterpret_cast<TC*>(tile_raw);            // [NC][kk * hw]
+  const int b = blockIdx.y, c0 = blockIdx.x * NC, nc = min(NC, c - c0), khw = kk * hw;
+  const TC* src = dcol + ((size_t)b * c + c0) * khw;
+  const int n = nc * khw;
+  if (vec_ok) {
+    constexpr int PER = 16 / (int)sizeof(TC);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
+    u32x4* t4 = reinterpret_cast<u32x4*>(tile);
+    for (int i = threadIdx.x; i < n / PER; i += kBlock) t4[i] = __builtin_nontemporal_load(s4 + i);   // read once
+  } else {
+    for (int i = threadIdx.x; i < n; i += kBlock) tile[i] = src[i];
+  }
+  __syncthreads();
+  const int* start_b = cell_start + (size_t)b * (hw + 1);
+  const uint2* ent_b = entries + (size_t)b * 4 * khw;
+  for (int cell = threadIdx.x; cell < hw; cell += kBlock) {
+    const int s = start_b[cell], e = start_b[cell + 1];
+    float acc[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) acc[j] = 0.f;
+    for (int i = s; i < e; ++i) {
+      const uint2 en = ent_b[i];
+      const float wgt = __uint_as_float(en.y);
+#pragma unroll
+      for (int j = 0; j < NC; ++j)
+        if (j < nc) acc[j] = fmaf(wgt, to_f32(tile[j * khw + (int)en.x]), acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+      if (j < nc) dx[((size_t)b * c + c0 + j) * hw + cell] = acc[j];
   }
 }
 
@@ -102,7 +218,8 @@ __global__ __launch_bounds__(kBlock) void deform_col2im(const float* __restrict_
 }
 
 // doff[b, 2t, p] = sum_c dcol * d val / d py, doff[b, 2t+1, p] = ... / d px  (mmcv deformable_col2im_coord)
-__global__ __launch_bounds__(kBlock) void deform_col2offset(const float* __restrict__ dcol, const float* __restrict__ x,
+template <typename TC>
+__global__ __launch_bounds__(kBlock) void deform_col2offset(const TC* __restrict__ dcol, const float* __restrict__ x,
                                                             const float* __restrict__ off, float* __restrict__ doff, int c, int h,
                                                             int w, int k, int pad, int dil) {
   const int hw = h * w, kk = k * k;
@@ -114,11 +231,11 @@ __global__ __launch_bounds__(kBlock) void deform_col2offset(const float* __restr
   if (tp.inside) {
     const float hy = 1.0f - tp.ly, hx = 1.0f - tp.lx;
     const float* xb = x + (size_t)b * c * hw;
-    const float* g = dcol + ((size_t)b * c * kk + t) * hw + p;
+    const TC* g = dcol + ((size_t)b * c * kk + t) * hw + p;
     for (int ch = 0; ch < c; ++ch, xb += hw, g += (size_t)kk * hw) {
       const float v00 = tp.v00 ? xb[tp.i00] : 0.f, v01 = tp.v01 ? xb[tp.i01] : 0.f;
       const float v10 = tp.v10 ? xb[tp.i10] : 0.f, v11 = tp.v11 ? xb[tp.i11] : 0.f;
-      const float gv = *g;
+      const float gv = to_f32(*g);
       gy = fmaf(gv, (v10 - v00) * hx + (v11 - v01) * tp.lx, gy);
       gx = fmaf(gv, (v01 - v00) * hy + (v11 - v10) * tp.ly, gx);
     }
@@ -128,19 +245,104 @@ __global__ __launch_bounds__(kBlock) void deform_col2offset(const float* __restr
   d[(size_t)(2 * t + 1) * hw + p] = gx;
 }
 
+// LDS the gather kernel may use per block: several blocks per CU so that one block's load phase overlaps another's gather phase
+static constexpr size_t kGatherLds = 64 * 1024;
+static constexpr size_t kSortLdsMax = 64 * 1024;
+
+static size_t deform_ws_offsets(int b, int h, int w, int k, size_t* entries_at) {
+  const size_t hw = (size_t)h * w, starts = ((size_t)b * (hw + 1) * sizeof(int) + 255) / 256 * 256;
+  if (entries_at) *entries_at = starts;
+  return starts + (size_t)b * 4 * k * k * hw * sizeof(uint2);
+}
+
+template <typename TC>
+static void launch_gather(const TC* dcol, const int* starts, const uint2* entries, float* dx, int b, int c, int hw, int kk,
+                          hipStream_t st) {
+  const size_t row = (size_t)kk * hw * sizeof(TC);
+  const int vec_ok = (row % 16 == 0) && ((uintptr_t)dcol % 16 == 0);
+  // channels per block: as many as keep the tile within kGatherLds (>= 1: a single row may take up to 144 KiB)
+  int nc = (int)(kGatherLds / row);
+  nc = nc >= 8 ? 8 : nc >= 4 ? 4 : nc >= 2 ? 2 : 1;
+  if (nc > c) nc = c >= 4 ? 4 : c >= 2 ? 2 : 1;
+  const dim3 grid(dhd_cdiv(c, nc), b);
+  const size_t lds = (size_t)nc * row;
+#define DHD_GATHER(NC)                                                                                                        \
+  do {                                                                                                                        \
+    if (lds > 48 * 1024)                                                                                                      \
+      (void)hipFuncSetAttribute((const void*)deform_col2im_gather<TC, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((deform_col2im_gather<TC, NC>), grid, dim3(kBlock), lds, st, dcol, starts, entries, dx, c, hw, kk, vec_ok); \
+  } while (0)
+  if (nc == 8) DHD_GATHER(8);
+  else if (nc == 4) DHD_GATHER(4);
+  else if (nc == 2) DHD_GATHER(2);
+  else DHD_GATHER(1);
+#undef DHD_GATHER
+}
+
 inline bool bad_shape(int b, int c, int h, int w, int k, int dil) { return b <= 0 || c <= 0 || h <= 0 || w <= 0 || k <= 0 || dil <= 0; }
 
 }  // namespace
 
 extern "C" {
 
-int dhd_deform_im2col(const float* x, const float* offset, float* col, int b, int c, int h, int w, int k, int pad, int dil,
-                      void* stream) {
+int dhd_deform_im2col_t(const float* x, const float* offset, void* col, int col_dtype, int b, int c, int h, int w, int k, int pad,
+                        int dil, void* stream) {
   if (!x || !offset || !col || bad_shape(b, c, h, w, k, dil)) return DHD_EINVAL;
   if ((long)b * c * k * k * h * w >= (1L << 40)) return DHD_EUNSUPPORTED;
   const int c_chunk = c >= 32 ? 32 : c;
-  hipLaunchKernelGGL(deform_im2col, dim3(dhd_cdiv((long)k * k * h * w, kBlock), dhd_cdiv(c, c_chunk), b), dim3(kBlock), 0,
-                     dhd_stream(stream), x, offset, col, c, h, w, k, pad, dil, c_chunk);
+  const dim3 grid(dhd_cdiv((long)k * k * h * w, kBlock), dhd_cdiv(c, c_chunk), b);
+  hipStream_t st = dhd_stream(stream);
+  if (col_dtype == DHD_F32)
+    hipLaunchKernelGGL(deform_im2col<float>, grid, dim3(kBlock), 0, st, x, offset, (float*)col, c, h, w, k, pad, dil, c_chunk);
+  else if (col_dtype == DHD_F16)
+    hipLaunchKernelGGL(deform_im2col<_Float16>, grid, dim3(kBlock), 0, st, x, offset, (_Float16*)col, c, h, w, k, pad, dil, c_chunk);
+  else if (col_dtype == DHD_BF16)
+    hipLaunchKernelGGL(deform_im2col<bf16_t>, grid, dim3(kBlock), 0, st, x, offset, (bf16_t*)col, c, h, w, k, pad, dil, c_chunk);
+  else
+    return DHD_EINVAL;
+  DHD_LAUNCH_CHECK();
+  return DHD_OK;
+}
+
+int dhd_deform_im2col(const float* x, const float* offset, float* col, int b, int c, int h, int w, int k, int pad, int dil,
+                      void* stream) {
+  return dhd_deform_im2col_t(x, offset, col, DHD_F32, b, c, h, w, k, pad, dil, stream);
+}
+
+size_t dhd_deform_col2im_workspace_bytes(int b, int h, int w, int k) {
+  if (b <= 0 || h <= 0 || w <= 0 || k <= 0) return 0;
+  return deform_ws_offsets(b, h, w, k, nullptr);
+}
+
+int dhd_deform_col2im_gather_supported(int col_dtype, int h, int w, int k) {
+  if (h <= 0 || w <= 0 || k <= 0 || col_dtype < DHD_F32 || col_dtype > DHD_BF16) return 0;
+  const size_t esz = col_dtype == DHD_F32 ? 4 : 2, khw = (size_t)k * k * h * w;
+  return khw * esz <= 144 * 1024 && (2 * (size_t)h * w + kSortBlock) * sizeof(int) <= kSortLdsMax && khw < (1u << 30);
+}
+
+int dhd_deform_col2im_t(const void* dcol, int col_dtype, const float* x, const float* offset, float* dx, float* doffset, int b, int c,
+                        int h, int w, int k, int pad, int dil, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dcol || !x || !offset || !dx || !doffset || !workspace || bad_shape(b, c, h, w, k, dil)) return DHD_EINVAL;
+  if (!dhd_deform_col2im_gather_supported(col_dtype, h, w, k)) return DHD_EUNSUPPORTED;
+  size_t entries_at = 0;
+  if (workspace_bytes < deform_ws_offsets(b, h, w, k, &entries_at) || ((uintptr_t)workspace & 15)) return DHD_EINVAL;
+  int* starts = (int*)workspace;
+  uint2* entries = (uint2*)((char*)workspace + entries_at);
+  hipStream_t st = dhd_stream(stream);
+  const int hw = h * w, kk = k * k;
+  hipLaunchKernelGGL(deform_tap_sort, dim3(b), dim3(kSortBlock), (2 * (size_t)hw + kSortBlock) * sizeof(int), st, offset, starts, entries,
+                     h, w, k, pad, dil);
+  const dim3 ogrid(dhd_cdiv((long)kk * hw, kBlock), b);
+  if (col_dtype == DHD_F32) {
+    launch_gather<float>((const float*)dcol, starts, entries, dx, b, c, hw, kk, st);
+    hipLaunchKernelGGL(deform_col2offset<float>, ogrid, dim3(kBlock), 0, st, (const float*)dcol, x, offset, doffset, c, h, w, k, pad, dil);
+  } else if (col_dtype == DHD_F16) {
+    launch_gather<_Float16>((const _Float16*)dcol, starts, entries, dx, b, c, hw, kk, st);
+    hipLaunchKernelGGL(deform_col2offset<_Float16>, ogrid, dim3(kBlock), 0, st, (const _Float16*)dcol, x, offset, doffset, c, h, w, k, pad, dil);
+  } else {
+    launch_gather<bf16_t>((const bf16_t*)dcol, starts, entries, dx, b, c, hw, kk, st);
+    hipLaunchKernelGGL(deform_col2offset<bf16_t>, ogrid, dim3(kBlock), 0, st, (const bf16_t*)dcol, x, offset, doffset, c, h, w, k, pad, dil);
+  }
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
@@ -156,7 +358,7 @@ int dhd_deform_col2im(const float* dcol, const float* x, const float* offset, fl
   hipStream_t st = dhd_stream(stream);
   hipLaunchKernelGGL(deform_col2im, dim3(dhd_cdiv(c, c_chunk), b), dim3(kBlock), (size_t)c_chunk * plane, st, dcol, offset, dx, c, h, w,
                      k, pad, dil, c_chunk);
-  hipLaunchKernelGGL(deform_col2offset, dim3(dhd_cdiv((long)k * k * h * w, kBlock), b), dim3(kBlock), 0, st, dcol, x, offset, doffset, c,
+  hipLaunchKernelGGL(deform_col2offset<float>, dim3(dhd_cdiv((long)k * k * h * w, kBlock), b), dim3(kBlock), 0, st, dcol, x, offset, doffset, c,
                      h, w, k, pad, dil);
   DHD_LAUNCH_CHECK();
   return DHD_OK;

@@ -38,36 +38,47 @@ class BasicBlock(nn.Module):
 
 
 class _DeformIm2col(torch.autograd.Function):
-    """x (B,C,H,W), offset (B,2kk,H,W) -> col (B, C*kk, H*W) through libdhd_amd.so (csrc/deform.hip)."""
+    """x (B,C,H,W), offset (B,2kk,H,W) -> col (B, C*kk, H*W) through libdhd_amd.so (csrc/deform.hip).  `col_dtype`: float32, or the
+    autocast half type -- the GEMM behind the sampling runs in it, so the 155 MB column matrix of the DHD-S HeightNet is written
+    once as 78 MB of half and its gradient is read as half, with no cast kernels in between.  Backward: the gather form of
+    col2im (dhd_deform_col2im_t) where the library takes the shape, else the float32 LDS-atomic form."""
 
     @staticmethod
-    def forward(ctx, x, offset, k, pad, dil):
+    def forward(ctx, x, offset, k, pad, dil, col_dtype=torch.float32):
         from . import _lib
         x = _lib.require_gpu_tensor(x.contiguous(), torch.float32, 'DCN input')
         offset = _lib.require_gpu_tensor(offset.contiguous(), torch.float32, 'DCN offsets')
         b, c, h, w = x.shape
         dev = x.device
         with torch.cuda.device(dev):
-            col = torch.empty((b, c * k * k, h * w), dtype=torch.float32, device=dev)
-            _lib.check(_lib.load().dhd_deform_im2col(_lib.ptr(x), _lib.ptr(offset), _lib.ptr(col), b, c, h, w, k, pad, dil,
-                                                     _lib.stream_ptr(dev)), 'dhd_deform_im2col')
+            col = torch.empty((b, c * k * k, h * w), dtype=col_dtype, device=dev)
+            _lib.check(_lib.load().dhd_deform_im2col_t(_lib.ptr(x), _lib.ptr(offset), _lib.ptr(col), _lib.dtype_code(col_dtype), b, c, h, w,
+                                                       k, pad, dil, _lib.stream_ptr(dev)), 'dhd_deform_im2col_t')
         ctx.save_for_backward(x, offset)
-        ctx.args = (k, pad, dil)
+        ctx.args = (k, pad, dil, col_dtype)
         return col
 
     @staticmethod
     def backward(ctx, dcol):
         from . import _lib
         x, offset = ctx.saved_tensors
-        k, pad, dil = ctx.args
+        k, pad, dil, col_dtype = ctx.args
         b, c, h, w = x.shape
         dev = x.device
-        dcol = dcol.float().contiguous()
+        lib = _lib.load()
         with torch.cuda.device(dev):
             dx, doff = torch.empty_like(x), torch.empty_like(offset)
-            _lib.check(_lib.load().dhd_deform_col2im(_lib.ptr(dcol), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(dx), _lib.ptr(doff), b, c, h, w,
-                                                     k, pad, dil, _lib.stream_ptr(dev)), 'dhd_deform_col2im')
-        return dx, doff, None, None, None
+            if lib.dhd_deform_col2im_gather_supported(_lib.dtype_code(col_dtype), h, w, k):
+                dcol = dcol.to(col_dtype).contiguous()
+                ws = torch.empty(lib.dhd_deform_col2im_workspace_bytes(b, h, w, k), dtype=torch.uint8, device=dev)
+                _lib.check(lib.dhd_deform_col2im_t(_lib.ptr(dcol), _lib.dtype_code(col_dtype), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(dx),
+                                                   _lib.ptr(doff), b, c, h, w, k, pad, dil, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+                           'dhd_deform_col2im_t')
+            else:
+                dcol = dcol.float().contiguous()
+                _lib.check(lib.dhd_deform_col2im(_lib.ptr(dcol), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(dx), _lib.ptr(doff), b, c, h, w,
+                                                 k, pad, dil, _lib.stream_ptr(dev)), 'dhd_deform_col2im')
+        return dx, doff, None, None, None, None
 
 
 class DCN(nn.Module):
@@ -98,10 +109,14 @@ class DCN(nn.Module):
         g = self.groups
         wgt = self.weight.reshape(g, self.out_channels // g, (c // g) * k * k)
         if self.use_hip and x.is_cuda and h * w * 4 <= 48 * 1024:
-            # sampling in HIP (float32); the GEMM with the layer's weight follows the ambient autocast dtype
-            col = _DeformIm2col.apply(x.float(), self.conv_offset(x).float(), k, self.padding, self.dilation)
-            col = col.view(b, g, (c // g) * k * k, h * w)
-            out = torch.einsum('gok,bgkp->bgop', wgt, col)
+            # sampling in HIP (float32 arithmetic); the GEMM with the layer's weight follows the ambient autocast dtype, and so
+            # does the column matrix.  matmul with the weight broadcast over the batch: the (B, g, K, HW) operand is used where it
+            # lies (einsum re-laid it out with a 155 MB copy each way)
+            cdt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else torch.float32
+            if cdt not in (torch.float16, torch.bfloat16):
+                cdt = torch.float32
+            col = _DeformIm2col.apply(x.float(), self.conv_offset(x).float(), k, self.padding, self.dilation, cdt)
+            out = torch.matmul(wgt, col.view(b, g, (c // g) * k * k, h * w))      # (g, o, K) x (B, g, K, HW) -> (B, g, o, HW)
             return out.reshape(b, self.out_channels, h, w)
         offset = self.conv_offset(x).view(b, k * k, 2, h, w)
         ys, xs = torch.meshgrid(torch.arange(h, device=x.device, dtype=x.dtype),

@@ -244,11 +244,19 @@ class MGHS(nn.Module):
         x, _, _, _, _, _, _, mlp_input = input[:8]
         B, N, C, H, W = x.shape
         x = x.view(B * N, C, H, W)
-        x_d = self.depth_net(x)
-        depth = x_d[:, :self.D].softmax(dim=1)
-        tran_feat = x_d[:, self.D:self.D + self.out_channels]
-        height = self.height_net(x, mlp_input, stereo_metas)[:, :self.H].softmax(dim=1)
+        depth, tran_feat, height = self._head(self.depth_net(x), self.height_net(x, mlp_input, stereo_metas))
         return self.view_transform(input, depth, tran_feat, height)
+
+    fused_head = not __import__('os').environ.get('DHD_PLAIN_SOFTMAX')   # A/B switch: the torch formulation below
+
+    def _head(self, x_d, h_logits):
+        """depth = softmax(x_d[:, :D]), tran_feat = x_d[:, D:D+C], height = softmax(h_logits[:, :H]) (reference :484-489).  On
+        the GPU one launch each way (mghs_op.depth_height_head: the softmax of torch's own kernel, bit for bit, float32 out as
+        under autocast); the band ids of the lift are the argmax of exactly these height probabilities."""
+        if self.fused_head and x_d.is_cuda and x_d.dim() == 4 and h_logits.dim() == 4:
+            depth, tran_feat, height, _ = mghs_op.depth_height_head(x_d, h_logits, self.D, self.out_channels, self.height_range, self.mask_range)
+            return depth, tran_feat, height
+        return (x_d[:, :self.D].softmax(dim=1), x_d[:, self.D:self.D + self.out_channels], h_logits[:, :self.H].softmax(dim=1))
 
     # ------------------------------------------------------------------ small helpers -----
     def get_mlp_input(self, sensor2ego, ego2global, intrin, post_rot, post_tran, bda):
@@ -344,10 +352,7 @@ class MGHS_Depth(MGHS):
         x, _, _, _, _, _, _, mlp_input = input[:8]
         B, N, C, H, W = x.shape
         x = x.view(B * N, C, H, W)
-        x_d = self.depth_net(x, mlp_input, stereo_metas)
-        depth = x_d[:, :self.D].softmax(dim=1)
-        tran_feat = x_d[:, self.D:self.D + self.out_channels]
-        height = self.height_net(x, mlp_input, stereo_metas=None)[:, :self.H].softmax(dim=1)
+        depth, tran_feat, height = self._head(self.depth_net(x, mlp_input, stereo_metas), self.height_net(x, mlp_input, stereo_metas=None))
         return self.view_transform(input, depth, tran_feat, height)
 
     def view_transform(self, input, depth, tran_feat, height):

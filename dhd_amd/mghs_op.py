@@ -191,6 +191,87 @@ def _nhwc_to_nchw(x):
     return out
 
 
+def _dense_layout(t):
+    """(tensor, nhwc flag) for a 4-D tensor the head kernels can read where it lies: dense NCHW or dense channels_last (scalar
+    accesses: any alignment); anything else is made NCHW-contiguous first."""
+    if t.is_contiguous():
+        return t, 0
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t, 1
+    return t.contiguous(), 0
+
+
+class _DepthHeightHead(torch.autograd.Function):
+    """softmax(depth bins), the context slice, softmax(height bins) and the band id per pixel in one launch; the two softmax
+    Jacobians + the context gradient in one launch back (csrc/mghs_softmax.hip, dhd_mghs_softmax_forward / _backward).
+    Outputs are float32 dense NCHW whatever the inputs' dtype and layout (under autocast torch's softmax returns float32 too)."""
+
+    @staticmethod
+    @traced('dhd.mghs.head.forward')
+    def forward(ctx, x_d, h_logits, d, c, h_bins, hr, mr):
+        lib = _lib.load()
+        x_d, x_nhwc = _dense_layout(x_d)
+        bn, ct, fh, fw = x_d.shape
+        dev = x_d.device
+        hl_code, h_nhwc, ht = 0, 0, 0
+        if h_logits is not None:
+            h_logits, h_nhwc = _dense_layout(h_logits)
+            hl_code, ht = _lib.dtype_code(h_logits.dtype), h_logits.shape[1]
+        with torch.cuda.device(dev):
+            depth = torch.empty((bn, d, fh, fw), dtype=torch.float32, device=dev)
+            feat = torch.empty((bn, c, fh, fw), dtype=torch.float32, device=dev)
+            height = band = None
+            if h_logits is not None:
+                height = torch.empty((bn, h_bins, fh, fw), dtype=torch.float32, device=dev)
+                band = torch.empty((bn, fh, fw), dtype=torch.uint8, device=dev)
+            _lib.check(lib.dhd_mghs_softmax_forward(_lib.ptr(x_d), _lib.dtype_code(x_d.dtype), x_nhwc, ct, _lib.ptr(h_logits), hl_code,
+                                                    h_nhwc, ht, bn, fh * fw, d, c, h_bins, hr, mr, _lib.ptr(depth), _lib.ptr(feat),
+                                                    _lib.ptr(height), _lib.ptr(band), _lib.stream_ptr(dev)), 'dhd_mghs_softmax_forward')
+        ctx.save_for_backward(depth, height)
+        ctx.meta = (d, c, h_bins, x_d.dtype, x_nhwc, ct, None if h_logits is None else h_logits.dtype, h_nhwc, ht, bn, fh, fw)
+        if h_logits is None:
+            return depth, feat
+        ctx.mark_non_differentiable(band)
+        return depth, feat, height, band
+
+    @staticmethod
+    @traced('dhd.mghs.head.backward')
+    def backward(ctx, g_depth, g_feat, g_height=None, _g_band=None):
+        lib = _lib.load()
+        depth, height = ctx.saved_tensors
+        d, c, h_bins, x_dt, x_nhwc, ct, h_dt, h_nhwc, ht, bn, fh, fw = ctx.meta
+        dev = depth.device
+        f32 = lambda g: None if g is None else g.float().contiguous()
+        g_depth, g_feat, g_height = f32(g_depth), f32(g_feat), f32(g_height)
+        want_x, want_h = ctx.needs_input_grad[0], h_dt is not None and ctx.needs_input_grad[1]
+        with torch.cuda.device(dev):
+            fmt = lambda nhwc: torch.channels_last if nhwc else torch.contiguous_format
+            g_xd = torch.empty((bn, ct, fh, fw), dtype=x_dt, device=dev, memory_format=fmt(x_nhwc)) if want_x else None
+            g_hl = torch.empty((bn, ht, fh, fw), dtype=h_dt, device=dev, memory_format=fmt(h_nhwc)) if want_h else None
+            if want_x or want_h:
+                _lib.check(lib.dhd_mghs_softmax_backward(_lib.ptr(g_depth), _lib.ptr(g_feat), _lib.ptr(g_height), _lib.ptr(depth),
+                                                         _lib.ptr(height), bn, fh * fw, d, c, h_bins,
+                                                         _lib.ptr(g_xd), _lib.dtype_code(x_dt), x_nhwc, ct, _lib.ptr(g_hl),
+                                                         0 if h_dt is None else _lib.dtype_code(h_dt), h_nhwc, ht, _lib.stream_ptr(dev)),
+                           'dhd_mghs_softmax_backward')
+        return g_xd, g_hl, None, None, None, None, None
+
+
+def depth_height_head(x_d, h_logits, n_depth, n_context, height_range=None, mask_range=None):
+    """lss_heightmap.py:484-489 on the GPU: (depth_net output, height_net output or None) -> (depth, tran_feat, height, band),
+    float32 NCHW (band uint8; height / band None without a height branch)."""
+    hr = mr = None
+    h_bins = 0
+    if h_logits is not None:
+        h_bins = len(height_range)
+        hr, mr = _range_arrays(height_range, mask_range)
+    for t in (x_d, h_logits):
+        if t is not None and not (t.is_cuda and t.dim() == 4 and t.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+            raise _lib.DhdError('depth_height_head: 4-D float32 / float16 / bfloat16 GPU tensors only')
+    out = _DepthHeightHead.apply(x_d, h_logits, n_depth, n_context, h_bins, hr, mr)
+    return out if h_logits is not None else (out[0], out[1], None, None)
+
+
 @traced('dhd.mghs.prepare')
 def prepare(plan, calib, band, workspace):
     lib = _lib.load()

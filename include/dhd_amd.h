@@ -34,7 +34,7 @@ extern "C" {
 #define DHD_ENOSPACE (-2)   /* workspace too small */
 #define DHD_EUNSUPPORTED (-3)
 
-#define DHD_ABI_VERSION 4
+#define DHD_ABI_VERSION 5
 int dhd_abi_version(void);
 
 /* ------------------------------------------------------------------------------------ *
@@ -526,6 +526,41 @@ int dhd_deform_im2col(const float* x, const float* offset, float* col, int b, in
 int dhd_deform_col2im(const float* dcol, const float* x, const float* offset, float* dx,
                       float* doffset, int b, int c, int h, int w, int k, int pad, int dil,
                       void* stream);
+/* ABI 5.  The same two operators with the column matrix in `col_dtype` (DHD_F32 / DHD_F16 / DHD_BF16: under autocast the GEMM
+ * behind the sampling runs in half, so the columns are written, and their gradient read, in half; x, offset, dx, doffset and the
+ * arithmetic stay float32), and col2im in its GATHER form: the bilinear corner entries of an image are grouped by the cell they
+ * land in (they are shared by all channels), then every cell sums its own list from LDS-staged dcol rows -- no atomics
+ * (csrc/deform.hip).  `workspace`: dhd_deform_col2im_workspace_bytes(b, h, w, k) bytes of device scratch, 16-byte aligned,
+ * owned by the caller.  Shapes the gather form does not take (dhd_deform_col2im_gather_supported == 0: k*k*h*w elements of
+ * `col_dtype` must fit 144 KiB of LDS) return DHD_EUNSUPPORTED; dhd_deform_col2im covers them in float32. */
+int dhd_deform_im2col_t(const float* x, const float* offset, void* col, int col_dtype, int b, int c,
+                        int h, int w, int k, int pad, int dil, void* stream);
+size_t dhd_deform_col2im_workspace_bytes(int b, int h, int w, int k);
+int dhd_deform_col2im_gather_supported(int col_dtype, int h, int w, int k);
+int dhd_deform_col2im_t(const void* dcol, int col_dtype, const float* x, const float* offset, float* dx,
+                        float* doffset, int b, int c, int h, int w, int k, int pad, int dil,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ABI 5.  The element-wise head of MGHS.forward / MGHS_Depth.forward (lss_heightmap.py:484-489, :829-834) in one launch each
+ * way (csrc/mghs_softmax.hip):
+ *   xd  (bn, ct >= d + c, hw)  depth_net's output in `xd_dtype`, dense NCHW (xd_nhwc = 0) or channels_last (1)
+ *   hl  (bn, ht >= h_bins, hw) height_net's output, likewise; NULL: no height branch (then height / band are not written)
+ *   -> depth (bn, d, hw) = softmax over xd's first d channels, feat (bn, c, hw) = its next c channels, height (bn, h_bins, hw)
+ *      = softmax over hl's first h_bins channels, all float32 dense NCHW; band (bn, hw) uint8 = the height band of
+ *      argmax(height) (0 / 1 / 2, 255 none; NULL: not wanted), from the float32 height_range[h_bins] / mask_range[4] as
+ *      dhd_height_band.  The softmax is torch's for this shape, operation for operation (max, sum of expf, correctly rounded
+ *      division, bins in order): the same bits as `x.float().softmax(1)` on the GPU.
+ * backward: g_depth / g_feat / g_height (float32 NCHW, any of them NULL = zero) -> g_xd (bn, ct, hw) in xd's dtype and layout
+ * (softmax Jacobian on the first d channels, g_feat on the next c, zeros beyond) and g_hl (bn, ht, hw) likewise; either output
+ * may be NULL.  Nothing is allocated; the caller's stream. */
+int dhd_mghs_softmax_forward(const void* xd, int xd_dtype, int xd_nhwc, int ct, const void* hl, int hl_dtype,
+                             int hl_nhwc, int ht, int bn, int hw, int d, int c, int h_bins,
+                             const float* height_range, const float* mask_range, float* depth, float* feat,
+                             float* height, uint8_t* band, void* stream);
+int dhd_mghs_softmax_backward(const float* g_depth, const float* g_feat, const float* g_height,
+                              const float* depth, const float* height, int bn, int hw, int d, int c,
+                              int h_bins, void* g_xd, int xd_dtype, int xd_nhwc, int ct, void* g_hl,
+                              int hl_dtype, int hl_nhwc, int ht, void* stream);
 
 /* LiDAR points -> sparse depth / height maps, all cameras of a sample at once
  * (datasets/pipelines/loading_new.py:35-99, PointToMultiViewDepthandHeight.points2depthmap /

@@ -1739,6 +1739,130 @@ def test_dcn_hip_sampling_vs_grid_sample_formulation(gpu, c, groups, h, w, dil, 
         assert (p.grad - q.grad).abs().max().item() < 5e-4 * max(1.0, q.grad.abs().max().item()), k
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('b,c,h,w,dil,scale', [(3, 16, 16, 44, 1, 0.5), (2, 10, 7, 9, 2, 3.0), (2, 12, 32, 88, 1, 8.0), (2, 8, 6, 10, 1, 40.0)])
+def test_dcn_gather_col2im_vs_atomic_form_and_typed_columns(gpu, dtype, b, c, h, w, dil, scale):
+    """ABI 5: dhd_deform_im2col_t / dhd_deform_col2im_t (gather form, columns in float32 / half) against the float32 LDS-atomic
+    entry points of ABI 4 on the same inputs.  float32 columns: the same values up to summation order.  Half columns: im2col
+    equals the rounded float32 columns bit for bit; the gradients equal those of the float32 path fed the same (half-valued)
+    dcol.  Cases: the HeightNet map, dilation 2 with odd channel counts (tail chunk), the DHD-L map (one channel per block,
+    101 KB of LDS for float32), offsets of +-40 pixels (most taps outside, many in the same border cells)."""
+    from dhd_amd import _lib
+    lib = _lib.load()
+    k = 3
+    torch.manual_seed(b * 100 + c)
+    x = torch.randn(b, c, h, w, device=gpu)
+    off = (scale * torch.randn(b, 2 * k * k, h, w, device=gpu)).contiguous()
+    st = _lib.stream_ptr(gpu)
+    code = _lib.dtype_code(dtype)
+    col32 = torch.empty(b, c * k * k, h * w, device=gpu)
+    _lib.check(lib.dhd_deform_im2col(_lib.ptr(x), _lib.ptr(off), _lib.ptr(col32), b, c, h, w, k, dil, dil, st), 'im2col')
+    col = torch.empty(b, c * k * k, h * w, device=gpu, dtype=dtype)
+    _lib.check(lib.dhd_deform_im2col_t(_lib.ptr(x), _lib.ptr(off), _lib.ptr(col), code, b, c, h, w, k, dil, dil, st), 'im2col_t')
+    assert torch.equal(col, col32.to(dtype))
+    dcol = torch.randn(b, c * k * k, h * w, device=gpu).to(dtype)
+    dx0, doff0 = torch.empty_like(x), torch.empty_like(off)
+    _lib.check(lib.dhd_deform_col2im(_lib.ptr(dcol.float().contiguous()), _lib.ptr(x), _lib.ptr(off), _lib.ptr(dx0), _lib.ptr(doff0), b, c, h, w,
+                                     k, dil, dil, st), 'col2im')
+    assert lib.dhd_deform_col2im_gather_supported(code, h, w, k)
+    ws = torch.empty(lib.dhd_deform_col2im_workspace_bytes(b, h, w, k), dtype=torch.uint8, device=gpu)
+    dx1, doff1 = torch.full_like(x, float('nan')), torch.full_like(off, float('nan'))
+    _lib.check(lib.dhd_deform_col2im_t(_lib.ptr(dcol), code, _lib.ptr(x), _lib.ptr(off), _lib.ptr(dx1), _lib.ptr(doff1), b, c, h, w, k, dil, dil,
+                                       _lib.ptr(ws), ws.numel(), st), 'col2im_t')
+    assert torch.isfinite(dx1).all() and torch.isfinite(doff1).all()
+    assert (dx1 - dx0).abs().max().item() <= 2e-5 * max(1.0, dx0.abs().max().item())
+    assert torch.equal(doff1, doff0)                 # same kernel, same order of operations
+    # too small a workspace / an unaligned one is refused, nothing is launched
+    assert lib.dhd_deform_col2im_t(_lib.ptr(dcol), code, _lib.ptr(x), _lib.ptr(off), _lib.ptr(dx1), _lib.ptr(doff1), b, c, h, w, k, dil, dil,
+                                   _lib.ptr(ws), ws.numel() - 1, st) == -1
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_dcn_module_under_autocast_uses_half_columns(gpu, dtype):
+    """DCN.forward under autocast: the column matrix and its gradient are half (no float32 155 MB tensors), results within half
+    precision of the float32 layer."""
+    import copy
+    from dhd_amd.depthnet import DCN
+    torch.manual_seed(5)
+    a = DCN(32, 32, kernel_size=3, padding=1, groups=4).to(gpu)
+    with torch.no_grad():
+        a.conv_offset.weight.normal_(0, 0.05)
+        a.conv_offset.bias.normal_(0, 1.0)
+    b = copy.deepcopy(a)
+    x = torch.randn(4, 32, 16, 44, device=gpu)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    seen = []
+    import dhd_amd.depthnet as dn
+    orig = dn._DeformIm2col.forward
+
+    def spy(ctx, *args):
+        out = orig(ctx, *args)
+        seen.append(out.dtype)
+        return out
+    dn._DeformIm2col.forward = staticmethod(spy)
+    try:
+        with torch.autocast('cuda', dtype=dtype):
+            ya = a(xa)
+    finally:
+        dn._DeformIm2col.forward = staticmethod(orig)
+    assert seen == [dtype] and ya.dtype == dtype
+    yb = b(xb)
+    g = torch.randn_like(yb)
+    ya.backward(g.to(dtype))
+    yb.backward(g)
+    tol = 2e-2 if dtype == torch.float16 else 1e-1
+    rel = lambda p, q: ((p.float() - q).norm() / q.norm()).item()
+    assert rel(ya, yb) < tol and rel(xa.grad, xb.grad) < tol
+    for (k, p), q in zip(a.named_parameters(), b.parameters()):
+        assert rel(p.grad, q.grad) < 3 * tol, k
+
+
+# --------------------------------------------------------------------------- softmax(depth), context, softmax(height), band: one launch (a11)
+
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('bn,d,c,hb,extra,fh,fw', [(24, 44, 64, 65, 0, 16, 44), (5, 88, 32, 17, 3, 7, 9), (2, 9, 8, 65, 0, 1, 3)])
+def test_depth_height_head_one_launch_vs_torch(gpu, dtype, layout, bn, d, c, hb, extra, fh, fw):
+    """dhd_mghs_softmax_forward / _backward against the torch formulation of lss_heightmap.py:484-489 on the same tensors:
+    the probabilities are torch's own softmax BIT FOR BIT (same operation order as aten's kernel for this shape), tran_feat is
+    the float32 slice, band = dhd_height_band of those probabilities; gradients of x_d / the height logits within float32
+    rounding of autograd's, in the inputs' dtype and layout."""
+    from dhd_amd import mghs_op
+    torch.manual_seed(bn + d)
+    fmt = torch.channels_last if layout == 'channels_last' else torch.contiguous_format
+    hr = [round(-1.0 + 0.1 * i, 1) for i in range(hb)]
+    mr = [-1.0, hr[hb // 4], hr[hb // 2], hr[-1]]
+    x_d = (3 * torch.randn(bn, d + c + extra, fh, fw, device=gpu)).to(dtype).contiguous(memory_format=fmt).requires_grad_()
+    hl = (3 * torch.randn(bn, hb + extra, fh, fw, device=gpu)).to(dtype).contiguous(memory_format=fmt)
+    hl[:, 3] = hl[:, 7]                       # exact ties between two bins
+    hl = hl.requires_grad_()
+    depth, feat, height, band = mghs_op.depth_height_head(x_d, hl, d, c, hr, mr)
+    assert depth.dtype == feat.dtype == height.dtype == torch.float32 and band.dtype == torch.uint8
+    assert depth.is_contiguous() and feat.is_contiguous() and height.is_contiguous()
+    xr, hlr = x_d.detach().clone().requires_grad_(), hl.detach().clone().requires_grad_()
+    depth_r = xr[:, :d].float().softmax(dim=1)
+    feat_r = xr[:, d:d + c].float()
+    height_r = hlr[:, :hb].float().softmax(dim=1)
+    bit_equal = torch.equal(depth, depth_r) and torch.equal(height, height_r)
+    print('softmax bit-identical to torch:', bit_equal)
+    assert (depth - depth_r).abs().max().item() <= 2 ** -23 and (height - height_r).abs().max().item() <= 2 ** -23
+    assert bit_equal
+    assert torch.equal(feat, feat_r)
+    assert torch.equal(band, mghs_op.height_band(height, hr, mr))
+    gd, gf, gh = torch.randn_like(depth), torch.randn_like(feat), torch.randn_like(height)
+    torch.autograd.backward([depth, feat, height], [gd, gf, gh])
+    torch.autograd.backward([depth_r, feat_r, height_r], [gd, gf, gh])
+    assert x_d.grad.dtype == dtype and x_d.grad.is_contiguous(memory_format=fmt) and hl.grad.is_contiguous(memory_format=fmt)
+    eps = {torch.float32: 1e-6, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    for a_, r_ in ((x_d.grad, xr.grad), (hl.grad, hlr.grad)):
+        assert (a_.float() - r_.float()).abs().max().item() <= eps * max(1.0, r_.float().abs().max().item())
+    if extra:
+        assert float(x_d.grad[:, d + c:].abs().max()) == 0.0 and float(hl.grad[:, hb:].abs().max()) == 0.0
+    # no height branch; only one of the gradients requested
+    d2, f2, h2, b2 = mghs_op.depth_height_head(x_d.detach().requires_grad_(), None, d, c)
+    assert h2 is None and b2 is None and torch.equal(d2, depth) and torch.equal(f2, feat)
+
+
 # --------------------------------------------------------------------------- stereo cost volume (DHD-M / DHD-L DepthNet)
 
 @pytest.mark.parametrize('bn,c,h,w,d,bias', [(2, 16, 6, 10, 8, 5.0), (3, 256, 16, 44, 88, 5.0), (1, 64, 9, 13, 70, 0.0),
