@@ -37,47 +37,66 @@ class BasicBlock(nn.Module):
         return bn_act(self.bn2, self.conv2(out), residual=identity)
 
 
+def _dense4(t):
+    """(tensor, nhwc flag): `t` where it lies if it is dense NCHW or dense channels_last, else an NCHW copy."""
+    if t.is_contiguous():
+        return t, 0
+    if t.is_contiguous(memory_format=torch.channels_last):
+        return t, 1
+    return t.contiguous(), 0
+
+
 class _DeformIm2col(torch.autograd.Function):
     """x (B,C,H,W), offset (B,2kk,H,W) -> col (B, C*kk, H*W) through libdhd_amd.so (csrc/deform.hip).  `col_dtype`: float32, or the
     autocast half type -- the GEMM behind the sampling runs in it, so the 155 MB column matrix of the DHD-S HeightNet is written
-    once as 78 MB of half and its gradient is read as half, with no cast kernels in between.  Backward: the gather form of
+    once as 78 MB of half and its gradient is read as half, with no cast kernels in between.  x is read where it lies (float32 or
+    col_dtype, NCHW or channels_last) and its gradient comes back in the same dtype and layout.  Backward: the gather form of
     col2im (dhd_deform_col2im_t) where the library takes the shape, else the float32 LDS-atomic form."""
 
     @staticmethod
     def forward(ctx, x, offset, k, pad, dil, col_dtype=torch.float32):
         from . import _lib
-        x = _lib.require_gpu_tensor(x.contiguous(), torch.float32, 'DCN input')
-        offset = _lib.require_gpu_tensor(offset.contiguous(), torch.float32, 'DCN offsets')
+        if not x.is_cuda:
+            raise _lib.DhdError(f'DCN input must live on the GPU: dhd_amd runs only as HIP kernels (got {x.device})')
+        if x.dtype not in (torch.float32, col_dtype):
+            x = x.float()
+        x, nhwc = _dense4(x)
+        offset = _lib.require_gpu_tensor(offset.float().contiguous(), torch.float32, 'DCN offsets')
         b, c, h, w = x.shape
         dev = x.device
         with torch.cuda.device(dev):
             col = torch.empty((b, c * k * k, h * w), dtype=col_dtype, device=dev)
-            _lib.check(_lib.load().dhd_deform_im2col_t(_lib.ptr(x), _lib.ptr(offset), _lib.ptr(col), _lib.dtype_code(col_dtype), b, c, h, w,
-                                                       k, pad, dil, _lib.stream_ptr(dev)), 'dhd_deform_im2col_t')
+            _lib.check(_lib.load().dhd_deform_im2col_t(_lib.ptr(x), _lib.dtype_code(x.dtype), nhwc, _lib.ptr(offset), _lib.ptr(col),
+                                                       _lib.dtype_code(col_dtype), b, c, h, w, k, pad, dil, _lib.stream_ptr(dev)),
+                       'dhd_deform_im2col_t')
         ctx.save_for_backward(x, offset)
-        ctx.args = (k, pad, dil, col_dtype)
+        ctx.args = (k, pad, dil, col_dtype, nhwc)
         return col
 
     @staticmethod
     def backward(ctx, dcol):
         from . import _lib
         x, offset = ctx.saved_tensors
-        k, pad, dil, col_dtype = ctx.args
+        k, pad, dil, col_dtype, nhwc = ctx.args
         b, c, h, w = x.shape
         dev = x.device
         lib = _lib.load()
         with torch.cuda.device(dev):
-            dx, doff = torch.empty_like(x), torch.empty_like(offset)
+            doff = torch.empty_like(offset)
             if lib.dhd_deform_col2im_gather_supported(_lib.dtype_code(col_dtype), h, w, k):
+                dx = torch.empty_like(x)      # x's dtype and strides
                 dcol = dcol.to(col_dtype).contiguous()
                 ws = torch.empty(lib.dhd_deform_col2im_workspace_bytes(b, h, w, k), dtype=torch.uint8, device=dev)
-                _lib.check(lib.dhd_deform_col2im_t(_lib.ptr(dcol), _lib.dtype_code(col_dtype), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(dx),
-                                                   _lib.ptr(doff), b, c, h, w, k, pad, dil, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
-                           'dhd_deform_col2im_t')
+                _lib.check(lib.dhd_deform_col2im_t(_lib.ptr(dcol), _lib.dtype_code(col_dtype), _lib.ptr(x), _lib.dtype_code(x.dtype), nhwc,
+                                                   _lib.ptr(offset), _lib.ptr(dx), _lib.ptr(doff), b, c, h, w, k, pad, dil, _lib.ptr(ws),
+                                                   ws.numel(), _lib.stream_ptr(dev)), 'dhd_deform_col2im_t')
             else:
+                xf = x.float().contiguous()
+                dx = torch.empty_like(xf)
                 dcol = dcol.float().contiguous()
-                _lib.check(lib.dhd_deform_col2im(_lib.ptr(dcol), _lib.ptr(x), _lib.ptr(offset), _lib.ptr(dx), _lib.ptr(doff), b, c, h, w,
+                _lib.check(lib.dhd_deform_col2im(_lib.ptr(dcol), _lib.ptr(xf), _lib.ptr(offset), _lib.ptr(dx), _lib.ptr(doff), b, c, h, w,
                                                  k, pad, dil, _lib.stream_ptr(dev)), 'dhd_deform_col2im')
+                dx = dx.to(x.dtype)
         return dx, doff, None, None, None, None
 
 
@@ -115,7 +134,7 @@ class DCN(nn.Module):
             cdt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else torch.float32
             if cdt not in (torch.float16, torch.bfloat16):
                 cdt = torch.float32
-            col = _DeformIm2col.apply(x.float(), self.conv_offset(x).float(), k, self.padding, self.dilation, cdt)
+            col = _DeformIm2col.apply(x, self.conv_offset(x), k, self.padding, self.dilation, cdt)
             out = torch.matmul(wgt, col.view(b, g, (c // g) * k * k, h * w))      # (g, o, K) x (B, g, K, HW) -> (B, g, o, HW)
             return out.reshape(b, self.out_channels, h, w)
         offset = self.conv_offset(x).view(b, k * k, 2, h, w)
@@ -177,8 +196,15 @@ class ASPP(nn.Module):
         pooled = self.global_avg_pool(x)
         # F.interpolate(pooled, size, 'bilinear', align_corners=True) of a 1 x 1 map (mmdet3d depthnet ASPP.forward) is that value
         # everywhere (scale 0: cell 0, lambda 0) -- a broadcast view instead of a float32 up-sampling kernel under autocast
-        branches.append(pooled.expand(-1, -1, *x.shape[2:]) if pooled.shape[2:] == (1, 1) else
-                        F.interpolate(pooled, size=x.shape[2:], mode='bilinear', align_corners=True))
+        if pooled.shape[2:] == (1, 1):
+            pooled = pooled.expand(-1, -1, *x.shape[2:])
+            if branches[0].is_contiguous(memory_format=torch.channels_last) and not branches[0].is_contiguous():
+                # a stride-0 view among channels_last branches makes `cat` answer in NCHW, and conv1 then re-lays the
+                # (B, 5 mid, H, W) tensor out twice per step (2 x 93 us at the DHD-S size); one small dense copy instead
+                pooled = pooled.contiguous(memory_format=torch.channels_last)
+            branches.append(pooled)
+        else:
+            branches.append(F.interpolate(pooled, size=x.shape[2:], mode='bilinear', align_corners=True))
         x = self.relu(self.bn1(self.conv1(torch.cat(branches, dim=1))))
         return self.dropout(x)
 
@@ -210,6 +236,37 @@ class SELayer(nn.Module):
         return x * self.gate(self.conv_expand(self.act1(self.conv_reduce(x_se))))
 
 
+class _AddChannelBias(torch.autograd.Function):
+    """y + bias[None, :, None, None] whose bias gradient is a (1 x rows) @ (rows x C) product when the gradient is channels_last.
+    torch's `sum((0, 2, 3))` of a channels_last tensor with an ODD channel count (HeightNet's 65 height bins) runs 111-136 us on
+    MI355X for 1.1 M elements (experiments/bias_sum_probe.py; 8 us in NCHW, 13 us for 108 channels): the single largest
+    reduction of the view transformer's backward."""
+
+    @staticmethod
+    def forward(ctx, y, bias):
+        return y + bias.to(y.dtype).view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        c = g.shape[1]
+        if g.is_cuda and not g.is_contiguous() and g.is_contiguous(memory_format=torch.channels_last):
+            rows = g.permute(0, 2, 3, 1).reshape(-1, c)                      # a view: (N H W, C)
+            gb = torch.ones(1, rows.shape[0], dtype=torch.float32, device=g.device).matmul(rows.float()).view(c)
+        else:
+            gb = g.sum((0, 2, 3), dtype=torch.float32)
+        return g, gb
+
+
+class HeadConv1x1(nn.Conv2d):
+    """nn.Conv2d(cin, cout, 1) (same parameters and state-dict keys) with the bias added -- and its gradient reduced -- by
+    _AddChannelBias; used where cout is odd (the 65-bin height head)."""
+
+    def forward(self, x):
+        if self.bias is None or not x.is_cuda:
+            return super().forward(x)
+        return _AddChannelBias.apply(self._conv_forward(x, self.weight, None), self.bias)
+
+
 def _depth_conv_stack(mid_channels, depth_channels, conv_in, downsample, use_dcn, use_aspp, aspp_mid_channels):
     layers = [BasicBlock(conv_in, mid_channels, downsample=downsample),
               BasicBlock(mid_channels, mid_channels), BasicBlock(mid_channels, mid_channels)]
@@ -217,7 +274,8 @@ def _depth_conv_stack(mid_channels, depth_channels, conv_in, downsample, use_dcn
         layers.append(ASPP(mid_channels, mid_channels if aspp_mid_channels < 0 else aspp_mid_channels))
     if use_dcn:
         layers.append(DCN(mid_channels, mid_channels, kernel_size=3, padding=1, groups=4, im2col_step=128))
-    layers.append(nn.Conv2d(mid_channels, depth_channels, kernel_size=1, stride=1, padding=0))
+    head = HeadConv1x1 if depth_channels % 2 else nn.Conv2d
+    layers.append(head(mid_channels, depth_channels, kernel_size=1, stride=1, padding=0))
     return nn.Sequential(*layers)
 
 
