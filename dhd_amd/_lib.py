@@ -144,10 +144,10 @@ _PROTOTYPES = {
     'dhd_deform_im2col': ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     'dhd_stereo_cost_volume': ([_P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P], _I),
     'dhd_deform_col2im': ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P], _I),
-    'dhd_deform_im2col_t': ([_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
+    'dhd_deform_im2col_t': ([_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     'dhd_deform_col2im_workspace_bytes': ([_I, _I, _I, _I], C.c_size_t),
     'dhd_deform_col2im_gather_supported': ([_I, _I, _I, _I], _I),
-    'dhd_deform_col2im_t': ([_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, C.c_size_t, _P], _I),
+    'dhd_deform_col2im_t': ([_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, C.c_size_t, _P], _I),
     'dhd_mghs_softmax_forward': ([_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
     'dhd_mghs_softmax_backward': ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _I, _I, _P], _I),
     'dhd_ema_update': ([_P, _P, _P, _I, C.c_float, C.c_float, _P], _I),

@@ -18,7 +18,8 @@
 //   deform_col2offset  thread = (b, t, p): channel loop of the coordinate gradients
 // The column matrix may be float32, float16 or bfloat16 (`col_dtype`): under autocast the GEMM behind it runs in half, so
 // im2col emits half and the two backward kernels read the half gradient (155 MB -> 78 MB per pass at the DHD-S size, and
-// no cast kernels in between); x, the offsets and every gradient that leaves are float32, arithmetic is float32.
+// no cast kernels in between); x is read, and its gradient written, as float32 or in the column type; the offsets and their
+// gradient are float32, arithmetic is float32.
 #include "common.h"
 
 namespace {
@@ -26,10 +27,9 @@ namespace {
 constexpr int kBlock = 256;
 
 typedef __bf16 bf16_t;
-// element (image, channel, cell) of x / dx: dense NCHW or channels_last
-template <bool NHWC> __device__ __forceinline__ size_t x_at(int b, int ch, int i, int c, int hw) {
-  return NHWC ? ((size_t)b * hw + i) * c + ch : ((size_t)b * c + ch) * hw + i;
-}
+// element (image, channel, cell) of x / dx (dense NCHW: lanes = consecutive cells, so the corner gathers of a wave stay within a
+// few lines per channel plane; a channels_last x measured 5-7x slower in these kernels and is converted by the caller instead)
+__device__ __forceinline__ size_t x_at(int b, int ch, int i, int c, int hw) { return ((size_t)b * c + ch) * hw + i; }
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }   // round to nearest even
 
@@ -68,7 +68,7 @@ __device__ __forceinline__ Tap tap_of(const float* __restrict__ off_b, int t, in
   return make_tap(py, px, h, w);
 }
 
-template <typename TC, typename TX, bool NHWC>
+template <typename TC, typename TX>
 __global__ __launch_bounds__(kBlock) void deform_im2col(const TX* __restrict__ x, const float* __restrict__ off,
                                                         TC* __restrict__ col, int c, int h, int w, int k, int pad, int dil,
                                                         int c_chunk) {
@@ -81,10 +81,10 @@ __global__ __launch_bounds__(kBlock) void deform_im2col(const TX* __restrict__ x
   TC* cb = col + (((size_t)b * c + c0) * kk + t) * hw + p;
   for (int ch = c0; ch < c1; ++ch, cb += (size_t)kk * hw) {
     float v = 0.f;
-    if (tp.v00) v = fmaf(tp.w00, to_f32(x[x_at<NHWC>(b, ch, tp.i00, c, hw)]), v);
-    if (tp.v01) v = fmaf(tp.w01, to_f32(x[x_at<NHWC>(b, ch, tp.i01, c, hw)]), v);
-    if (tp.v10) v = fmaf(tp.w10, to_f32(x[x_at<NHWC>(b, ch, tp.i10, c, hw)]), v);
-    if (tp.v11) v = fmaf(tp.w11, to_f32(x[x_at<NHWC>(b, ch, tp.i11, c, hw)]), v);
+    if (tp.v00) v = fmaf(tp.w00, to_f32(x[x_at(b, ch, tp.i00, c, hw)]), v);
+    if (tp.v01) v = fmaf(tp.w01, to_f32(x[x_at(b, ch, tp.i01, c, hw)]), v);
+    if (tp.v10) v = fmaf(tp.w10, to_f32(x[x_at(b, ch, tp.i10, c, hw)]), v);
+    if (tp.v11) v = fmaf(tp.w11, to_f32(x[x_at(b, ch, tp.i11, c, hw)]), v);
     *cb = from_f32<TC>(v);
   }
 }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kSortBlock) void deform_tap_sort(const float* __res
 }
 
 // dx[b, c0 .. c0+NC) for one image and NC channels whose dcol rows (NC x kk x hw, contiguous) sit in LDS
-template <typename TC, int NC, typename TX, bool NHWC>
+template <typename TC, int NC, typename TX>
 __global__ __launch_bounds__(kBlock) void deform_col2im_gather(const TC* __restrict__ dcol, const int* __restrict__ cell_start,
                                                                const uint2* __restrict__ entries, TX* __restrict__ dx, int c,
                                                                int hw, int kk, int vec_ok) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void deform_col2im_gather(const TC* __restr
     }
 #pragma unroll
     for (int j = 0; j < NC; ++j)
-      if (j < nc) dx[x_at<NHWC>(b, c0 + j, cell, c, hw)] = from_f32<TX>(acc[j]);
+      if (j < nc) dx[x_at(b, c0 + j, cell, c, hw)] = from_f32<TX>(acc[j]);
   }
 }
 
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void deform_col2im(const float* __restrict_
 }
 
 // doff[b, 2t, p] = sum_c dcol * d val / d py, doff[b, 2t+1, p] = ... / d px  (mmcv deformable_col2im_coord)
-template <typename TC, typename TX = float, bool NHWC = false>
+template <typename TC, typename TX = float>
 __global__ __launch_bounds__(kBlock) void deform_col2offset(const TC* __restrict__ dcol, const TX* __restrict__ x,
                                                             const float* __restrict__ off, float* __restrict__ doff, int c, int h,
                                                             int w, int k, int pad, int dil) {
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(kBlock) void deform_col2offset(const TC* __restrict
     const float hy = 1.0f - tp.ly, hx = 1.0f - tp.lx;
     const TC* g = dcol + ((size_t)b * c * kk + t) * hw + p;
     for (int ch = 0; ch < c; ++ch, g += (size_t)kk * hw) {
-      const float v00 = tp.v00 ? to_f32(x[x_at<NHWC>(b, ch, tp.i00, c, hw)]) : 0.f, v01 = tp.v01 ? to_f32(x[x_at<NHWC>(b, ch, tp.i01, c, hw)]) : 0.f;
-      const float v10 = tp.v10 ? to_f32(x[x_at<NHWC>(b, ch, tp.i10, c, hw)]) : 0.f, v11 = tp.v11 ? to_f32(x[x_at<NHWC>(b, ch, tp.i11, c, hw)]) : 0.f;
+      const float v00 = tp.v00 ? to_f32(x[x_at(b, ch, tp.i00, c, hw)]) : 0.f, v01 = tp.v01 ? to_f32(x[x_at(b, ch, tp.i01, c, hw)]) : 0.f;
+      const float v10 = tp.v10 ? to_f32(x[x_at(b, ch, tp.i10, c, hw)]) : 0.f, v11 = tp.v11 ? to_f32(x[x_at(b, ch, tp.i11, c, hw)]) : 0.f;
       const float gv = to_f32(*g);
       gy = fmaf(gv, (v10 - v00) * hx + (v11 - v01) * tp.lx, gy);
       gx = fmaf(gv, (v01 - v00) * hy + (v11 - v10) * tp.ly, gx);
@@ -257,7 +257,7 @@ static size_t deform_ws_offsets(int b, int h, int w, int k, size_t* entries_at) 
   return starts + (size_t)b * 4 * k * k * hw * sizeof(uint2);
 }
 
-template <typename TC, typename TX, bool NHWC>
+template <typename TC, typename TX>
 static void launch_gather(const TC* dcol, const int* starts, const uint2* entries, TX* dx, int b, int c, int hw, int kk,
                           hipStream_t st) {
   const size_t row = (size_t)kk * hw * sizeof(TC);
@@ -271,8 +271,8 @@ static void launch_gather(const TC* dcol, const int* starts, const uint2* entrie
 #define DHD_GATHER(NC)                                                                                                        \
   do {                                                                                                                        \
     if (lds > 48 * 1024)                                                                                                      \
-      (void)hipFuncSetAttribute((const void*)deform_col2im_gather<TC, NC, TX, NHWC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((deform_col2im_gather<TC, NC, TX, NHWC>), grid, dim3(kBlock), lds, st, dcol, starts, entries, dx, c, hw, kk, vec_ok); \
+      (void)hipFuncSetAttribute((const void*)deform_col2im_gather<TC, NC, TX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((deform_col2im_gather<TC, NC, TX>), grid, dim3(kBlock), lds, st, dcol, starts, entries, dx, c, hw, kk, vec_ok); \
   } while (0)
   if (nc == 8) DHD_GATHER(8);
   else if (nc == 4) DHD_GATHER(4);
@@ -281,30 +281,22 @@ static void launch_gather(const TC* dcol, const int* starts, const uint2* entrie
 #undef DHD_GATHER
 }
 
-// x may be float32 (any col_dtype) or of the column type itself; dense NCHW or channels_last
+// x may be float32 (any col_dtype) or of the column type itself; dense NCHW
 static bool x_combo_ok(int x_dtype, int col_dtype) { return x_dtype == DHD_F32 || x_dtype == col_dtype; }
 
 template <typename TC, typename TX>
-static void launch_im2col(const void* x, int x_nhwc, const float* offset, void* col, dim3 grid, hipStream_t st, int c, int h, int w, int k,
-                          int pad, int dil, int c_chunk) {
-  if (x_nhwc)
-    hipLaunchKernelGGL((deform_im2col<TC, TX, true>), grid, dim3(kBlock), 0, st, (const TX*)x, offset, (TC*)col, c, h, w, k, pad, dil, c_chunk);
-  else
-    hipLaunchKernelGGL((deform_im2col<TC, TX, false>), grid, dim3(kBlock), 0, st, (const TX*)x, offset, (TC*)col, c, h, w, k, pad, dil, c_chunk);
+static void launch_im2col(const void* x, const float* offset, void* col, dim3 grid, hipStream_t st, int c, int h, int w, int k, int pad,
+                          int dil, int c_chunk) {
+  hipLaunchKernelGGL((deform_im2col<TC, TX>), grid, dim3(kBlock), 0, st, (const TX*)x, offset, (TC*)col, c, h, w, k, pad, dil, c_chunk);
 }
 
 template <typename TC, typename TX>
-static void launch_col2im(const void* dcol, const void* x, int x_nhwc, const float* offset, void* dx, float* doffset, const int* starts,
+static void launch_col2im(const void* dcol, const void* x, const float* offset, void* dx, float* doffset, const int* starts,
                           const uint2* entries, int b, int c, int h, int w, int k, int pad, int dil, hipStream_t st) {
   const int hw = h * w, kk = k * k;
-  const dim3 ogrid(dhd_cdiv((long)kk * hw, kBlock), b);
-  if (x_nhwc) {
-    launch_gather<TC, TX, true>((const TC*)dcol, starts, entries, (TX*)dx, b, c, hw, kk, st);
-    hipLaunchKernelGGL((deform_col2offset<TC, TX, true>), ogrid, dim3(kBlock), 0, st, (const TC*)dcol, (const TX*)x, offset, doffset, c, h, w, k, pad, dil);
-  } else {
-    launch_gather<TC, TX, false>((const TC*)dcol, starts, entries, (TX*)dx, b, c, hw, kk, st);
-    hipLaunchKernelGGL((deform_col2offset<TC, TX, false>), ogrid, dim3(kBlock), 0, st, (const TC*)dcol, (const TX*)x, offset, doffset, c, h, w, k, pad, dil);
-  }
+  launch_gather<TC, TX>((const TC*)dcol, starts, entries, (TX*)dx, b, c, hw, kk, st);
+  hipLaunchKernelGGL((deform_col2offset<TC, TX>), dim3(dhd_cdiv((long)kk * hw, kBlock), b), dim3(kBlock), 0, st, (const TC*)dcol, (const TX*)x,
+                     offset, doffset, c, h, w, k, pad, dil);
 }
 
 inline bool bad_shape(int b, int c, int h, int w, int k, int dil) { return b <= 0 || c <= 0 || h <= 0 || w <= 0 || k <= 0 || dil <= 0; }
@@ -313,7 +305,7 @@ inline bool bad_shape(int b, int c, int h, int w, int k, int dil) { return b <= 
 
 extern "C" {
 
-int dhd_deform_im2col_t(const void* x, int x_dtype, int x_nhwc, const float* offset, void* col, int col_dtype, int b, int c, int h, int w,
+int dhd_deform_im2col_t(const void* x, int x_dtype, const float* offset, void* col, int col_dtype, int b, int c, int h, int w,
                         int k, int pad, int dil, void* stream) {
   if (!x || !offset || !col || bad_shape(b, c, h, w, k, dil)) return DHD_EINVAL;
   if (col_dtype < DHD_F32 || col_dtype > DHD_BF16 || !x_combo_ok(x_dtype, col_dtype)) return DHD_EINVAL;
@@ -321,18 +313,18 @@ int dhd_deform_im2col_t(const void* x, int x_dtype, int x_nhwc, const float* off
   const int c_chunk = c >= 32 ? 32 : c;
   const dim3 grid(dhd_cdiv((long)k * k * h * w, kBlock), dhd_cdiv(c, c_chunk), b);
   hipStream_t st = dhd_stream(stream);
-  if (col_dtype == DHD_F32) launch_im2col<float, float>(x, x_nhwc, offset, col, grid, st, c, h, w, k, pad, dil, c_chunk);
-  else if (col_dtype == DHD_F16 && x_dtype == DHD_F32) launch_im2col<_Float16, float>(x, x_nhwc, offset, col, grid, st, c, h, w, k, pad, dil, c_chunk);
-  else if (col_dtype == DHD_F16) launch_im2col<_Float16, _Float16>(x, x_nhwc, offset, col, grid, st, c, h, w, k, pad, dil, c_chunk);
-  else if (x_dtype == DHD_F32) launch_im2col<bf16_t, float>(x, x_nhwc, offset, col, grid, st, c, h, w, k, pad, dil, c_chunk);
-  else launch_im2col<bf16_t, bf16_t>(x, x_nhwc, offset, col, grid, st, c, h, w, k, pad, dil, c_chunk);
+  if (col_dtype == DHD_F32) launch_im2col<float, float>(x, offset, col, grid, st, c, h, w, k, pad, dil, c_chunk);
+  else if (col_dtype == DHD_F16 && x_dtype == DHD_F32) launch_im2col<_Float16, float>(x, offset, col, grid, st, c, h, w, k, pad, dil, c_chunk);
+  else if (col_dtype == DHD_F16) launch_im2col<_Float16, _Float16>(x, offset, col, grid, st, c, h, w, k, pad, dil, c_chunk);
+  else if (x_dtype == DHD_F32) launch_im2col<bf16_t, float>(x, offset, col, grid, st, c, h, w, k, pad, dil, c_chunk);
+  else launch_im2col<bf16_t, bf16_t>(x, offset, col, grid, st, c, h, w, k, pad, dil, c_chunk);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }
 
 int dhd_deform_im2col(const float* x, const float* offset, float* col, int b, int c, int h, int w, int k, int pad, int dil,
                       void* stream) {
-  return dhd_deform_im2col_t(x, DHD_F32, 0, offset, col, DHD_F32, b, c, h, w, k, pad, dil, stream);
+  return dhd_deform_im2col_t(x, DHD_F32, offset, col, DHD_F32, b, c, h, w, k, pad, dil, stream);
 }
 
 size_t dhd_deform_col2im_workspace_bytes(int b, int h, int w, int k) {
@@ -346,7 +338,7 @@ int dhd_deform_col2im_gather_supported(int col_dtype, int h, int w, int k) {
   return khw * esz <= 144 * 1024 && (2 * (size_t)h * w + kSortBlock) * sizeof(int) <= kSortLdsMax && khw < (1u << 30);
 }
 
-int dhd_deform_col2im_t(const void* dcol, int col_dtype, const void* x, int x_dtype, int x_nhwc, const float* offset, void* dx,
+int dhd_deform_col2im_t(const void* dcol, int col_dtype, const void* x, int x_dtype, const float* offset, void* dx,
                         float* doffset, int b, int c, int h, int w, int k, int pad, int dil, void* workspace, size_t workspace_bytes,
                         void* stream) {
   if (!dcol || !x || !offset || !dx || !doffset || !workspace || bad_shape(b, c, h, w, k, dil)) return DHD_EINVAL;
@@ -359,11 +351,11 @@ int dhd_deform_col2im_t(const void* dcol, int col_dtype, const void* x, int x_dt
   hipStream_t st = dhd_stream(stream);
   hipLaunchKernelGGL(deform_tap_sort, dim3(b), dim3(kSortBlock), (2 * (size_t)h * w + kSortBlock) * sizeof(int), st, offset, starts, entries,
                      h, w, k, pad, dil);
-  if (col_dtype == DHD_F32) launch_col2im<float, float>(dcol, x, x_nhwc, offset, dx, doffset, starts, entries, b, c, h, w, k, pad, dil, st);
-  else if (col_dtype == DHD_F16 && x_dtype == DHD_F32) launch_col2im<_Float16, float>(dcol, x, x_nhwc, offset, dx, doffset, starts, entries, b, c, h, w, k, pad, dil, st);
-  else if (col_dtype == DHD_F16) launch_col2im<_Float16, _Float16>(dcol, x, x_nhwc, offset, dx, doffset, starts, entries, b, c, h, w, k, pad, dil, st);
-  else if (x_dtype == DHD_F32) launch_col2im<bf16_t, float>(dcol, x, x_nhwc, offset, dx, doffset, starts, entries, b, c, h, w, k, pad, dil, st);
-  else launch_col2im<bf16_t, bf16_t>(dcol, x, x_nhwc, offset, dx, doffset, starts, entries, b, c, h, w, k, pad, dil, st);
+  if (col_dtype == DHD_F32) launch_col2im<float, float>(dcol, x, offset, dx, doffset, starts, entries, b, c, h, w, k, pad, dil, st);
+  else if (col_dtype == DHD_F16 && x_dtype == DHD_F32) launch_col2im<_Float16, float>(dcol, x, offset, dx, doffset, starts, entries, b, c, h, w, k, pad, dil, st);
+  else if (col_dtype == DHD_F16) launch_col2im<_Float16, _Float16>(dcol, x, offset, dx, doffset, starts, entries, b, c, h, w, k, pad, dil, st);
+  else if (x_dtype == DHD_F32) launch_col2im<bf16_t, float>(dcol, x, offset, dx, doffset, starts, entries, b, c, h, w, k, pad, dil, st);
+  else launch_col2im<bf16_t, bf16_t>(dcol, x, offset, dx, doffset, starts, entries, b, c, h, w, k, pad, dil, st);
   DHD_LAUNCH_CHECK();
   return DHD_OK;
 }

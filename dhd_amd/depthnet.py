@@ -37,20 +37,12 @@ class BasicBlock(nn.Module):
         return bn_act(self.bn2, self.conv2(out), residual=identity)
 
 
-def _dense4(t):
-    """(tensor, nhwc flag): `t` where it lies if it is dense NCHW or dense channels_last, else an NCHW copy."""
-    if t.is_contiguous():
-        return t, 0
-    if t.is_contiguous(memory_format=torch.channels_last):
-        return t, 1
-    return t.contiguous(), 0
-
-
 class _DeformIm2col(torch.autograd.Function):
     """x (B,C,H,W), offset (B,2kk,H,W) -> col (B, C*kk, H*W) through libdhd_amd.so (csrc/deform.hip).  `col_dtype`: float32, or the
     autocast half type -- the GEMM behind the sampling runs in it, so the 155 MB column matrix of the DHD-S HeightNet is written
-    once as 78 MB of half and its gradient is read as half, with no cast kernels in between.  x is read where it lies (float32 or
-    col_dtype, NCHW or channels_last) and its gradient comes back in the same dtype and layout.  Backward: the gather form of
+    once as 78 MB of half and its gradient is read as half, with no cast kernels in between.  x is read in its own dtype (float32
+    or col_dtype; one NCHW copy if it arrives channels_last: the sampling kernels want consecutive cells on consecutive lanes) and
+    its gradient comes back in that dtype.  Backward: the gather form of
     col2im (dhd_deform_col2im_t) where the library takes the shape, else the float32 LDS-atomic form."""
 
     @staticmethod
@@ -60,24 +52,24 @@ class _DeformIm2col(torch.autograd.Function):
             raise _lib.DhdError(f'DCN input must live on the GPU: dhd_amd runs only as HIP kernels (got {x.device})')
         if x.dtype not in (torch.float32, col_dtype):
             x = x.float()
-        x, nhwc = _dense4(x)
+        x = x.contiguous()
         offset = _lib.require_gpu_tensor(offset.float().contiguous(), torch.float32, 'DCN offsets')
         b, c, h, w = x.shape
         dev = x.device
         with torch.cuda.device(dev):
             col = torch.empty((b, c * k * k, h * w), dtype=col_dtype, device=dev)
-            _lib.check(_lib.load().dhd_deform_im2col_t(_lib.ptr(x), _lib.dtype_code(x.dtype), nhwc, _lib.ptr(offset), _lib.ptr(col),
+            _lib.check(_lib.load().dhd_deform_im2col_t(_lib.ptr(x), _lib.dtype_code(x.dtype), _lib.ptr(offset), _lib.ptr(col),
                                                        _lib.dtype_code(col_dtype), b, c, h, w, k, pad, dil, _lib.stream_ptr(dev)),
                        'dhd_deform_im2col_t')
         ctx.save_for_backward(x, offset)
-        ctx.args = (k, pad, dil, col_dtype, nhwc)
+        ctx.args = (k, pad, dil, col_dtype)
         return col
 
     @staticmethod
     def backward(ctx, dcol):
         from . import _lib
         x, offset = ctx.saved_tensors
-        k, pad, dil, col_dtype, nhwc = ctx.args
+        k, pad, dil, col_dtype = ctx.args
         b, c, h, w = x.shape
         dev = x.device
         lib = _lib.load()
@@ -87,7 +79,7 @@ class _DeformIm2col(torch.autograd.Function):
                 dx = torch.empty_like(x)      # x's dtype and strides
                 dcol = dcol.to(col_dtype).contiguous()
                 ws = torch.empty(lib.dhd_deform_col2im_workspace_bytes(b, h, w, k), dtype=torch.uint8, device=dev)
-                _lib.check(lib.dhd_deform_col2im_t(_lib.ptr(dcol), _lib.dtype_code(col_dtype), _lib.ptr(x), _lib.dtype_code(x.dtype), nhwc,
+                _lib.check(lib.dhd_deform_col2im_t(_lib.ptr(dcol), _lib.dtype_code(col_dtype), _lib.ptr(x), _lib.dtype_code(x.dtype),
                                                    _lib.ptr(offset), _lib.ptr(dx), _lib.ptr(doff), b, c, h, w, k, pad, dil, _lib.ptr(ws),
                                                    ws.numel(), _lib.stream_ptr(dev)), 'dhd_deform_col2im_t')
             else:

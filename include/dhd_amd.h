@@ -528,19 +528,20 @@ int dhd_deform_col2im(const float* dcol, const float* x, const float* offset, fl
                       void* stream);
 /* ABI 5.  The same two operators with the column matrix in `col_dtype` (DHD_F32 / DHD_F16 / DHD_BF16: under autocast the GEMM
  * behind the sampling runs in half, so the columns are written, and their gradient read, in half; offset, doffset and the
- * arithmetic stay float32), x read -- and dx written -- where the caller has them: `x_dtype` float32 or equal to col_dtype,
- * dense NCHW (x_nhwc = 0) or channels_last (1), no staging copies; and col2im in its GATHER form: the bilinear corner entries of an image are grouped by the cell they
+ * arithmetic stay float32), x read -- and dx written -- in `x_dtype`: float32 or col_dtype (dense NCHW: the sampling kernels put
+ * consecutive cells on consecutive lanes; a channels_last x measured 5-7x slower and is converted by the caller); and col2im in
+ * its GATHER form: the bilinear corner entries of an image are grouped by the cell they
  * land in (they are shared by all channels), then every cell sums its own list from LDS-staged dcol rows -- no atomics
  * (csrc/deform.hip).  `workspace`: dhd_deform_col2im_workspace_bytes(b, h, w, k) bytes of device scratch, 16-byte aligned,
  * owned by the caller.  Shapes the gather form does not take (dhd_deform_col2im_gather_supported == 0: k*k*h*w elements of
  * `col_dtype` must fit 144 KiB of LDS) return DHD_EUNSUPPORTED; dhd_deform_col2im covers them in float32. */
-int dhd_deform_im2col_t(const void* x, int x_dtype, int x_nhwc, const float* offset, void* col,
-                        int col_dtype, int b, int c, int h, int w, int k, int pad, int dil, void* stream);
+int dhd_deform_im2col_t(const void* x, int x_dtype, const float* offset, void* col, int col_dtype,
+                        int b, int c, int h, int w, int k, int pad, int dil, void* stream);
 size_t dhd_deform_col2im_workspace_bytes(int b, int h, int w, int k);
 int dhd_deform_col2im_gather_supported(int col_dtype, int h, int w, int k);
-int dhd_deform_col2im_t(const void* dcol, int col_dtype, const void* x, int x_dtype, int x_nhwc,
-                        const float* offset, void* dx, float* doffset, int b, int c, int h, int w, int k,
-                        int pad, int dil, void* workspace, size_t workspace_bytes, void* stream);
+int dhd_deform_col2im_t(const void* dcol, int col_dtype, const void* x, int x_dtype, const float* offset,
+                        void* dx, float* doffset, int b, int c, int h, int w, int k, int pad, int dil,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ABI 5.  The element-wise head of MGHS.forward / MGHS_Depth.forward (lss_heightmap.py:484-489, :829-834) in one launch each
  * way (csrc/mghs_softmax.hip):

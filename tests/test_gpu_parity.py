@@ -1758,14 +1758,14 @@ def test_dcn_gather_col2im_vs_atomic_form_and_typed_columns(gpu, dtype, b, c, h,
     col32 = torch.empty(b, c * k * k, h * w, device=gpu)
     _lib.check(lib.dhd_deform_im2col(_lib.ptr(x), _lib.ptr(off), _lib.ptr(col32), b, c, h, w, k, dil, dil, st), 'im2col')
     col = torch.empty(b, c * k * k, h * w, device=gpu, dtype=dtype)
-    _lib.check(lib.dhd_deform_im2col_t(_lib.ptr(x), 0, 0, _lib.ptr(off), _lib.ptr(col), code, b, c, h, w, k, dil, dil, st), 'im2col_t')
+    _lib.check(lib.dhd_deform_im2col_t(_lib.ptr(x), 0, _lib.ptr(off), _lib.ptr(col), code, b, c, h, w, k, dil, dil, st), 'im2col_t')
     assert torch.equal(col, col32.to(dtype))
-    # x in the column type and channels_last, read where it lies: the columns of the rounded x
-    xh = x.to(dtype).contiguous(memory_format=torch.channels_last)
+    # x in the column type: the columns of the rounded x
+    xh = x.to(dtype)
     colh = torch.empty_like(col)
-    _lib.check(lib.dhd_deform_im2col_t(_lib.ptr(xh), code, 1, _lib.ptr(off), _lib.ptr(colh), code, b, c, h, w, k, dil, dil, st), 'im2col_t nhwc')
+    _lib.check(lib.dhd_deform_im2col_t(_lib.ptr(xh), code, _lib.ptr(off), _lib.ptr(colh), code, b, c, h, w, k, dil, dil, st), 'im2col_t nhwc')
     ref = torch.empty_like(col32)
-    _lib.check(lib.dhd_deform_im2col(_lib.ptr(xh.float().contiguous()), _lib.ptr(off), _lib.ptr(ref), b, c, h, w, k, dil, dil, st), 'im2col')
+    _lib.check(lib.dhd_deform_im2col(_lib.ptr(xh.float()), _lib.ptr(off), _lib.ptr(ref), b, c, h, w, k, dil, dil, st), 'im2col')
     assert torch.equal(colh, ref.to(dtype))
     dcol = torch.randn(b, c * k * k, h * w, device=gpu).to(dtype)
     dx0, doff0 = torch.empty_like(x), torch.empty_like(off)
@@ -1774,30 +1774,29 @@ def test_dcn_gather_col2im_vs_atomic_form_and_typed_columns(gpu, dtype, b, c, h,
     assert lib.dhd_deform_col2im_gather_supported(code, h, w, k)
     ws = torch.empty(lib.dhd_deform_col2im_workspace_bytes(b, h, w, k), dtype=torch.uint8, device=gpu)
     dx1, doff1 = torch.full_like(x, float('nan')), torch.full_like(off, float('nan'))
-    _lib.check(lib.dhd_deform_col2im_t(_lib.ptr(dcol), code, _lib.ptr(x), 0, 0, _lib.ptr(off), _lib.ptr(dx1), _lib.ptr(doff1), b, c, h, w, k, dil, dil,
+    _lib.check(lib.dhd_deform_col2im_t(_lib.ptr(dcol), code, _lib.ptr(x), 0, _lib.ptr(off), _lib.ptr(dx1), _lib.ptr(doff1), b, c, h, w, k, dil, dil,
                                        _lib.ptr(ws), ws.numel(), st), 'col2im_t')
     assert torch.isfinite(dx1).all() and torch.isfinite(doff1).all()
     assert (dx1 - dx0).abs().max().item() <= 2e-5 * max(1.0, dx0.abs().max().item())
     assert torch.equal(doff1, doff0)                 # same kernel, same order of operations
-    # x / dx in the column type, channels_last: dx = the float32 result rounded once, doffset from the rounded x
+    # x / dx in the column type: dx = the float32 result rounded once, doffset from the rounded x
     dxh = torch.full_like(xh, float('nan'))
     doffh = torch.empty_like(off)
-    _lib.check(lib.dhd_deform_col2im_t(_lib.ptr(dcol), code, _lib.ptr(xh), code, 1, _lib.ptr(off), _lib.ptr(dxh), _lib.ptr(doffh), b, c, h, w, k, dil,
+    _lib.check(lib.dhd_deform_col2im_t(_lib.ptr(dcol), code, _lib.ptr(xh), code, _lib.ptr(off), _lib.ptr(dxh), _lib.ptr(doffh), b, c, h, w, k, dil,
                                        dil, _lib.ptr(ws), ws.numel(), st), 'col2im_t nhwc')
-    assert dxh.is_contiguous(memory_format=torch.channels_last)
     ulp = {torch.float32: 2e-5, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
     assert (dxh.float() - dx0).abs().max().item() <= ulp * max(1.0, dx0.abs().max().item())
     doff2 = torch.empty_like(off)
-    _lib.check(lib.dhd_deform_col2im(_lib.ptr(dcol.float().contiguous()), _lib.ptr(xh.float().contiguous()), _lib.ptr(off), _lib.ptr(dx0), _lib.ptr(doff2),
+    _lib.check(lib.dhd_deform_col2im(_lib.ptr(dcol.float().contiguous()), _lib.ptr(xh.float()), _lib.ptr(off), _lib.ptr(dx0), _lib.ptr(doff2),
                                      b, c, h, w, k, dil, dil, st), 'col2im')
     assert torch.equal(doffh, doff2)
     # too small a workspace is refused, nothing is launched
-    assert lib.dhd_deform_col2im_t(_lib.ptr(dcol), code, _lib.ptr(x), 0, 0, _lib.ptr(off), _lib.ptr(dx1), _lib.ptr(doff1), b, c, h, w, k, dil, dil,
+    assert lib.dhd_deform_col2im_t(_lib.ptr(dcol), code, _lib.ptr(x), 0, _lib.ptr(off), _lib.ptr(dx1), _lib.ptr(doff1), b, c, h, w, k, dil, dil,
                                    _lib.ptr(ws), ws.numel() - 1, st) == -1
     # a float16 x with bfloat16 columns (neither float32 nor the column type) is refused
     if dtype != torch.float32:
         other = 3 - code
-        assert lib.dhd_deform_col2im_t(_lib.ptr(dcol), code, _lib.ptr(xh), other, 1, _lib.ptr(off), _lib.ptr(dxh), _lib.ptr(doffh), b, c, h, w, k, dil,
+        assert lib.dhd_deform_col2im_t(_lib.ptr(dcol), code, _lib.ptr(xh), other, _lib.ptr(off), _lib.ptr(dxh), _lib.ptr(doffh), b, c, h, w, k, dil,
                                        dil, _lib.ptr(ws), ws.numel(), st) == -1
 
 
@@ -1874,7 +1873,8 @@ def test_depth_height_head_one_launch_vs_torch(gpu, dtype, layout, bn, d, c, hb,
     bit_equal = torch.equal(depth, depth_r) and torch.equal(height, height_r)
     print('softmax bit-identical to torch:', bit_equal)
     assert (depth - depth_r).abs().max().item() <= 2 ** -23 and (height - height_r).abs().max().item() <= 2 ** -23
-    assert bit_equal
+    if fh * fw > 64:       # aten's one-thread-per-pixel form (every DHD configuration: 16x44, 32x88); smaller maps reduce in a block
+        assert bit_equal
     assert torch.equal(feat, feat_r)
     assert torch.equal(band, mghs_op.height_band(height, hr, mr))
     gd, gf, gh = torch.randn_like(depth), torch.randn_like(feat), torch.randn_like(height)
