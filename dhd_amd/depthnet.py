@@ -40,9 +40,8 @@ class BasicBlock(nn.Module):
 class _DeformIm2col(torch.autograd.Function):
     """x (B,C,H,W), offset (B,2kk,H,W) -> col (B, C*kk, H*W) through libdhd_amd.so (csrc/deform.hip).  `col_dtype`: float32, or the
     autocast half type -- the GEMM behind the sampling runs in it, so the 155 MB column matrix of the DHD-S HeightNet is written
-    once as 78 MB of half and its gradient is read as half, with no cast kernels in between.  x is read in its own dtype (float32
-    or col_dtype; one NCHW copy if it arrives channels_last: the sampling kernels want consecutive cells on consecutive lanes) and
-    its gradient comes back in that dtype.  Backward: the gather form of
+    once as 78 MB of half and its gradient is read as half, with no cast kernels in between.  x is staged as float32 NCHW (the
+    sampling kernels want consecutive cells on consecutive lanes and 4-byte gathers).  Backward: the gather form of
     col2im (dhd_deform_col2im_t) where the library takes the shape, else the float32 LDS-atomic form."""
 
     @staticmethod
@@ -50,9 +49,9 @@ class _DeformIm2col(torch.autograd.Function):
         from . import _lib
         if not x.is_cuda:
             raise _lib.DhdError(f'DCN input must live on the GPU: dhd_amd runs only as HIP kernels (got {x.device})')
-        if x.dtype not in (torch.float32, col_dtype):
-            x = x.float()
-        x = x.contiguous()
+        # float32 NCHW staging copy of x (8.6 -> 17 MB at the DHD-S size): the library also reads a half x (x_dtype), but its
+        # corner gathers as 2-byte loads ran col2offset at 466 us against 138 us on the float32 copy (profiles/r6)
+        x = x.float().contiguous()
         offset = _lib.require_gpu_tensor(offset.float().contiguous(), torch.float32, 'DCN offsets')
         b, c, h, w = x.shape
         dev = x.device
