@@ -1765,11 +1765,13 @@ def test_dcn_gather_col2im_vs_atomic_form_and_typed_columns(gpu, dtype, b, c, h,
     colh = torch.empty_like(col)
     _lib.check(lib.dhd_deform_im2col_t(_lib.ptr(xh), code, _lib.ptr(off), _lib.ptr(colh), code, b, c, h, w, k, dil, dil, st), 'im2col_t nhwc')
     ref = torch.empty_like(col32)
-    _lib.check(lib.dhd_deform_im2col(_lib.ptr(xh.float()), _lib.ptr(off), _lib.ptr(ref), b, c, h, w, k, dil, dil, st), 'im2col')
+    xh32 = xh.float()
+    _lib.check(lib.dhd_deform_im2col(_lib.ptr(xh32), _lib.ptr(off), _lib.ptr(ref), b, c, h, w, k, dil, dil, st), 'im2col')
     assert torch.equal(colh, ref.to(dtype))
     dcol = torch.randn(b, c * k * k, h * w, device=gpu).to(dtype)
     dx0, doff0 = torch.empty_like(x), torch.empty_like(off)
-    _lib.check(lib.dhd_deform_col2im(_lib.ptr(dcol.float().contiguous()), _lib.ptr(x), _lib.ptr(off), _lib.ptr(dx0), _lib.ptr(doff0), b, c, h, w,
+    dcol32 = dcol.float().contiguous()          # (kept in variables: a temporary freed before the launch could be handed out again)
+    _lib.check(lib.dhd_deform_col2im(_lib.ptr(dcol32), _lib.ptr(x), _lib.ptr(off), _lib.ptr(dx0), _lib.ptr(doff0), b, c, h, w,
                                      k, dil, dil, st), 'col2im')
     assert lib.dhd_deform_col2im_gather_supported(code, h, w, k)
     ws = torch.empty(lib.dhd_deform_col2im_workspace_bytes(b, h, w, k), dtype=torch.uint8, device=gpu)
@@ -1787,7 +1789,7 @@ def test_dcn_gather_col2im_vs_atomic_form_and_typed_columns(gpu, dtype, b, c, h,
     ulp = {torch.float32: 2e-5, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
     assert (dxh.float() - dx0).abs().max().item() <= ulp * max(1.0, dx0.abs().max().item())
     doff2 = torch.empty_like(off)
-    _lib.check(lib.dhd_deform_col2im(_lib.ptr(dcol.float().contiguous()), _lib.ptr(xh.float()), _lib.ptr(off), _lib.ptr(dx0), _lib.ptr(doff2),
+    _lib.check(lib.dhd_deform_col2im(_lib.ptr(dcol32), _lib.ptr(xh32), _lib.ptr(off), _lib.ptr(dx0), _lib.ptr(doff2),
                                      b, c, h, w, k, dil, dil, st), 'col2im')
     assert torch.equal(doffh, doff2)
     # too small a workspace is refused, nothing is launched
