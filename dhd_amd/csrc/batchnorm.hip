@@ -161,8 +161,7 @@ __global__ __launch_bounds__(kBnBlock) void bn_forward_finalize(const float* __r
     s2 += (double)part[((size_t)q * 2 + 1) * c + ch];
   }
   const double cnt = (double)n * (double)hw, shift = (double)(float)x[(size_t)ch * hw];
-  const double m = s1 / cnt, v0 = s2 / cnt - m * m, mean = shift + m;
-  const double var = v0 < 0.0 ? 0.0 : v0;   // not fmax(v0, 0): a non-finite channel (inf - inf) must stay NaN, as in torch
+  const double m = s1 / cnt, var = fmax(s2 / cnt - m * m, 0.0), mean = shift + m;   // (inf - inf clamps to 0, as torch's kernels do: an Inf input turns the channel's finite entries into -inf)
   const double rstd = 1.0 / sqrt(var + (double)eps);
   save_mean[ch] = (float)mean;
   save_rstd[ch] = (float)rstd;
@@ -403,8 +402,7 @@ __global__ __launch_bounds__(kBnBlock) void bn_cl_forward_finalize(const float* 
   fold_parts(part, n_part, c, ch, lane, &s1, &s2);
   if (lane) return;
   const double shift = (double)(float)x[ch];
-  const double m = s1 / cnt, v0 = s2 / cnt - m * m, mean = shift + m;
-  const double var = v0 < 0.0 ? 0.0 : v0;   // not fmax(v0, 0): a non-finite channel (inf - inf) must stay NaN, as in torch
+  const double m = s1 / cnt, var = fmax(s2 / cnt - m * m, 0.0), mean = shift + m;   // (inf - inf clamps to 0, as torch's kernels do: an Inf input turns the channel's finite entries into -inf)
   const double rstd = 1.0 / sqrt(var + (double)eps);
   save_mean[ch] = (float)mean;
   save_rstd[ch] = (float)rstd;
