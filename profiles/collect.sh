@@ -53,8 +53,8 @@ head -1 $(find $OUT/ef -name 'ef_counter_collection.csv') > $OUT/pmc_ema.csv
 grep -h ema_update_kernel $(find $OUT/ef -name 'ef_counter_collection.csv') $(find $OUT/ew -name 'ew_counter_collection.csv') >> $OUT/pmc_ema.csv
 rm -rf $OUT/es $OUT/ef $OUT/ew
 fi
-PREV=${PREV_PROFILES:-$R/profiles/r4}
-ROUND=${ROUND:-r5}
+PREV=${PREV_PROFILES:-$R/profiles/r5}
+ROUND=${ROUND:-r6}
 [ -f $OUT/pmc_fetch_size.csv ] || cp $PREV/pmc_fetch_size.csv $PREV/pmc_write_size.csv $OUT/
 [ -f $OUT/pmc_ema.csv ] || cp $PREV/pmc_ema.csv $OUT/ 2>/dev/null || head -1 $OUT/pmc_fetch_size.csv > $OUT/pmc_ema.csv
 cd $R
@@ -77,12 +77,21 @@ def means(path, counter):
 f, w = means(out + '/pmc_fetch_size.csv', 'FETCH_SIZE'), means(out + '/pmc_write_size.csv', 'WRITE_SIZE')
 f.update(means(out + '/pmc_ema.csv', 'FETCH_SIZE')); w.update(means(out + '/pmc_ema.csv', 'WRITE_SIZE'))  # bench.py --workload ema
 ks = {}
+FETCH_FACTOR = {'mghs_stream_fwd': 1.0}
 for k in sorted(set(f) | set(w)):
     if k.startswith('Cijk') or 'at::native' in k or k.startswith('__amd'): continue
-    ks[k] = dict(FETCH_SIZE_KB=f.get(k, 0.0), WRITE_SIZE_KB=w.get(k, 0.0), hbm_bytes_per_launch=int((2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024))
+    # gfx950: FETCH_SIZE tallies a 128-byte request at 64 bytes -- HALF the bytes of any fully coalesced read (16 B or 4 B per lane), but
+    # EXACTLY the bytes of a read made of 64-byte pieces (experiments/fetch_size_calib.hip, profiles/r6/fetch_size_calib.txt: 0.500 /
+    # 0.500 / 1.000 of 768 MiB; WRITE_SIZE 1.003).  The writer's reads are such pieces: every (segment, channel part) workgroup takes
+    # 16 channels x 4 B of each 256-byte vsum row; its coalesced index reads (nzvox, <= 3 MB) are then undercounted by <= 3 MB.
+    ff = FETCH_FACTOR.get(k, 2.0)
+    ks[k] = dict(FETCH_SIZE_KB=f.get(k, 0.0), WRITE_SIZE_KB=w.get(k, 0.0), fetch_factor=ff,
+                 hbm_bytes_per_launch=int((ff * f.get(k, 0.0) + w.get(k, 0.0)) * 1024))
 json.dump(dict(samples_per_gpu=4, source_sha256=kernel_source_sha256(),
                command='rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 5 --warmup 2 --pmc-pass (two separate passes)',
-               correction='bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of a wide coalesced read)',
+               correction='bytes = (fetch_factor*FETCH_SIZE + WRITE_SIZE) * 1024; fetch_factor 2 (gfx950: FETCH_SIZE reports half of a coalesced '
+                          'read) except where a kernel reads 64-byte pieces, which the counter reports exactly (mghs_stream_fwd: 1; calibration '
+                          'profiles/r6/fetch_size_calib.txt)',
                kernels=ks), open(out + '/pmc_summary.json', 'w'), indent=1)
 print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in ks.items()}, indent=0)[:3000])
 if os.path.exists(out + '/pmc_sfa_half.csv'):
