@@ -22,6 +22,7 @@
 // A generic dense-row path (any C, any grid shape) is kept for configurations the compact path does
 // not cover.
 #include "lift_device.h"
+#include <stdlib.h>
 #include "mghs_layout.h"
 
 namespace dhd {
@@ -124,8 +125,8 @@ struct GatherStep<DHD_WAVE> {
 
 // BANDS_ONLY: the entries of the full-height grid 0 (the first offset[vox_base[1]] of the list) are left to mghs_col_sums.
 template <bool BANDS_ONLY>
-__global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float* __restrict__ depth,
-                                                            const float* __restrict__ feat) {
+__device__ __forceinline__ void gather_sums_body(const Layout& L, const float* __restrict__ depth, const float* __restrict__ feat,
+                                                 const int block) {
   const int lane = threadIdx.x & 63;
   const int T0 = BANDS_ONLY ? L.offset[L.vox_base[1]] : 0;
   const int T = L.offset[L.V];  // total entries (device-side value, scalar load)
@@ -134,8 +135,8 @@ __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float
   // XCD x (workgroups x, x+8, ...) takes the x-th eighth of the entries actually present: entries are
   // sorted by voxel, so one XCD's waves gather a compact part of the feature map through their L2
   const int per_xcd = ((T - T0 + kBlock - 1) / kBlock + 7) >> 3;
-  if ((int)(blockIdx.x >> 3) >= per_xcd) return;
-  const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((block >> 3) >= per_xcd) return;
+  const int wg = (block & 7) * per_xcd + (block >> 3);
   const int a = rfl(T0 + (wg * (kBlock / DHD_WAVE) + (threadIdx.x >> 6)) * DHD_WAVE);
   if (a >= T) return;
   const int b = min(T, a + DHD_WAVE);
@@ -204,6 +205,12 @@ __global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float
   vrow[(size_t)cur * kTileC] = acc;
 }
 
+template <bool BANDS_ONLY>
+__global__ __launch_bounds__(kBlock) void mghs_gather_sums(Layout L, const float* __restrict__ depth,
+                                                            const float* __restrict__ feat) {
+  gather_sums_body<BANDS_ONLY>(L, depth, feat, (int)blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------
 // 1b. forward sums of the FULL-HEIGHT grid 0 by pixel column ("column form").
 // Grid 0 pools every pixel and has one z cell, so the fH rows of a pixel column at one depth bin mostly fall into the same
@@ -246,10 +253,11 @@ struct ColStep<FH, FH> {
 };
 
 template <int FH>
-__global__ __launch_bounds__(kBlock) void mghs_col_sums(Layout L, const float* __restrict__ depth, const float* __restrict__ feat) {
+__device__ __forceinline__ void col_sums_body(const Layout& L, const float* __restrict__ depth, const float* __restrict__ feat,
+                                              const int block) {
   const int lane = threadIdx.x & 63;
   const int n_chunks = (L.D + kDepthChunk - 1) / kDepthChunk;
-  const int wave = rfl((int)(blockIdx.x * (kBlock / DHD_WAVE) + (threadIdx.x >> 6)));
+  const int wave = rfl((int)(block * (kBlock / DHD_WAVE) + (threadIdx.x >> 6)));
   const int n_cols = L.B * L.N * L.fw;
   if (wave >= n_cols * n_chunks) return;
   // consecutive waves = consecutive columns of one camera and depth chunk (neighbouring columns hit neighbouring voxels)
@@ -282,6 +290,28 @@ __global__ __launch_bounds__(kBlock) void mghs_col_sums(Layout L, const float* _
     float acc = 0.f;
     ColStep<FH, 0>::run(f, firsts, slot[k], dvk, vrow, cur, acc);
     if (cur >= 0) atomicAdd(vrow + (size_t)cur * kTileC, acc);
+  }
+}
+
+template <int FH>
+__global__ __launch_bounds__(kBlock) void mghs_col_sums(Layout L, const float* __restrict__ depth, const float* __restrict__ feat) {
+  col_sums_body<FH>(L, depth, feat, (int)blockIdx.x);
+}
+
+// Round 6: the column sums of grid 0 and the sorted gather of the band grids touch disjoint slots
+// of vsum, so they can share one launch instead of running back to back (56 + 30 us at the DHD-L geometry, B = 2).  Groups of 8
+// consecutive workgroups (one per XCD: both bodies place their work by blockIdx & 7) alternate 2 : 1 between the two roles, so
+// that both kinds are resident together from start to end.  The merged kernel carries the gather's 84 registers.
+template <int FH>
+__global__ __launch_bounds__(kBlock) void mghs_sums_cols_bands(Layout L, const float* __restrict__ depth, const float* __restrict__ feat,
+                                                               int n_col_groups, int n_gather_groups, int kc) {
+  const int grp = rfl((int)(blockIdx.x >> 3)), x = (int)(blockIdx.x & 7);
+  const int period = grp / (kc + 1), r = grp - (kc + 1) * period;
+  if (r < kc) {
+    const int cg = kc * period + r;
+    if (cg < n_col_groups) col_sums_body<FH>(L, depth, feat, (cg << 3) | x);
+  } else if (period < n_gather_groups) {
+    gather_sums_body<true>(L, depth, feat, (period << 3) | x);
   }
 }
 
@@ -888,9 +918,20 @@ int dhd_mghs_forward_gather(const dhd_mghs_desc* desc, const float* depth, const
     hipLaunchKernelGGL(mghs_zero_grid0_rows, dim3(1024), dim3(kBlock), 0, st, L);
     const int waves = L.B * L.N * L.fw * dhd_cdiv(L.D, kDepthChunk);
     const dim3 grid(dhd_cdiv(waves, kBlock / DHD_WAVE));
-    hipLaunchKernelGGL(mghs_col_sums<32>, grid, dim3(kBlock), 0, st, L, depth, feat_nhwc);
-    // the band grids' entries: at most one per point
-    hipLaunchKernelGGL(mghs_gather_sums<true>, dim3(dhd_cdiv((long)L.P, 8 * kBlock) * 8), dim3(kBlock), 0, st, L, depth, feat_nhwc);
+    const int n_gather = dhd_cdiv((long)L.P, 8 * kBlock) * 8;   // the band grids' entries: at most one per point
+    // one launch for both (round 6; experiments/ab/run_merged_sums.sh, DHD-L geometry B = 2, MGHS-only step, alternating runs on one
+    // box: 0.479 / 0.475 / 0.483 ms separate -> 0.464 / 0.463 / 0.469 ms merged; interleave 1:1 and 2:1 equal, 3:1 and beyond worse).
+    // DHD_MGHS_SEPARATE_SUMS=1 keeps the two launches (A/B switch, read once)
+    static const bool merged = getenv("DHD_MGHS_SEPARATE_SUMS") == nullptr;
+    constexpr int kc = 2;
+    if (merged) {
+      const int ncg = dhd_cdiv(grid.x, 8), ngg = n_gather / 8;
+      const int periods = ((ncg + kc - 1) / kc) > ngg ? (ncg + kc - 1) / kc : ngg;
+      hipLaunchKernelGGL(mghs_sums_cols_bands<32>, dim3(periods * (kc + 1) * 8), dim3(kBlock), 0, st, L, depth, feat_nhwc, ncg, ngg, kc);
+    } else {
+      hipLaunchKernelGGL(mghs_col_sums<32>, grid, dim3(kBlock), 0, st, L, depth, feat_nhwc);
+      hipLaunchKernelGGL(mghs_gather_sums<true>, dim3(n_gather), dim3(kBlock), 0, st, L, depth, feat_nhwc);
+    }
   } else {
     // 2P is an upper bound of the entry count; waves past the real count exit at once
     hipLaunchKernelGGL(mghs_gather_sums<false>, dim3(dhd_cdiv(2L * L.P, 8 * kBlock) * 8), dim3(kBlock), 0, st, L, depth, feat_nhwc);
