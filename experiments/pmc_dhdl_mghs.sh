@@ -33,19 +33,21 @@ for k in sorted(acc, key=lambda k: -dur.get(k, 0)):
     vg, ag, sg, lds, wg, grid = meta[k]
     waves = c.get('SQ_WAVES', 0)
     wc = c.get('SQ_WAVE_CYCLES', 1)
-    alloc = (int(vg or 0) + 7) // 8 * 8
-    print(f'\n{k}: {dur.get(k, float("nan")):.1f} us | VGPR {vg} (alloc {alloc}: {min(8, 512 // max(alloc, 1))} waves/SIMD) SGPR {sg} LDS {lds} B  workgroup {wg} grid {grid}  waves {waves:.0f}')
+    regs = int(vg or 0) + int(ag or 0)           # arch + accumulation registers: one unified file on gfx950
+    alloc = (regs + 7) // 8 * 8
+    print(f'\n{k}: {dur.get(k, float("nan")):.1f} us | VGPR {vg} + AGPR {ag} (alloc {alloc}: {min(8, 512 // max(alloc, 1))} waves/SIMD by registers) SGPR {sg} LDS {lds} B  workgroup {wg} grid {grid}  waves {waves:.0f}')
     if 'SQ_WAVE_CYCLES' in c:
         print(f'   wave-cycles: active-inst {c.get("SQ_ACTIVE_INST_ANY", 0) / wc:.2f}  wait-any (s_waitcnt / barrier) {c.get("SQ_WAIT_ANY", 0) / wc:.2f}  '
               f'wait-inst-any (issue stall) {c.get("SQ_WAIT_INST_ANY", 0) / wc:.2f}  |  VALU insts/wave {c.get("SQ_INSTS_VALU", 0) / max(waves, 1):.0f}  '
               f'VMEM-read insts/wave {c.get("SQ_INSTS_VMEM_RD", 0) / max(waves, 1):.1f}')
-        if 'SQ_BUSY_CYCLES' in c and k in dur:
-            print(f'   mean resident waves per SIMD while busy ~ {4 * wc / max(c["SQ_BUSY_CYCLES"], 1) / 4:.2f} (4 x SQ_WAVE_CYCLES / SQ_BUSY_CYCLES per SE-sum; indicative)')
+        if k in dur:   # SQ_WAVE_CYCLES counts quad-cycles summed over waves: x 4 / (kernel time x clock x 1024 SIMDs) = mean waves per SIMD
+            clk = c.get('GRBM_GUI_ACTIVE', 0) / 8 / (dur[k] * 1e3) if 'GRBM_GUI_ACTIVE' in c else 2.1
+            print(f'   mean resident waves per SIMD over the kernel ~ {4 * wc / (dur[k] * 1e3 * clk * 1024):.2f}  (of 8)')
     if 'TCC_HIT_sum' in c:
         h, m_ = c['TCC_HIT_sum'], c.get('TCC_MISS_sum', 0)
         print(f'   L2: requests from L1 {c.get("TCP_TCC_READ_REQ_sum", 0):.3g}  hit rate {h / max(h + m_, 1):.3f}  fabric read requests {c.get("TCC_EA0_RDREQ_sum", 0):.3g}')
     if 'GRBM_GUI_ACTIVE' in c and k in dur:
-        print(f'   GRBM_GUI_ACTIVE {c["GRBM_GUI_ACTIVE"]:.3g} cycles -> effective clock {c["GRBM_GUI_ACTIVE"] / dur[k] / 1e3:.2f} GHz (under the profiler)  LDS insts/wave {c.get("SQ_INSTS_LDS", 0) / max(waves, 1):.0f}')
+        print(f'   GRBM_GUI_ACTIVE {c["GRBM_GUI_ACTIVE"]:.3g} cycles over 8 XCDs -> effective clock {c["GRBM_GUI_ACTIVE"] / 8 / dur[k] / 1e3:.2f} GHz (under the profiler)  LDS insts/wave {c.get("SQ_INSTS_LDS", 0) / max(waves, 1):.0f}')
 PY
 rm -rf /tmp/pd
 cat $OUT
