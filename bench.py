@@ -521,13 +521,14 @@ def resolve_ddp_graph(a, world):
 def e2e_measure(a, rank, world, dev, legs, model, warmup, steps, emit_partial=None, stub=False, want_util=False):
     """The whole-detector step, per leg (amp, tag, with_cp).  N = 1: eager + HIP-graph step.  N > 1, in this order:
       1. the SAME binary's single-GPU step on every rank at once (no DDP wrapper, no collective): eager and graphed -- the
-         like-for-like denominators of a scaling efficiency;
+         like-for-like denominators of a scaling efficiency (its eager step here, its graph step in 3);
       2. the DDP step eagerly (bucketed all-reduce overlapped with backward), each rank's own time next to the MAX, and the
          same under no_sync() -> exposed (non-overlapped) all-reduce time;
-      3. LAST, when asked for or by default over RCCL (resolve_ddp_graph): the DDP step captured into a HIP graph, under a
-         watchdog -- everything above is already in the record if the capture fails, poisons the context or hangs.
+      3. LAST, under a watchdog, every graph capture: the single-GPU graph steps, then -- when asked for or by default over RCCL
+         (resolve_ddp_graph) -- the DDP step captured into a HIP graph.  Every eager number above is already in the record if a
+         capture fails, poisons the context or hangs.
     Returns (out, scaling): `out[tag]` as before; `scaling` = the N > 1 summary that goes to the top level of the line."""
-    out, scaling, pending = {}, {}, []
+    out, scaling, pending, singles = {}, {}, [], []
     per_rank = {}
     backend = a.dist_backend if world > 1 else None
     try_ddp_graph = resolve_ddp_graph(a, world)
@@ -572,16 +573,19 @@ def e2e_measure(a, rank, world, dev, legs, model, warmup, steps, emit_partial=No
             for _ in range(warmup):
                 single.step(False)
             sg = dict(ms_per_step_eager=1e3 * timed(single, max(2, steps // 2)))
-            single.capture()
-            if single.graphed is not None:
-                sg['ms_per_step_graph'] = 1e3 * timed(single, steps)
-            if single.graph_error:
-                sg['hip_graph_error'] = single.graph_error
             sg['note'] = 'no DDP wrapper, no collective; every rank runs it at the same time, MAX over ranks'
             rec['single_gpu_same_binary'] = sg
-            del single
-            if torch.cuda.is_available():
-                torch.cuda.empty_cache()
+            # its HIP-graph step is measured AFTER every eager number of the record (phase 3 below): on the development box a graph
+            # capture in the process made the next DDP-over-gloo float32 step 100x slower (226 ms -> 24-35 s per step; fp16 unaffected;
+            # profiles/r6/two_rank_e2e_scaling_gloo.txt) -- whatever a capture does to the context, no eager measurement may come after one
+            if single.want_graph:
+                singles.append((tag, single))
+            else:
+                if single.graph_error:
+                    sg['hip_graph_error'] = single.graph_error
+                del single
+                if torch.cuda.is_available():
+                    torch.cuda.empty_cache()
         job, errs = guarded(lambda: make(amp, world, with_cp, ddp_graph=try_ddp_graph))
         if errs:
             out[tag] = dict(rec, error=errs)
@@ -612,6 +616,9 @@ def e2e_measure(a, rank, world, dev, legs, model, warmup, steps, emit_partial=No
             rec.update(allreduce_bytes=4 * job.n_params, bucket_mb=a.bucket_mb, static_graph=bool(a.ddp_static_graph))
             if job.graph_error:     # e.g. "not attempted: --ddp-graph needs RCCL"
                 rec['hip_graph_error'] = job.graph_error
+            elif not rec['ddp_graph_attempt']:
+                rec['hip_graph_error'] = 'not attempted: ' + ('--no-graph' if a.no_graph else '--no-ddp-graph' if a.ddp_graph is False else
+                                                              f'backend "{a.dist_backend}" is not RCCL (the default tries the capture over "nccl" only)')
             if rec['ddp_graph_attempt']:
                 pending.append((tag, job))
         if not with_cp:
@@ -654,14 +661,29 @@ def e2e_measure(a, rank, world, dev, legs, model, warmup, steps, emit_partial=No
                          'HIP graph, beside the single-GPU step of the same binary measured in the same process -- compare eager with eager and '
                          'graph with graph.  The top-level `value` of this line is the collective-free hot path and says nothing about the fabric.')
 
-    # 3. the DDP graph attempt, last, under the watchdog
-    if pending:
+    # 3. every graph capture of the N > 1 record, last, under the watchdog: the single-GPU graph steps, then the DDP graph attempt
+    if pending or singles:
         if emit_partial is not None:
             wd = Watchdog(a.ddp_graph_timeout, lambda why: emit_partial(out, dict(summary() or {}, ddp_graph_abandoned=why)))
         else:
             wd = Watchdog(a.ddp_graph_timeout, lambda why: None)
         fence()
         with wd:
+            for tag, single in singles:
+                sg = out[tag]['single_gpu_same_binary']
+                single.capture()
+                if ddist.gather_errors(single.graph_error):
+                    single.graphed = None
+                if single.graphed is not None:
+                    try:
+                        sg['ms_per_step_graph'] = 1e3 * timed(single, steps)
+                    except Exception as exc:  # noqa: BLE001
+                        sg['hip_graph_error'] = f'replay: {type(exc).__name__}: {exc}'[:300]
+                if single.graph_error:
+                    sg['hip_graph_error'] = single.graph_error
+            singles.clear()
+            if torch.cuda.is_available():
+                torch.cuda.empty_cache()
             for tag, job in pending:
                 rec = out[tag]
                 job.capture()

@@ -10,7 +10,7 @@ print('fresh', ['%.3f' % f['ms_per_step']['median'] for f in d.get('fresh_proces
 print('writer us %.1f  frac %.3f  of_fill %.3f  of_memset %.3f  fill us %.1f  memset us %.1f  read us %.1f  traffic %s' % (
     r['launch_ms'] * 1e3, r['frac'], r['frac_of_fill'], r['frac_of_memset'], r['fill_ms'] * 1e3, r['memset_ms'] * 1e3, r['read_ms'] * 1e3, r['traffic']))
 b = d['roofline_bwd']
-print('mghs backward us %.1f frac %.3f traffic %s' % (b['launch_ms'] * 1e3, b['frac'], b['traffic']))
+print('mghs backward us %.1f frac_effective %.3f frac_hbm %s traffic %s' % (b['launch_ms'] * 1e3, b.get('frac_effective', b.get('frac')), b.get('frac_hbm'), b['traffic']))
 print('sfa fwd %.3f bwd %.3f ms  traffic %s' % (s['launch_ms'], s['backward_ms'], s['traffic']))
 print('prepare', {k: round(v, 1) for k, v in d.get('prepare', {}).items() if k.endswith('_us')})
 a = d.get('hotpath_amp', {})
