@@ -511,6 +511,20 @@ class Watchdog:
         return False
 
 
+# set when a graph capture of the N > 1 record raised outside its own try blocks (a context left unusable by a failed capture):
+# the line is then printed from what was measured and the process leaves without the closing barrier (main, run_e2e)
+CAPTURE_TROUBLE = []
+
+
+def leave():
+    """ddist.shutdown(), unless a capture left the context in doubt: then no collective, no destructors, exit code 0."""
+    if CAPTURE_TROUBLE:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    ddist.shutdown()
+
+
 def resolve_ddp_graph(a, world):
     """--ddp-graph / --no-ddp-graph / neither (= try when the backend is RCCL)."""
     if world == 1 or a.no_graph:
@@ -668,38 +682,48 @@ def e2e_measure(a, rank, world, dev, legs, model, warmup, steps, emit_partial=No
         else:
             wd = Watchdog(a.ddp_graph_timeout, lambda why: None)
         fence()
-        with wd:
-            for tag, single in singles:
-                sg = out[tag]['single_gpu_same_binary']
-                single.capture()
-                if ddist.gather_errors(single.graph_error):
-                    single.graphed = None
-                if single.graphed is not None:
+        try:
+            with wd:
+                for tag, single in singles:
+                    sg = out[tag]['single_gpu_same_binary']
+                    single.capture()
+                    if ddist.gather_errors(single.graph_error):
+                        single.graphed = None
+                    if single.graphed is not None:
+                        try:
+                            sg['ms_per_step_graph'] = 1e3 * timed(single, steps)
+                        except Exception as exc:  # noqa: BLE001
+                            sg['hip_graph_error'] = f'replay: {type(exc).__name__}: {exc}'[:300]
+                    if single.graph_error:
+                        sg['hip_graph_error'] = single.graph_error
+                singles.clear()
+                if torch.cuda.is_available():
+                    torch.cuda.empty_cache()
+                for tag, job in pending:
+                    rec = out[tag]
+                    # torch's notes on DDP under graph capture ask for >= 11 DDP-enabled eager iterations before it (bucket rebuild,
+                    # static-graph bookkeeping): warm-up + timed steps so far are 3 + 5 (+ the no_sync ones); 8 more
+                    for _ in range(8):
+                        job.step(False)
+                    job.capture()
+                    failed = ddist.gather_errors(job.graph_error)   # a capture that failed on one rank only: every rank stays eager
+                    if failed:
+                        job.graphed = None
+                        rec['hip_graph_error'] = failed
+                        continue
                     try:
-                        sg['ms_per_step_graph'] = 1e3 * timed(single, steps)
+                        g = timed(job, steps)
+                        rec.update(ms_per_step_graph=1e3 * g, hip_graph=True, ms_per_step=1e3 * g, samples_per_s=a.batch * world / g)
                     except Exception as exc:  # noqa: BLE001
-                        sg['hip_graph_error'] = f'replay: {type(exc).__name__}: {exc}'[:300]
-                if single.graph_error:
-                    sg['hip_graph_error'] = single.graph_error
-            singles.clear()
-            if torch.cuda.is_available():
-                torch.cuda.empty_cache()
-            for tag, job in pending:
-                rec = out[tag]
-                job.capture()
-                failed = ddist.gather_errors(job.graph_error)   # a capture that failed on one rank only: every rank stays eager
-                if failed:
-                    job.graphed = None
-                    rec['hip_graph_error'] = failed
-                    continue
-                try:
-                    g = timed(job, steps)
-                    rec.update(ms_per_step_graph=1e3 * g, hip_graph=True, ms_per_step=1e3 * g, samples_per_s=a.batch * world / g)
-                except Exception as exc:  # noqa: BLE001
-                    rec['hip_graph_error'] = f'replay: {type(exc).__name__}: {exc}'[:300]
-                    break
+                        rec['hip_graph_error'] = f'replay: {type(exc).__name__}: {exc}'[:300]
+                        break
+        except Exception as exc:  # noqa: BLE001 -- e.g. a collective that fails because a capture left the context unusable
+            CAPTURE_TROUBLE.append(f'{type(exc).__name__}: {exc}'[:300])
         pending.clear()
-    return out, summary(), n_params
+    sc = summary()
+    if CAPTURE_TROUBLE and sc is not None:
+        sc['graph_phase_abandoned'] = CAPTURE_TROUBLE[0]
+    return out, sc, n_params
 
 
 E2E_WORKLOAD = {'dhd-m': 'DHD-M (DHD_stereo: key + adjacent + stereo reference frame, D=88) whole detector: ResNet-50 + FPN',
@@ -744,7 +768,7 @@ def run_e2e(a, rank, world, dev):
     if tag in out and isinstance(out[tag], dict):
         out[tag]['n_params'] = n_params
     emit(out, scaling)
-    ddist.shutdown()
+    leave()
 
 
 def hbm_calibration(dev, nbytes, reps=20, warmup=3):
@@ -1547,7 +1571,7 @@ def main():
     if rank == 0:
         line['event_samples_dropped'] = dict(EVENT_DROPS)   # event intervals event_mean() left out as host stalls (> 3 x median)
         print(json.dumps(line), flush=True)
-    ddist.shutdown()
+    leave()
 
 
 def fresh_process_repeats(a, n=None, geometry=None, batch=None, no_sfa=None):
