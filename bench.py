@@ -398,6 +398,12 @@ class EndToEnd:
             mask_camera=(torch.rand(batch, 200, 200, 16, generator=g) < 0.3).to(dev))
         self.amp = {'off': None, 'bf16': torch.bfloat16, 'fp16': torch.float16}[amp]
         self.scaler = torch.amp.GradScaler('cuda') if amp == 'fp16' else None
+        # persistent half copies of the convolution / linear weights, refreshed by one multi-tensor copy after the optimizer step,
+        # instead of autocast's cast per weight and forward (and once more in the checkpointed recomputation): dhd_amd/amp_weights.py.
+        # After the EMA's deepcopy on purpose (a copy made later would fall back to autocast's path anyway).  DHD_NO_HALF_WEIGHT_CACHE=1: A/B
+        self.wcache = None
+        if self.amp is not None and not os.environ.get('DHD_NO_HALF_WEIGHT_CACHE'):
+            self.wcache = dhd_amd.HalfWeightCache(self.model, self.amp)
         self.B = batch
         self.graphed = None
         self.graph_error = None
@@ -471,6 +477,8 @@ class EndToEnd:
             loss.backward()
             torch.nn.utils.clip_grad_norm_(self.params, 5.0)  # DHD-S.py:263
             self.opt.step()
+        if getattr(self, 'wcache', None) is not None:
+            self.wcache.refresh()
         if self.ema is not None:
             self.ema.update(None, self.model)
         return loss

@@ -15,5 +15,6 @@ from .swin import SwinTransformer  # noqa: F401
 from .ema import ModelEMA, MEGVIIEMAHook, SyncbnControlHook, SequentialControlHook  # noqa: F401
 from .config import Config  # noqa: F401
 from .checkpoint import load_checkpoint, load_state_dict, save_checkpoint  # noqa: F401
+from .amp_weights import HalfWeightCache  # noqa: F401
 
 __version__ = '0.1.0'

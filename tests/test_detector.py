@@ -181,6 +181,70 @@ def test_dhd_step_in_channels_last_equals_the_nchw_step(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_half_weight_cache_equals_autocast_bit_for_bit(gpu, dtype):
+    """dhd_amd.HalfWeightCache: the reduced DHD-S under autocast with persistent half weights against the same model under plain
+    autocast -- identical losses and identical float32 gradients (the half copy IS what autocast's cast produces), over two steps
+    with an optimizer step and refresh() between them; a stale copy (step without refresh), a load_state_dict and a deepcopy of
+    the model all fall back to autocast's own path and still give the plain model's numbers."""
+    import copy
+    import dhd_amd
+    from dhd_amd.detector import dhd_s_model_cfg
+    torch.manual_seed(0)
+    vt = dict(syn.dhd_s_config(), type='MGHS', input_size=(64, 176))
+    ref = dhd_amd.build_detector(dhd_s_model_cfg(img_view_transformer=vt)).to(gpu).train().use_channels_last()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    ours = copy.deepcopy(ref)
+    cache = dhd_amd.HalfWeightCache(ours, dtype)
+    n_routed = len(cache)
+    n_plain = sum(1 for m in ours.modules() if type(m) in (torch.nn.Conv2d, torch.nn.ConvTranspose2d, torch.nn.Linear))
+    assert n_routed >= 0.9 * n_plain and n_routed > 150, (n_routed, n_plain)
+    assert set(ours.state_dict()) == set(ref.state_dict())          # the copies are not buffers
+    B, N = 1, 2
+    calib = [T(a, gpu) for a in syn.make_calibration(3, B, N, (64, 176))]
+    imgs = torch.randn(B, N, 3, 64, 176, device=gpu)
+    gt_d = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, 1 + 40 * syn.hash_uniform(2, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    gt_h = T(np.where(syn.hash_uniform(1, (B, N, 64, 176)) < 0.05, -1 + 6 * syn.hash_uniform(3, (B, N, 64, 176)), 0).astype(np.float32), gpu)
+    sem = torch.randint(0, 18, (B, 200, 200, 16), device=gpu)
+    cam = torch.rand(B, 200, 200, 16, device=gpu) < 0.3
+    kw = dict(return_loss=True, img_inputs=[imgs] + calib, gt_depth=gt_d, gt_height=gt_h, voxel_semantics=sem, mask_camera=cam)
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-3) for m in (ref, ours)]
+
+    def step(model):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=dtype):
+            losses = model(**kw)
+        sum(losses.values()).backward()
+        return {k: float(v) for k, v in losses.items()}
+
+    def same(tag):
+        la, lb = step(ref), step(ours)
+        assert la == lb, (tag, la, lb)
+        for (k, p), q in zip(ref.named_parameters(), ours.parameters()):
+            if p.grad is None:
+                assert q.grad is None, k
+            else:
+                assert q.grad.dtype == torch.float32 and torch.equal(p.grad, q.grad), (tag, k)
+
+    same('first step')
+    for o in opts:
+        o.step()
+    same('stale copies after the optimizer step: every routed layer falls back')
+    cache.refresh()
+    same('refreshed')
+    ours.load_state_dict(ref.state_dict())
+    same('after load_state_dict, before a refresh')
+    clone = copy.deepcopy(ours)          # its routed forwards are bound to ITS modules, its copies belong to other parameter tensors
+    with torch.autocast('cuda', dtype=dtype):
+        la, lb = ref(**kw), clone(**kw)
+    assert {k: float(v) for k, v in la.items()} == {k: float(v) for k, v in lb.items()}
+    cache.remove()
+    assert all('forward' not in m.__dict__ for m in ours.modules())
+
+
+@pytest.mark.gpu
 def test_dhd_stereo_forward_train_and_simple_test_on_gpu(gpu):
     """DHD-M wiring (temporal stereo: key frame + one adjacent frame + one stereo reference frame, D = 88,
     uncollapsed band tensors, SFA with C = 512) through forward_train + backward and simple_test on reduced images."""
