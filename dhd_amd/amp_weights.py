@@ -12,7 +12,7 @@ per step).  The casts all produce the same thing: the rounded image of a paramet
 
 `UseHalf` returns the half copy (no kernel) and hands its gradient back to the float32 parameter as float32 -- the same node
 autocast's own cast creates, so `.grad`, gradient clipping, `GradScaler`, DDP's bucket hooks and the optimizer see what they
-see without the cache.  The values are bit for bit those of autocast's cast (`tests/test_detector.py`).
+see without the cache.  A routed layer's output is bit for bit the plain layer's under autocast (`tests/test_detector.py`).
 
 Only plain `nn.Conv2d` / `nn.ConvTranspose2d` / `nn.Linear` forwards are routed (a subclass with its own `forward` keeps
 autocast's path), only while autocast with the cache's dtype is active and the input is a GPU tensor, and only while the copy is
