@@ -279,14 +279,21 @@ def test_half_weight_cache_on_the_reduced_detector(gpu):
         sum(losses.values()).backward()
         return {k: float(v.detach()) for k, v in losses.items()}
 
-    la, lb = step(ref), step(ours)
-    for k in la:
-        assert abs(la[k] - lb[k]) <= 5e-3 * abs(la[k]) + 1e-4, (k, la[k], lb[k])
+    names = ('occ_head.predicter.0.weight', 'img_voxel_encoder0.inc.double_conv.0.weight')
     pa, pb = dict(ref.named_parameters()), dict(ours.named_parameters())
-    for name, tol in (('occ_head.predicter.0.weight', 2e-2), ('img_voxel_encoder0.inc.double_conv.0.weight', 2e-1)):
-        ga, gb = pa[name].grad.double(), pb[name].grad.double()
-        assert pb[name].grad.dtype == torch.float32 and torch.isfinite(gb).all()
-        assert float((ga - gb).norm() / ga.norm()) < tol, (name, float((ga - gb).norm() / ga.norm()))
+    la0 = step(ref)
+    g0 = {n: pa[n].grad.double().clone() for n in names}
+    la, lb = step(ref), step(ours)                      # a second run of the plain model = the step's own run-to-run spread
+    rel = lambda a, b: float((a - b).norm() / a.norm())
+    for k in la:
+        spread = abs(la0[k] - la[k])
+        assert abs(la[k] - lb[k]) <= 3 * spread + 5e-3 * abs(la[k]) + 1e-4, (k, la0[k], la[k], lb[k])
+    for n in names:
+        ga, gb = pa[n].grad.double(), pb[n].grad.double()
+        assert pb[n].grad.dtype == torch.float32 and torch.isfinite(gb).all()
+        spread, diff = rel(g0[n], ga), rel(ga, gb)
+        print(f'{n}: plain vs plain {spread:.3e}, plain vs cache {diff:.3e}')
+        assert diff <= 3 * spread + 2e-2, (n, spread, diff)
 
 
 @pytest.mark.gpu
