@@ -184,7 +184,13 @@ class ASPP(nn.Module):
 
     def forward(self, x):
         branches = [self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x)]
-        pooled = self.global_avg_pool(x)
+        pooled = self.global_avg_pool[1](self.global_avg_pool[0](x))          # AdaptiveAvgPool2d((1, 1)) -> 1x1 conv
+        if pooled.shape[2:] == (1, 1) and pooled.stride() != (pooled.shape[1], 1, 1, 1):   # (is_contiguous() ignores size-1 axes)
+            # a channels_last convolution returns the (N, C, 1, 1) map with strides (C, 1, C, C); MIOpen's half-precision training
+            # BatchNorm SEGFAULTS on that at N = 2 (experiments/bn_1x1_crash_probe.py: plain strides, float32 or N = 24 are fine).
+            # The same bytes with plain strides:
+            pooled = pooled.reshape(pooled.shape[0], pooled.shape[1]).reshape(pooled.shape)
+        pooled = self.global_avg_pool[3](self.global_avg_pool[2](pooled))     # BatchNorm -> ReLU
         # F.interpolate(pooled, size, 'bilinear', align_corners=True) of a 1 x 1 map (mmdet3d depthnet ASPP.forward) is that value
         # everywhere (scale 0: cell 0, lambda 0) -- a broadcast view instead of a float32 up-sampling kernel under autocast
         if pooled.shape[2:] == (1, 1):

@@ -2,6 +2,8 @@
 Everything here needs a real MI355X:  python -m pytest tests -m gpu"""
 import hashlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1843,6 +1845,22 @@ def test_dcn_module_under_autocast_uses_half_columns(gpu, dtype):
     errs = dict(y=rel(ya, yb), x_grad=rel(xa.grad, xb.grad), **{k: rel(p.grad, q.grad) for (k, p), q in zip(a.named_parameters(), b.parameters())})
     print(dtype, {k: round(v, 4) for k, v in errs.items()})
     assert errs['y'] < tol and all(v < 12 * tol for v in errs.values()), errs
+
+
+def test_aspp_half_channels_last_two_images_does_not_crash(gpu):
+    """MIOpen's half-precision training BatchNorm segfaults on an (N, C, 1, 1) map with channels_last strides at N = 2
+    (experiments/bn_1x1_crash_probe.py): ASPP's global-pool branch hands its BatchNorm plain strides.  In a subprocess, so that a
+    regression fails the test instead of killing the session."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch\nfrom dhd_amd.depthnet import ASPP\n"
+            "m = ASPP(64, 64).cuda().train().to(memory_format=torch.channels_last)\n"
+            "x = torch.randn(2, 64, 4, 11, device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_()\n"
+            "with torch.autocast('cuda', dtype=torch.float16):\n    y = m(x)\n"
+            "y.float().sum().backward(); torch.cuda.synchronize(); print('ok', tuple(y.shape))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'ok (2, 64, 4, 11)' in out.stdout, (out.returncode, out.stderr[-400:])
 
 
 # --------------------------------------------------------------------------- softmax(depth), context, softmax(height), band: one launch (a11)
